@@ -1,0 +1,177 @@
+/*
+ * wcn.h - C-ABI of the MI355X (gfx950) sparse-3D-convolution engine.
+ *
+ * This is the drop-in boundary for the SparseConv3d hot path: every entry point replaces one
+ * binding of the reference's pybind11 module `warpconvnet._C` (the file:line cited at each
+ * declaration is relative to the reference tree).  Conventions:
+ *
+ *   - plain C: raw device pointers, sizes, and a `hipStream_t` passed as `void*`; no torch types;
+ *   - the CALLER allocates every buffer (outputs, workspaces); the library never allocates or frees
+ *     device memory and keeps no global mutable state -> re-entrant and graph-capturable;
+ *   - every launch goes to the stream argument and is asynchronous; nothing here synchronises;
+ *   - return value: 0 on success, negative `wcn_status` otherwise (same numbering as the reference's
+ *     `GemmStatus`, warpconvnet/csrc/include/gemm_error_codes.h:7-15);
+ *   - data-dependent failures (hash table full, coordinate out of packed range, pair-buffer
+ *     overflow) are reported through a device status word the caller reads back when it chooses
+ *     (reference: warpconvnet/geometry/coords/search/_packed_base.py:113-120).
+ *
+ * All index tensors are int32.  Feature tensors are row-major [N, C].
+ */
+#ifndef WCN_H_
+#define WCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wcn_stream_t; /* hipStream_t */
+
+/* Status codes: numbering of reference GemmStatus (include/gemm_error_codes.h:7-15). */
+enum wcn_status {
+  WCN_SUCCESS = 0,
+  WCN_ERROR_PROBLEM_NOT_SUPPORTED = -1,
+  WCN_ERROR_KERNEL_INITIALIZATION = -2,
+  WCN_ERROR_KERNEL_EXECUTION = -3,
+  WCN_ERROR_UNSUPPORTED_CONFIG = -4,
+  WCN_ERROR_INVALID_PARAMETERS = -5,
+  WCN_ERROR_MIXED_INPUT_UNSUPPORTED = -6
+};
+
+enum wcn_dtype { WCN_F32 = 0, WCN_F16 = 1, WCN_BF16 = 2 };
+
+/* Bits of the device status word written by the kernel-map kernels. */
+enum wcn_kmap_flag {
+  WCN_FLAG_TABLE_FULL = 1,      /* hash insert ran out of slots   (reference hash_table.cuh:60-62)   */
+  WCN_FLAG_COORD_RANGE = 2,     /* batch not in [0,511] or coord not in [-131072,131071]
+                                   (reference packed_hashmap.py:66-82 raises ValueError)            */
+  WCN_FLAG_PAIR_OVERFLOW = 4    /* in_maps/out_maps capacity smaller than the number of pairs       */
+};
+
+/* ---- misc ------------------------------------------------------------------------------------ */
+int wcn_abi_version(void);
+/* reference: _C.gemm.gemm_status_to_string (bindings/gemm_bindings.cpp) */
+const char* wcn_status_string(int status);
+
+/* ---- packed 64-bit coordinate hash table -------------------------------------------------------
+ * Key = 1<<63 | batch(9b)<<54 | x(18b)<<36 | y(18b)<<18 | z(18b)   (reference hash_functions.cuh:40-44)
+ * Slot = 16 bytes {uint64 key, int32 value, int32 pad}: one 16-B load per probe returns key AND
+ * value (the reference keeps two arrays -> two random loads per hit).  Empty key = 0, value = row
+ * index of the inserted coordinate; duplicates keep the SMALLEST row index (deterministic; the
+ * reference keeps whichever CAS wins, hash_table.cuh:36-63).  Splitmix64 & (capacity-1), linear
+ * probing (hash_functions.cuh:75-84, hash_table.cuh:94-108).  capacity must be a power of two.
+ */
+/* reference: _C.cuhash.packed_prepare (bindings/cuhash_bindings.cpp:244-262, cuhash_hash_table.cu:19-25) */
+int wcn_hash_prepare(void* slots, int64_t capacity, wcn_stream_t stream);
+/* reference: _C.cuhash.packed_insert (cuhash_hash_table.cu:179-220); coords int32 [n,4]; status int32[1] (OR of wcn_kmap_flag) */
+int wcn_hash_insert(void* slots, int64_t capacity, const int32_t* coords, int64_t n, int32_t* status,
+                    wcn_stream_t stream);
+/* reference: _C.cuhash.packed_search (cuhash_hash_table.cu:222-262); results int32 [m], -1 on miss */
+int wcn_hash_search(const void* slots, int64_t capacity, const int32_t* queries, int64_t m,
+                    int32_t* results, wcn_stream_t stream);
+
+/* ---- kernel map ----------------------------------------------------------------------------------
+ * Neighbour table layout is ROW-major: nbr[m*kp + k] = input row matched by output row m at kernel
+ * offset k, or -1 (kp = wcn_kmap_row_pitch(K), rows are 32-B aligned so a tile of rows is one
+ * contiguous slab).  The reference's `found_in_coord_index` is the transpose [K, M]
+ * (cuhash_kernel_map.cu:93-134); `wcn_kmap_transpose` converts for consumers that want that layout.
+ * Kernel offset enumeration: k = (i*ky + j)*kz + l -> offset ((i-cx)*dx, (j-cy)*dy, (l-cz)*dz) with
+ * c = (size-1)/2 for odd sizes and 0 for even sizes (torch_discrete.py:24-56, kernel_map.cuh:34-54).
+ * Query coordinate = out_coord * stride (torch_discrete.py:352-361).
+ */
+int32_t wcn_kmap_row_pitch(int32_t num_offsets);
+int32_t wcn_kmap_mask_words(int32_t num_offsets);
+/* number of count blocks the probe kernel uses for m query rows (rows of block_counts) */
+int64_t wcn_kmap_num_blocks(int64_t m);
+
+/* reference: _C.cuhash.packed_kernel_map_size + packed_kernel_map_offset (cuhash_kernel_map.cu:68-134)
+ * fused with build_pair_mask (mask_data_kernels.cu:23-44) and the per-offset count of
+ * postprocess_count (cuhash_kernel_map.cu:508-544).
+ *   query   int32 [m,4]      mask         uint32 [m, mask_words]  (bit k <=> nbr[m][k] >= 0)
+ *   nbr     int32 [m,kp]     block_counts int32  [num_blocks, K]  (valid pairs per block of rows)
+ */
+int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, int64_t m,
+                   const int32_t ksize[3], const int32_t stride[3], const int32_t dilation[3],
+                   int32_t* nbr, uint32_t* mask, int32_t* block_counts, wcn_stream_t stream);
+/* exclusive scan of block_counts over blocks (in place) and over offsets -> offsets int32 [K+1].
+ * reference: host torch.cumsum in torch_discrete.py:268-272. */
+int wcn_kmap_scan(int32_t* block_counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
+                  wcn_stream_t stream);
+/* deterministic compaction (pairs of one offset ordered by output row).
+ * reference: _C.cuhash.postprocess_scatter (cuhash_kernel_map.cu:546-599, order there is racy).
+ * pair_capacity = length of in_maps/out_maps; sets WCN_FLAG_PAIR_OVERFLOW in *status if too small. */
+int wcn_kmap_scatter(const int32_t* nbr, int64_t m, int32_t num_offsets, const int32_t* block_counts,
+                     const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
+                     int32_t* status, wcn_stream_t stream);
+/* nbr [m,kp] -> pair_table [K,m]   (the reference layout, cuhash_kernel_map.cu:133) */
+int wcn_kmap_transpose(const int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* pair_table,
+                       wcn_stream_t stream);
+/* reverse table for dgrad of strided / transposed maps: rev_nbr[in][k] = out, rev_mask bit k.
+ * The call itself pre-fills rev_nbr with -1 and rev_mask with 0.  `max_pairs` bounds the launch
+ * (length of in_maps/out_maps); the true pair count is read from offsets[K] on the device.
+ * reference: _C.gemm.build_reverse_mask_data_cuda (mask_data_kernels.cu:101-124). */
+int wcn_kmap_reverse(const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets,
+                     int32_t num_offsets, int64_t max_pairs, int64_t n_in, int32_t* rev_nbr,
+                     uint32_t* rev_mask, wcn_stream_t stream);
+/* reference: _C.gemm.csr_to_pair_table_cuda + build_pair_mask_cuda (mask_data_kernels.cu:23-82):
+ * rebuild nbr/mask from a CSR map (used for maps that were swapped for transposed conv). */
+int wcn_kmap_from_csr(const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets,
+                      int32_t num_offsets, int64_t max_pairs, int64_t n_out, int32_t* nbr, uint32_t* mask,
+                      wcn_stream_t stream);
+/* permutation of rows sorted by descending mask word 0 (rows with equal neighbourhood pattern become
+ * adjacent so a wavefront can skip absent offsets).  reference: _C.gemm.mask_argsort_cuda
+ * (mask_data_kernels.cu:187-220, CUB radix sort).  Stable (ties keep ascending row order).
+ * workspace: wcn_mask_argsort_workspace(n) bytes. */
+size_t wcn_mask_argsort_workspace(int64_t n);
+int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int64_t n, int32_t* perm,
+                     void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+
+/* ---- sparse convolution GEMMs ------------------------------------------------------------------
+ * Forward  (AB gather-scatter):  y[m]  = sum_k x[nbr[m][k]] . w[k]            w: [K, Cin, Cout]
+ * Dgrad    (ABt gather-scatter): dx[n] = sum_k dy[rnbr[n][k]] . w[k]^T
+ * Wgrad    (AtB gather-gather):  dw[k] = sum_p x[in_maps[p]]^T . dy[out_maps[p]],  p in bucket k
+ * reference semantics: nn/functional/sparse_conv/detail/explicit.py:22-101; fused production kernels
+ * _C.mask_gemm.fwd/.dgrad/.wgrad (bindings/mask_gemm_bindings.cu:2071-2123).
+ *
+ * `algo`: 1 = hip_ref (any channel count / dtype), 2 = hip_mfma (bf16/f16; forward/dgrad: Cin%16==0,
+ * Cout in {32,64,96,128,256}, K<=32; wgrad: Cin%64==0, Cout%64==0; WCN_ERROR_UNSUPPORTED_CONFIG
+ * otherwise).  0 (auto) is resolved by the caller with wcn_mfma_*_supported because the two algorithms
+ * take different weight images.  Accumulation is always fp32.
+ */
+enum wcn_algo { WCN_ALGO_AUTO = 0, WCN_ALGO_REF = 1, WCN_ALGO_MFMA = 2 };
+
+/* 1 if the MFMA kernels cover the shape (so the caller can resolve "auto" without a trial launch). */
+int wcn_mfma_gather_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype);
+int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype);
+
+/* Packed weight image consumed by the MFMA kernels (fragment order, zero padding).  `transpose`=1
+ * packs w[k]^T (dgrad); `flip`=1 additionally reverses k (dgrad of a submanifold map reuses the
+ * forward table: rnbr[n][k] == nbr[n][K-1-k]).  Returns bytes needed / fills `packed`. */
+size_t wcn_packed_weight_bytes(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose);
+int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype,
+                    int32_t transpose, int32_t flip, void* packed, wcn_stream_t stream);
+
+/* y = gather-GEMM over a neighbour table.  Serves forward (x, packed w) and dgrad (dy, packed w^T).
+ *   in   [n_in, cin]   out [n_out, cout]   nbr [n_out, kp]   mask [n_out, mw]   perm [n_out] or NULL
+ *   w:   for WCN_ALGO_REF the plain [K, cin, cout] tensor (or [K, cout', cin'] with w_transposed=1),
+ *        for WCN_ALGO_MFMA the image made by wcn_pack_weight.
+ * reference: _C.mask_gemm.fwd / .dgrad (mask_gemm_bindings.cu:2074-2101). */
+int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t* nbr,
+                         const uint32_t* mask, const int32_t* perm, int64_t n_in, int64_t n_out,
+                         int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype, int32_t algo,
+                         int32_t w_transposed, int32_t k_flip, wcn_stream_t stream);
+
+/* dw [K, cin, cout] fp32 (overwritten).  workspace: wcn_conv_wgrad_workspace(...) bytes.
+ * reference: _C.mask_gemm.wgrad (mask_gemm_bindings.cu:2103-2116), fp32 output. */
+size_t wcn_conv_wgrad_workspace(int32_t num_offsets, int32_t cin, int32_t cout, int32_t algo);
+int wcn_conv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps,
+                   const int32_t* out_maps, const int32_t* offsets, int64_t n_in, int64_t n_out,
+                   int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype, int32_t algo,
+                   void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WCN_H_ */

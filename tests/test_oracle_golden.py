@@ -1,0 +1,142 @@
+"""CPU: the oracle against the golden vectors produced by the reference itself, and against itself."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import brute, conv, kmap
+from tests.util import scene_u
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_offset_tables_match_reference(golden_dir):
+    g = _load(golden_dir, "offset_tables.npz")
+    assert len(g.files) == 10
+    for name in g.files:
+        ks = tuple(int(c) for c in name[1:4])
+        dl = tuple(int(c) for c in name[6:9])
+        ref = g[name]
+        assert ref.shape == (int(np.prod(ks)), 4)
+        assert (ref[:, 0] == 0).all()
+        np.testing.assert_array_equal(brute.kernel_offsets(ks, dl), ref[:, 1:])
+    t = g["k333_d111"]
+    assert t[0].tolist() == [0, -1, -1, -1] and t[13].tolist() == [0, 0, 0, 0] and t[26].tolist() == [0, 1, 1, 1]
+    assert g["k222_d111"][-1].tolist() == [0, 1, 1, 1]  # even kernels probe {0, 1}
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "explicit_*.npz"))))
+def test_conv_oracle_matches_reference_explicit(golden_dir, name):
+    g = _load(golden_dir, name)
+    iden = int(g["identity"])
+    iden = None if iden < 0 else iden
+    Y = conv.forward(g["X"], g["W"], g["in_maps"], g["out_maps"], g["offsets"], g["out_coords"].shape[0], iden)
+    dX, dW = conv.backward(g["dY"], g["X"], g["W"], g["in_maps"], g["out_maps"], g["offsets"], iden)
+    tol = 1e-12 if g["X"].dtype == np.float64 else 1e-6
+    for got, want in ((Y, g["Y"]), (dX, g["dX"]), (dW, g["dW"])):
+        want = torch.from_numpy(want)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+
+
+def test_kmap_oracle_reproduces_golden_maps(golden_dir):
+    """The maps stored in the fixtures were made by the brute-force builder; the C restatement must agree."""
+    for name in ("explicit_u2048_16x32_f32.npz", "explicit_b2_7x13_f32_noiden.npz", "explicit_stride2_k2_16x32_f32.npz"):
+        g = _load(golden_dir, name)
+        r = kmap.kernel_map(g["in_coords"], g["out_coords"], g["ksize"], g["stride"])
+        np.testing.assert_array_equal(r["offsets"], g["offsets"])
+        np.testing.assert_array_equal(r["in_maps"], g["in_maps"])
+        np.testing.assert_array_equal(r["out_maps"], g["out_maps"])
+
+
+def test_known_answer_patterns(golden_dir):
+    from tests.golden.make_golden import make_feats, make_grad_out, make_weight
+
+    g = _load(golden_dir, "known_answer.npz")
+    n = g["coords"].shape[0]
+    for cin, cout in [(8, 8), (7, 13), (32, 16)]:
+        for wp in ["ones", "triu", "tril", "eye", "center_eye"]:
+            for fp in ["ones", "range", "row_index"]:
+                W = make_weight(27, cin, cout, wp, torch.float64)
+                X = make_feats(n, cin, fp, torch.float64)
+                dY = make_grad_out(n, cout, torch.float64)
+                Y = conv.forward(X, W, g["in_maps"], g["out_maps"], g["offsets"], n, 13)
+                dX, dW = conv.backward(dY, X, W, g["in_maps"], g["out_maps"], g["offsets"], 13)
+                tag = f"{cin}x{cout}_{wp}_{fp}"
+                np.testing.assert_allclose(Y.numpy(), g[f"Y_{tag}"], rtol=1e-6, atol=1e-6)
+                np.testing.assert_allclose(dX.numpy(), g[f"dX_{tag}"], rtol=1e-6, atol=1e-6)
+                np.testing.assert_allclose(dW.numpy(), g[f"dW_{tag}"], rtol=1e-6, atol=1e-5)
+    # analytic check: centre-identity weight on a submanifold map is a pass-through
+    Y = conv.forward(make_feats(n, 8, "row_index", torch.float64), make_weight(27, 8, 8, "center_eye", torch.float64),
+                     g["in_maps"], g["out_maps"], g["offsets"], n, 13)
+    np.testing.assert_allclose(Y.numpy(), make_feats(n, 8, "row_index", torch.float64).numpy())
+
+
+@pytest.mark.parametrize("ksize,stride", [((3, 3, 3), (1, 1, 1)), ((2, 2, 2), (2, 2, 2)), ((3, 3, 3), (2, 2, 2)), ((5, 5, 5), (1, 1, 1)), ((3, 1, 2), (1, 1, 1))])
+def test_kmap_oracle_vs_bruteforce_and_invariants(ksize, stride):
+    """No missing / no spurious pairs, invariant in = stride*out + offset[k], exactly-once coverage
+    (reference tests/coords/test_kernel_map_invariants.py:94-277)."""
+    a = np.concatenate([scene_u(400, 7, 0), scene_u(350, 8, 1)], 0)
+    out = a if all(s == 1 for s in stride) else kmap.stride_coords(a, stride)[0]
+    r = kmap.kernel_map(a, out, ksize, stride)
+    f, o, i, om = brute.kernel_map(a, out, ksize, stride)
+    np.testing.assert_array_equal(r["found"], f)
+    np.testing.assert_array_equal(r["offsets"], o)
+    np.testing.assert_array_equal(r["in_maps"], i)
+    np.testing.assert_array_equal(r["out_maps"], om)
+    offs = brute.kernel_offsets(ksize)
+    K = len(offs)
+    assert r["offsets"][-1] == len(r["in_maps"]) == len(r["out_maps"])
+    st = np.asarray(stride)
+    for k in range(K):
+        s, e = r["offsets"][k], r["offsets"][k + 1]
+        ii, oo = r["in_maps"][s:e], r["out_maps"][s:e]
+        np.testing.assert_array_equal(a[ii, 1:], out[oo, 1:] * st + offs[k])
+        np.testing.assert_array_equal(a[ii, 0], out[oo, 0])  # never across batch elements
+        assert len(np.unique(oo)) == len(oo)  # an output row appears at most once per offset
+        assert (np.diff(oo) > 0).all()  # canonical order
+    # mask and reverse table are consistent with found
+    for k in range(K):
+        np.testing.assert_array_equal((r["mask"][:, k // 32] >> (k % 32)) & 1, (r["found"][k] >= 0).astype(np.uint32))
+        rows = np.nonzero(r["found"][k] >= 0)[0]
+        np.testing.assert_array_equal(r["rev"][k][r["found"][k][rows]], rows)
+    if all(s == 1 for s in stride) and all(k % 2 == 1 for k in ksize):
+        np.testing.assert_array_equal(r["rev"], r["found"][::-1])  # submanifold symmetry used by dgrad
+        np.testing.assert_array_equal(r["found"][K // 2], np.arange(len(a)))
+
+
+def test_hash_table_contract():
+    """Value = insertion row index, -1 on miss, duplicates keep the first, bounds, capacity rule
+    (reference tests/coords/test_packed_hashmap.py:70-133, 283-340)."""
+    c = scene_u(500, 3)
+    t = kmap.HashTable(c)
+    assert t.capacity == 1024 and (t.capacity & (t.capacity - 1)) == 0
+    np.testing.assert_array_equal(t.search(c), np.arange(len(c)))
+    miss = c.copy()
+    miss[:, 1] += 1000
+    assert (t.search(miss) == -1).all()
+    dup = np.concatenate([c[:10], c[:10], c[10:20]], 0)
+    td = kmap.HashTable(dup)
+    np.testing.assert_array_equal(td.search(dup), np.concatenate([np.arange(10), np.arange(10), np.arange(20, 30)]))
+    edge = np.array([[511, 131071, -131072, 0], [0, -131072, 131071, 5]], np.int32)
+    np.testing.assert_array_equal(kmap.HashTable(edge).search(edge), [0, 1])
+    for bad in ([[512, 0, 0, 0]], [[-1, 0, 0, 0]], [[0, 131072, 0, 0]], [[0, 0, -131073, 0]]):
+        with pytest.raises(ValueError):
+            kmap.HashTable(np.asarray(bad, np.int32))
+    with pytest.raises(RuntimeError):
+        kmap.HashTable(c[:40], capacity=32)  # 40 distinct keys do not fit 32 slots
+
+
+def test_stride_coords_oracle():
+    a = np.concatenate([scene_u(300, 1, 0), scene_u(300, 2, 1)], 0)
+    a[:, 1:] -= 4  # negative coordinates: floor, not truncation
+    out, first = kmap.stride_coords(a, (2, 2, 2))
+    want = np.floor_divide(a[:, 1:], 2)
+    np.testing.assert_array_equal(out[:, 1:], want[first])
+    full = np.concatenate([a[:, :1], want], 1)
+    assert len(np.unique(full, axis=0)) == len(out)
+    assert (np.diff(first) > 0).all() and (np.diff(out[:, 0]) >= 0).all()

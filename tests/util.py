@@ -1,0 +1,46 @@
+"""Shared helpers of the test-suite: synthetic scenes and oracle-backed kernel maps."""
+import numpy as np
+import torch
+
+
+def scene_u(n, seed, batch=0):
+    """Reference-style uniform scene: extent 2*ceil(n^(1/3)), draw 1.3n, unique (first occurrence), truncate."""
+    rng = np.random.default_rng(seed)
+    extent = 2 * int(np.ceil(n ** (1.0 / 3.0)))
+    c = rng.integers(0, extent, size=(int(1.3 * n), 3))
+    _, first = np.unique(c, axis=0, return_index=True)
+    c = c[np.sort(first)][:n].astype(np.int32)
+    return np.concatenate([np.full((len(c), 1), batch, np.int32), c], axis=1)
+
+
+def scene_surface(side, seed, batch=0):
+    """Surface-like scene: two height-field sheets over a side x side grid."""
+    rng = np.random.default_rng(seed)
+    xs, ys = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    sheets = []
+    for l in range(2):
+        a1, a2 = rng.uniform(3, 9), rng.uniform(1, 4)
+        f = rng.uniform(0.02, 0.15, size=4)
+        ph = rng.uniform(0, 6.28, size=3)
+        z = np.round(40 * l + a1 * np.sin(f[0] * xs + ph[0]) * np.cos(f[1] * ys + ph[1]) + a2 * np.sin(f[2] * xs + f[3] * ys + ph[2]))
+        sheets.append(np.stack([xs.ravel(), ys.ravel(), z.ravel().astype(np.int64)], 1))
+    c = np.unique(np.concatenate(sheets, 0), axis=0).astype(np.int32)
+    rng.shuffle(c)
+    return np.concatenate([np.full((len(c), 1), batch, np.int32), c], axis=1)
+
+
+def rel_max_err(a: torch.Tensor, ref: torch.Tensor) -> float:
+    """max|a - ref| / max|ref|  (metric of the reference's tests/nn/test_kernel_correctness.py:139-145)."""
+    a, ref = a.double().cpu(), ref.double().cpu()
+    denom = ref.abs().max().item()
+    return (a - ref).abs().max().item() / (denom if denom > 0 else 1.0)
+
+
+def sort_buckets(in_maps, out_maps, offsets):
+    """Sort every bucket by (out, in) so pair sets can be compared independent of order."""
+    in_maps, out_maps = np.asarray(in_maps).copy(), np.asarray(out_maps).copy()
+    for k in range(len(offsets) - 1):
+        s, e = int(offsets[k]), int(offsets[k + 1])
+        order = np.lexsort((in_maps[s:e], out_maps[s:e]))
+        in_maps[s:e], out_maps[s:e] = in_maps[s:e][order], out_maps[s:e][order]
+    return in_maps, out_maps

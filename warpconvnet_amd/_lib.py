@@ -1,0 +1,147 @@
+"""ctypes binding of the C-ABI library ``libwcn_hip.so`` (declared in ``include/wcn.h``).
+
+The library is built in-tree by ``make -C warpconvnet_amd/csrc`` (``__graft_entry__.build()``); this
+module never falls back to another implementation: if the shared object is missing or a symbol is
+absent, ``lib()`` raises.  Tensors cross the boundary as raw device pointers + sizes, the stream as
+``torch.cuda.current_stream().cuda_stream`` (a ``hipStream_t``).
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libwcn_hip.so")
+
+WCN_F32, WCN_F16, WCN_BF16 = 0, 1, 2
+WCN_ALGO_AUTO, WCN_ALGO_REF, WCN_ALGO_MFMA = 0, 1, 2
+WCN_FLAG_TABLE_FULL, WCN_FLAG_COORD_RANGE, WCN_FLAG_PAIR_OVERFLOW = 1, 2, 4
+
+_I32P = c_void_p  # all pointers travel as void*
+_3I = c_int32 * 3
+
+# name -> (restype, argtypes); one line per declaration in include/wcn.h
+SIGNATURES = {
+    "wcn_abi_version": (c_int, []),
+    "wcn_status_string": (c_char_p, [c_int]),
+    "wcn_hash_prepare": (c_int, [c_void_p, c_int64, c_void_p]),
+    "wcn_hash_insert": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "wcn_hash_search": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "wcn_kmap_row_pitch": (c_int32, [c_int32]),
+    "wcn_kmap_mask_words": (c_int32, [c_int32]),
+    "wcn_kmap_num_blocks": (c_int64, [c_int64]),
+    "wcn_kmap_probe": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, _3I, _3I, _3I, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "wcn_kmap_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "wcn_kmap_scatter": (
+        c_int,
+        [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+    ),
+    "wcn_kmap_transpose": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "wcn_kmap_reverse": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
+    "wcn_kmap_from_csr": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
+    "wcn_mask_argsort_workspace": (c_size_t, [c_int64]),
+    "wcn_mask_argsort": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_mfma_gather_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
+    "wcn_mfma_wgrad_supported": (c_int, [c_int32, c_int32, c_int32]),
+    "wcn_packed_weight_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "wcn_pack_weight": (
+        c_int,
+        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
+    ),
+    "wcn_conv_gather_gemm": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+         c_int32, c_int32, c_int32, c_int32, c_void_p],
+    ),
+    "wcn_conv_wgrad_workspace": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "wcn_conv_wgrad": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+         c_int32, c_int32, c_void_p, c_size_t, c_void_p],
+    ),
+}
+
+_LIB: Optional[ctypes.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU). Returns the .so path."""
+    cmd = ["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"building libwcn_hip.so failed:\n{res.stdout[-4000:]}\n{res.stderr[-4000:]}")
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the C-ABI library; raise loudly if it is not there."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C warpconvnet_amd/csrc`). "
+                "There is no CPU fallback for the HIP paths."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = handle
+    return _LIB
+
+
+def status_string(code: int) -> str:
+    return lib().wcn_status_string(int(code)).decode()
+
+
+def check(code: int, what: str) -> None:
+    """Non-zero C status -> RuntimeError (reference convention: `backends.py:489-510`)."""
+    if code != 0:
+        raise RuntimeError(f"{what} error: {status_string(code)} ({code})")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return WCN_F32
+    if dtype == torch.float16:
+        return WCN_F16
+    if dtype == torch.bfloat16:
+        return WCN_BF16
+    raise TypeError(f"unsupported feature dtype {dtype} (supported: float32, float16, bfloat16)")
+
+
+def i3(v) -> "ctypes.Array":
+    return _3I(int(v[0]), int(v[1]), int(v[2]))
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a GPU for the HIP path (got {t.device}); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")

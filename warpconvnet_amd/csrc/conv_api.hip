@@ -1,0 +1,94 @@
+// conv_api.hip - C-ABI entry points of the sparse-conv GEMMs (include/wcn.h); dispatch only.
+#include "wcn_common.h"
+
+namespace wcn {
+// conv_ref.hip
+int conv_gather_gemm_ref(const void* in, const void* w, void* out, const int32_t* nbr, int64_t n_out, int cin, int cout,
+                         int K, int dtype, int w_transposed, int k_flip, hipStream_t s);
+int conv_wgrad_ref(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                   const int32_t* offsets, int cin, int cout, int K, int dtype, hipStream_t s);
+// conv_mfma.hip
+bool mfma_gather_supported(int cin, int cout, int K, int dtype);
+int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                          const int32_t* perm, int64_t n_out, int cin, int cout, int K, int dtype, hipStream_t s);
+int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
+                     hipStream_t s);
+// wgrad_mfma.hip
+bool mfma_wgrad_supported(int cin, int cout, int dtype);
+size_t wgrad_mfma_workspace(int K, int cin, int cout);
+int conv_wgrad_mfma(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                    const int32_t* offsets, int cin, int cout, int K, int dtype, void* workspace, size_t workspace_bytes,
+                    hipStream_t s);
+}  // namespace wcn
+
+using namespace wcn;
+
+static inline size_t dtype_size(int dtype) { return dtype == WCN_F32 ? 4 : 2; }
+static inline bool dtype_ok(int dtype) { return dtype == WCN_F32 || dtype == WCN_F16 || dtype == WCN_BF16; }
+
+extern "C" {
+
+int wcn_mfma_gather_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype) {
+  return mfma_gather_supported(cin, cout, num_offsets, dtype) ? 1 : 0;
+}
+int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype) {
+  return mfma_wgrad_supported(cin, cout, dtype) ? 1 : 0;
+}
+
+size_t wcn_packed_weight_bytes(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose) {
+  (void)transpose;
+  if (num_offsets < 1 || cin < 1 || cout < 1 || !dtype_ok(dtype)) return 0;
+  return (size_t)num_offsets * cin * cout * dtype_size(dtype);
+}
+
+int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose,
+                    int32_t flip, void* packed, wcn_stream_t stream) {
+  if (!w || !packed || num_offsets < 1 || cin < 1 || cout < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  return pack_weight_mfma(w, num_offsets, cin, cout, dtype, transpose, flip, packed, (hipStream_t)stream);
+}
+
+int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t* nbr, const uint32_t* mask,
+                         const int32_t* perm, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout,
+                         int32_t num_offsets, int32_t dtype, int32_t algo, int32_t w_transposed, int32_t k_flip,
+                         wcn_stream_t stream) {
+  if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || !dtype_ok(dtype))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  if (n_out == 0) return WCN_SUCCESS;
+  if (!w || !out || !nbr || (n_in > 0 && !in)) return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  switch (algo) {
+    case WCN_ALGO_REF:
+      return conv_gather_gemm_ref(in, w, out, nbr, n_out, cin, cout, num_offsets, dtype, w_transposed, k_flip, s);
+    case WCN_ALGO_MFMA:
+      // `w` must be the packed image (wcn_pack_weight already applied transpose / flip)
+      if (!mask) return WCN_ERROR_INVALID_PARAMETERS;
+      return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, n_out, cin, cout, num_offsets, dtype, s);
+    default:
+      // AUTO cannot be resolved here because the two algorithms take different weight images.
+      return WCN_ERROR_INVALID_PARAMETERS;
+  }
+}
+
+size_t wcn_conv_wgrad_workspace(int32_t num_offsets, int32_t cin, int32_t cout, int32_t algo) {
+  if (algo == WCN_ALGO_MFMA) return wgrad_mfma_workspace(num_offsets, cin, cout);
+  return 256;
+}
+
+int wcn_conv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                   const int32_t* offsets, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets,
+                   int32_t dtype, int32_t algo, void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
+  if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || !dtype_ok(dtype) || !dw || !offsets)
+    return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  switch (algo) {
+    case WCN_ALGO_REF:
+      return conv_wgrad_ref(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, s);
+    case WCN_ALGO_MFMA:
+      return conv_wgrad_mfma(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, workspace,
+                             workspace_bytes, s);
+    default:
+      return WCN_ERROR_INVALID_PARAMETERS;
+  }
+}
+
+}  // extern "C"

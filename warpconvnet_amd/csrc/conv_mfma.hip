@@ -1,0 +1,329 @@
+// conv_mfma.hip - fused gather -> MFMA -> store kernel for the AB (forward) and ABt (dgrad) sparse-conv GEMMs.
+//
+// Design (gfx950, wave64):
+//   * output-stationary: a workgroup of 4 waves owns TILE = 4*32*RB output rows (taken through the
+//     mask-sorted permutation) and all CO output channels; fp32 accumulators live in registers.
+//   * the MFMA is issued "transposed": A operand = weight fragment (M = 32 output channels),
+//     B operand = 32 gathered feature rows (N = rows).  With the row/column permutations folded into
+//     the PACKED weight image (wcn_pack_weight) every lane (a) gathers CIC/2 CONTIGUOUS channels of one
+//     input row straight from HBM into its B registers - no LDS hop, no transpose - and (b) ends up
+//     holding CO/2 contiguous output channels of one output row, stored with 16-B writes.
+//   * weights: the [CIC x CO] slab of the current (offset, channel-chunk) step is streamed into LDS by
+//     LDS-DMA (global_load_lds, 16 B/lane) in exactly the order the A fragments are read back
+//     (lane-linear => conflict-free ds_read_b128), double buffered, one barrier per step.
+//   * the tile's neighbour rows (TILE x 32 int32) are staged in LDS once ("index slab").
+//   * offsets absent from every row of the workgroup are skipped (bitmask OR), and a wave skips the
+//     gather + MFMA of an offset none of its own rows has.
+//
+// Math: out[r] = sum_k in[nbr[r][k]] . Wp[k]  (fp32 accumulate), Wp = packed image of w (forward),
+// or of w^T with k reversed (dgrad of a submanifold map), or of w^T (dgrad with a reverse table).
+// Reference semantics: warpconvnet/nn/functional/sparse_conv/detail/explicit.py:22-57, 60-92; role of
+// _C.mask_gemm.fwd/.dgrad (warpconvnet/csrc/bindings/mask_gemm_bindings.cu:2074-2101).
+#include "wcn_common.h"
+
+namespace wcn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <typename T> struct Frag;
+template <> struct Frag<__bf16> {
+  typedef bf16x8 type;
+  static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Frag<_Float16> {
+  typedef f16x8 type;
+  static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int kWaves = 4;
+constexpr int kMaxKp = 32;  // fast path covers kernel volumes up to 32 (one mask word)
+
+// ---- weight packing --------------------------------------------------------------------------------
+// packed[k][chunk][b][s][lane][j], lane = (h<<5)|m:
+//   ci = chunk*CIC + h*(CIC/2) + 8*s + j
+//   co = ((m>>2)&1)*(CO/2) + 16*b + 4*(m>>3) + (m&3)
+// so that the C fragment of lane (h', n) holds out channels h'*(CO/2) + 16*b + reg, reg = 0..15.
+template <typename T>
+__global__ void pack_weight_kernel(const T* __restrict__ w, T* __restrict__ packed, int K, int cin, int cout, int cic,
+                                   int transpose, int flip) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * cin * cout;
+  if (e >= total) return;
+  const int NS = cic / 16, NB = cout / 32, nchunk = cin / cic;
+  int64_t t = e;
+  const int j = (int)(t % 8); t /= 8;
+  const int lane = (int)(t % 64); t /= 64;
+  const int s = (int)(t % NS); t /= NS;
+  const int b = (int)(t % NB); t /= NB;
+  const int chunk = (int)(t % nchunk); t /= nchunk;
+  const int k = (int)t;
+  const int h = lane >> 5, m = lane & 31;
+  const int ci = chunk * cic + h * (cic / 2) + 8 * s + j;
+  const int co = ((m >> 2) & 1) * (cout / 2) + 16 * b + 4 * (m >> 3) + (m & 3);
+  const int kw = flip ? (K - 1 - k) : k;
+  // not transposed: w[kw][ci][co] ([K, cin, cout]); transposed: w is the forward weight [K, cout, cin]
+  const int64_t src = transpose ? (((int64_t)kw * cout + co) * cin + ci) : (((int64_t)kw * cin + ci) * cout + co);
+  packed[e] = w[src];
+}
+
+// ---- main kernel -------------------------------------------------------------------------------------
+template <typename T, int CIC, int CO, int RB>
+struct GatherGemm {
+  static constexpr int NS = CIC / 16;
+  static constexpr int NB = CO / 32;
+  static constexpr int ROWS_PER_WAVE = 32 * RB;
+  static constexpr int TILE = kWaves * ROWS_PER_WAVE;
+  static constexpr int SLAB_ELEMS = CIC * CO;
+  static constexpr int SLAB_BYTES = SLAB_ELEMS * 2;
+  static constexpr int DMA_UNITS = SLAB_BYTES / 1024;  // one wave-instruction of LDS-DMA moves 1 KiB
+  static_assert(SLAB_BYTES % 1024 == 0, "weight slab must be a multiple of 1 KiB");
+  static constexpr size_t LDS_BYTES = 2 * (size_t)SLAB_BYTES + (size_t)TILE * kMaxKp * 4 + (size_t)TILE * 4 + 64;
+  typedef typename Frag<T>::type frag_t;
+};
+
+template <typename T, int CIC, int CO, int RB>
+__global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __restrict__ in, const T* __restrict__ wp,
+                                                               T* __restrict__ out, const int32_t* __restrict__ nbr,
+                                                               const uint32_t* __restrict__ mask,
+                                                               const int32_t* __restrict__ perm, int64_t n_out, int cin,
+                                                               int K, int kp) {
+  typedef GatherGemm<T, CIC, CO, RB> G;
+  typedef typename G::frag_t frag_t;
+  constexpr int NS = G::NS, NB = G::NB, RPW = G::ROWS_PER_WAVE, TILE = G::TILE;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* s_w = reinterpret_cast<T*>(smem);                                        // [2][SLAB_ELEMS]
+  int32_t* s_nbr = reinterpret_cast<int32_t*>(smem + 2 * G::SLAB_BYTES);      // [TILE][kp]
+  int32_t* s_rows = s_nbr + TILE * kMaxKp;                                    // [TILE]
+  uint32_t* s_wmask = reinterpret_cast<uint32_t*>(s_rows + TILE);             // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, n = lane & 31;
+  const int nchunk = cin / CIC;
+  const int64_t row0 = (int64_t)blockIdx.x * TILE;
+
+  // ---- stage output row ids, neighbour slab and masks ----
+  uint32_t my_mask = 0;
+  if (tid < TILE) {
+    const int64_t pr = row0 + tid;
+    int32_t r = -1;
+    if (pr < n_out) r = perm ? perm[pr] : (int32_t)pr;
+    s_rows[tid] = r;
+    // thread tid stages row tid, which belongs to wave tid / RPW
+    if (r >= 0) my_mask = mask[r];
+  }
+  __syncthreads();
+  {
+    const int vec_per_row = kp >> 2;
+    for (int e = tid; e < TILE * vec_per_row; e += 256) {
+      const int i = e / vec_per_row, c = e - i * vec_per_row;
+      const int32_t r = s_rows[i];
+      int4 v = make_int4(-1, -1, -1, -1);
+      if (r >= 0) v = reinterpret_cast<const int4*>(nbr + (int64_t)r * kp)[c];
+      reinterpret_cast<int4*>(s_nbr + i * kp)[c] = v;
+    }
+  }
+  // OR-reduce masks: rows of wave w are [w*RPW, (w+1)*RPW)
+  if (tid < kWaves) s_wmask[tid] = 0;
+  __syncthreads();
+  if (tid < TILE && my_mask) atomicOr(&s_wmask[tid / RPW], my_mask);
+  __syncthreads();
+  const uint32_t wave_mask = s_wmask[wave];
+  const uint32_t block_mask = s_wmask[0] | s_wmask[1] | s_wmask[2] | s_wmask[3];
+
+  f32x16 acc[NB][RB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[b][rb][q] = 0.f;
+
+  if (block_mask != 0u) {
+    // ---- helpers ----
+    auto dma_weights = [&](int buf, int k, int chunk) {
+      const T* src = wp + ((int64_t)k * nchunk + chunk) * G::SLAB_ELEMS;
+      char* dst = reinterpret_cast<char*>(s_w) + (size_t)buf * G::SLAB_BYTES;
+#pragma unroll
+      for (int it = 0; it < (G::DMA_UNITS + kWaves - 1) / kWaves; ++it) {
+        const int u = it * kWaves + wave;  // wave-uniform 1-KiB unit
+        if (u < G::DMA_UNITS)
+          __builtin_amdgcn_global_load_lds(
+              (const void __attribute__((address_space(1)))*)(reinterpret_cast<const char*>(src) + u * 1024 + lane * 16),
+              (void __attribute__((address_space(3)))*)(dst + u * 1024), 16, 0, 0);
+      }
+    };
+    // LDS-DMA completion is tracked by vmcnt; drain it explicitly before every barrier.
+    auto sync_step = [&]() {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    auto gather = [&](frag_t (&bf)[RB][NS], int k, int chunk) {
+      if (!((wave_mask >> k) & 1u)) return;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int i = wave * RPW + rb * 32 + n;
+        const int32_t idx = s_nbr[i * kp + k];
+        const T* p = in + (int64_t)idx * cin + chunk * CIC + h * (CIC / 2);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          frag_t v;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = (T)0.f;
+          if (idx >= 0) v = *reinterpret_cast<const frag_t*>(p + s * 8);
+          bf[rb][s] = v;
+        }
+      }
+    };
+    auto compute = [&](const frag_t (&bf)[RB][NS], int buf, int k) {
+      if (!((wave_mask >> k) & 1u)) return;
+      const frag_t* wl = reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(s_w) + (size_t)buf * G::SLAB_BYTES);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const frag_t a = wl[(b * NS + s) * 64 + lane];
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) acc[b][rb] = Frag<T>::mfma(a, bf[rb][s], acc[b][rb]);
+        }
+      }
+    };
+    // step iterator over (set bits of block_mask ascending) x (channel chunks)
+    uint32_t rem = block_mask;
+    auto next_step = [&](int& k, int& chunk) -> bool {
+      if (k >= 0 && chunk + 1 < nchunk) { ++chunk; return true; }
+      if (rem == 0u) return false;
+      k = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      chunk = 0;
+      return true;
+    };
+
+    frag_t B0[RB][NS], B1[RB][NS];
+    int k0 = -1, c0 = 0, k1 = -1, c1 = 0;
+    next_step(k0, c0);
+    dma_weights(0, k0, c0);
+    gather(B0, k0, c0);
+    sync_step();
+    bool more = true;
+    while (more) {
+      // even half-iteration: compute (k0,c0) from buffer 0 while fetching (k1,c1) into buffer 1
+      k1 = k0; c1 = c0;
+      const bool has1 = next_step(k1, c1);
+      if (has1) { dma_weights(1, k1, c1); gather(B1, k1, c1); }
+      compute(B0, 0, k0);
+      sync_step();
+      if (!has1) break;
+      // odd half-iteration
+      k0 = k1; c0 = c1;
+      const bool has0 = next_step(k0, c0);
+      if (has0) { dma_weights(0, k0, c0); gather(B0, k0, c0); }
+      compute(B1, 1, k1);
+      sync_step();
+      more = has0;
+    }
+  }
+
+  // ---- epilogue: lane (h, n) holds out channels h*CO/2 + 16*b + q of row (rb, n) ----
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int i = wave * RPW + rb * 32 + n;
+    const int32_t r = s_rows[i];
+    if (r < 0) continue;
+    T* dst = out + (int64_t)r * CO + h * (CO / 2);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      frag_t lo, hi;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        lo[q] = (T)acc[b][rb][q];
+        hi[q] = (T)acc[b][rb][8 + q];
+      }
+      *reinterpret_cast<frag_t*>(dst + 16 * b) = lo;
+      *reinterpret_cast<frag_t*>(dst + 16 * b + 8) = hi;
+    }
+  }
+}
+
+template <typename T, int CIC, int CO, int RB>
+static int launch_gather_gemm(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                              const int32_t* perm, int64_t n_out, int cin, int K, hipStream_t s) {
+  typedef GatherGemm<T, CIC, CO, RB> G;
+  const int kp = wcn_kmap_row_pitch(K);
+  auto kern = gather_gemm_mfma_kernel<T, CIC, CO, RB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)G::LDS_BYTES) != hipSuccess)
+      return WCN_ERROR_KERNEL_INITIALIZATION;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm,
+                     n_out, cin, K, kp);
+  return launch_status();
+}
+
+template <typename T, int CIC>
+static int dispatch_co(int cout, const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                       const int32_t* perm, int64_t n_out, int cin, int K, hipStream_t s) {
+  switch (cout) {
+    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
+  }
+}
+
+int mfma_chunk_for(int cin) {
+  if (cin % 64 == 0) return 64;
+  if (cin % 32 == 0) return 32;
+  if (cin % 16 == 0) return 16;
+  return 0;
+}
+
+bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
+  if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
+  if (K < 1 || K > kMaxKp) return false;
+  if (mfma_chunk_for(cin) == 0) return false;
+  return cout == 32 || cout == 64 || cout == 96 || cout == 128 || cout == 256;
+}
+
+template <typename T>
+static int dispatch_cic(int cin, int cout, const void* in, const void* wp, void* out, const int32_t* nbr,
+                        const uint32_t* mask, const int32_t* perm, int64_t n_out, int K, hipStream_t s) {
+  switch (mfma_chunk_for(cin)) {
+    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
+  }
+}
+
+int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                          const int32_t* perm, int64_t n_out, int cin, int cout, int K, int dtype, hipStream_t s) {
+  if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, n_out, K, s);
+  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, n_out, K, s);
+}
+
+int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
+                     hipStream_t s) {
+  const int cic = mfma_chunk_for(cin);
+  if (cic == 0 || cout % 32 != 0 || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  const int64_t total = (int64_t)K * cin * cout;
+  // bf16 and f16 are both 2-byte moves
+  hipLaunchKernelGGL(pack_weight_kernel<uint16_t>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
+                     (const uint16_t*)w, (uint16_t*)packed, K, cin, cout, cic, transpose, flip);
+  return launch_status();
+}
+
+}  // namespace wcn

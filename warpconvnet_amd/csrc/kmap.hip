@@ -1,0 +1,460 @@
+// kmap.hip - kernel-map construction for gfx950 (wave64).
+//
+//   hash table  : 16-B slots, Splitmix64, linear probing, duplicates keep the smallest row index
+//   probe       : one LANE per (output row, kernel offset); a 32-lane group covers one row so the
+//                 neighbour row is written as one contiguous 128-B line and the row's neighbour mask
+//                 is a single wave ballot
+//   bucketing   : per-block counts -> scan -> ballot/popcount ranking => pairs of each offset come
+//                 out ordered by output row (deterministic, no atomics on the output cursor)
+//
+// Reference behaviour being replaced (semantics only, nothing copied):
+//   warpconvnet/csrc/cuhash_hash_table.cu:19-262, cuhash_kernel_map.cu:68-134, 508-599,
+//   mask_data_kernels.cu:23-124, 187-220.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "wcn_common.h"
+
+namespace wcn {
+
+constexpr int kBlockRows = 256;  // rows per count block (probe + scatter must agree)
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------------
+// hash table
+// ------------------------------------------------------------------------------------------------
+__global__ void hash_prepare_kernel(uint4* __restrict__ slots, int64_t capacity) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < capacity) slots[i] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+}
+
+__global__ void hash_insert_kernel(Slot* __restrict__ slots, uint32_t capacity_mask, const int4* __restrict__ coords,
+                                   int64_t n, int32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  if (!coord_in_range(c.x, c.y, c.z, c.w)) {
+    atomicOr(status, (int)WCN_FLAG_COORD_RANGE);
+    return;
+  }
+  const uint64_t key = pack_key(c.x, c.y, c.z, c.w);
+  uint32_t s = hash_slot(key, capacity_mask);
+  for (uint32_t attempts = 0; attempts <= capacity_mask; ++attempts) {
+    unsigned long long* kp = reinterpret_cast<unsigned long long*>(&slots[s].key);
+    const unsigned long long prev = atomicCAS(kp, 0ull, (unsigned long long)key);
+    if (prev == 0ull || prev == key) {
+      // unsigned min: the empty marker 0xFFFFFFFF loses against every row index
+      atomicMin(reinterpret_cast<unsigned int*>(&slots[s].value), (unsigned int)i);
+      return;
+    }
+    s = (s + 1) & capacity_mask;
+  }
+  atomicOr(status, (int)WCN_FLAG_TABLE_FULL);
+}
+
+__global__ void hash_search_kernel(const Slot* __restrict__ slots, uint32_t capacity_mask,
+                                   const int4* __restrict__ queries, int64_t m, int32_t* __restrict__ results) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int4 q = queries[i];
+  results[i] = slot_lookup(slots, capacity_mask, pack_key(q.x, q.y, q.z, q.w));
+}
+
+// ------------------------------------------------------------------------------------------------
+// probe: nbr[m][kp], mask[m][mw], block_counts[blk][K]
+// ------------------------------------------------------------------------------------------------
+struct ProbeGeom {
+  int kx, ky, kz;  // kernel size
+  int cx, cy, cz;  // centre
+  int sx, sy, sz;  // stride (query = out * stride)
+  int dx, dy, dz;  // dilation
+};
+
+template <int LPR>  // lanes per row: 8, 16, 32 or 64
+__global__ __launch_bounds__(kThreads) void kmap_probe_kernel(const Slot* __restrict__ slots, uint32_t capacity_mask,
+                                                              const int4* __restrict__ query, int64_t m, ProbeGeom g,
+                                                              int K, int kp, int mw, int32_t* __restrict__ nbr,
+                                                              uint32_t* __restrict__ mask,
+                                                              int32_t* __restrict__ block_counts) {
+  extern __shared__ int s_counts[];  // [K]
+  const int tid = threadIdx.x;
+  for (int k = tid; k < K; k += kThreads) s_counts[k] = 0;
+  __syncthreads();
+
+  constexpr int kRowsPerIter = 64 / LPR;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int sub = lane % LPR;
+  const int rsel = lane / LPR;
+  const int64_t wave_row0 = (int64_t)blockIdx.x * kBlockRows + wave * 64;
+  const int num_chunks = (kp + LPR - 1) / LPR;
+
+  for (int kc = 0; kc < num_chunks; ++kc) {
+    const int k = kc * LPR + sub;
+    const bool k_real = k < K;
+    const bool k_store = k < kp;
+    // k = (i*ky + j)*kz + l  ->  offset (i-cx, j-cy, l-cz) * dilation
+    const int l = k % g.kz;
+    const int j = (k / g.kz) % g.ky;
+    const int i = k / (g.kz * g.ky);
+    const int ox = (i - g.cx) * g.dx, oy = (j - g.cy) * g.dy, oz = (l - g.cz) * g.dz;
+    int cnt = 0;
+#pragma unroll 4
+    for (int it = 0; it < 64 / kRowsPerIter; ++it) {
+      const int64_t row = wave_row0 + it * kRowsPerIter + rsel;
+      int found = -1;
+      if (row < m && k_real) {
+        const int4 q = query[row];
+        const uint64_t key = pack_key(q.x, q.y * g.sx + ox, q.z * g.sy + oy, q.w * g.sz + oz);
+        found = slot_lookup(slots, capacity_mask, key);
+      }
+      if (row < m && k_store) nbr[row * kp + k] = found;
+      const unsigned long long ball = __ballot(found >= 0);
+      cnt += found >= 0;
+      if (row < m && sub == 0) {
+        const unsigned long long bits = (LPR == 64) ? ball : ((ball >> (rsel * LPR)) & ((1ull << (LPR & 63)) - 1ull));
+        const int w0 = (kc * LPR) >> 5;
+        if (w0 < mw) mask[row * mw + w0] = (uint32_t)bits;
+        if (LPR == 64 && w0 + 1 < mw) mask[row * mw + w0 + 1] = (uint32_t)(bits >> 32);
+      }
+    }
+    if (k_real && cnt) atomicAdd(&s_counts[k], cnt);
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += kThreads) block_counts[(int64_t)blockIdx.x * K + k] = s_counts[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan: block_counts (in place, exclusive over blocks) and offsets[K+1]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ bc, int64_t num_blocks, int K,
+                                                         int32_t* __restrict__ offsets) {
+  extern __shared__ int s_tot[];  // [K]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nwaves = blockDim.x >> 6;
+  for (int k = wave; k < K; k += nwaves) {
+    int running = 0;
+    for (int64_t b0 = 0; b0 < num_blocks; b0 += 64) {
+      const int64_t b = b0 + lane;
+      const int v = b < num_blocks ? bc[b * K + k] : 0;
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (b < num_blocks) bc[b * K + k] = running + incl - v;
+      running += __shfl(incl, 63);
+    }
+    if (lane == 0) s_tot[k] = running;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    offsets[0] = 0;
+    for (int k = 0; k < K; ++k) {
+      acc += s_tot[k];
+      offsets[k + 1] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scatter: deterministic compaction, one thread per output row, wave ballot ranking
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void kmap_scatter_kernel(const int32_t* __restrict__ nbr, int64_t m, int K,
+                                                                int kp, const int32_t* __restrict__ bc,
+                                                                const int32_t* __restrict__ offsets,
+                                                                int32_t* __restrict__ in_maps,
+                                                                int32_t* __restrict__ out_maps, int64_t pair_capacity,
+                                                                int32_t* __restrict__ status) {
+  extern __shared__ int s_wcnt[];  // [4][K] per-wave valid counts
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = (int64_t)blockIdx.x * kBlockRows + tid;
+  const bool in_range = row < m;
+  const int32_t* my = nbr + row * kp;
+  // phase 1: per-wave counts for every offset
+  for (int k = 0; k < K; ++k) {
+    const bool v = in_range && my[k] >= 0;
+    const unsigned long long ball = __ballot(v);
+    if (lane == 0) s_wcnt[wave * K + k] = __popcll(ball);
+  }
+  __syncthreads();
+  // phase 2: write pairs
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  bool overflow = false;
+  for (int k = 0; k < K; ++k) {
+    const int in_row = in_range ? my[k] : -1;
+    const bool v = in_row >= 0;
+    const unsigned long long ball = __ballot(v);
+    if (ball == 0ull) continue;
+    if (v) {
+      int base = offsets[k] + bc[(int64_t)blockIdx.x * K + k];
+      for (int w = 0; w < wave; ++w) base += s_wcnt[w * K + k];
+      const int64_t pos = (int64_t)base + __popcll(ball & lt);
+      if (pos < pair_capacity) {
+        in_maps[pos] = in_row;
+        out_maps[pos] = (int32_t)row;
+      } else {
+        overflow = true;
+      }
+    }
+  }
+  if (overflow) atomicOr(status, (int)WCN_FLAG_PAIR_OVERFLOW);
+}
+
+// nbr [m][kp] -> pair_table [K][m]
+__global__ __launch_bounds__(kThreads) void kmap_transpose_kernel(const int32_t* __restrict__ nbr, int64_t m, int K,
+                                                                  int kp, int32_t* __restrict__ pair_table) {
+  extern __shared__ int s_tile[];  // [64][kp+1]
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int pitch = kp + 1;
+  for (int e = threadIdx.x; e < 64 * kp; e += kThreads) {
+    const int r = e / kp, k = e % kp;
+    s_tile[r * pitch + k] = (row0 + r < m) ? nbr[(row0 + r) * kp + k] : -1;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * K; e += kThreads) {
+    const int k = e / 64, r = e % 64;
+    if (row0 + r < m) pair_table[(int64_t)k * m + row0 + r] = s_tile[r * pitch + k];
+  }
+}
+
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__device__ __forceinline__ int find_bucket(const int32_t* __restrict__ offsets, int K, int64_t p) {
+  int lo = 0, hi = K;  // largest k with offsets[k] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offsets[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// For every pair p of bucket k: tbl[row_of(p)][k] = other_of(p); mask bit k.  `by_in` selects which map
+// indexes the table (reverse table: by input row; from_csr: by output row).
+__global__ void kmap_pairs_to_table_kernel(const int32_t* __restrict__ in_maps, const int32_t* __restrict__ out_maps,
+                                           const int32_t* __restrict__ offsets, int K, int kp, int mw, int64_t max_pairs,
+                                           int by_in, int32_t* __restrict__ tbl, uint32_t* __restrict__ mask) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= max_pairs || p >= offsets[K]) return;
+  const int k = find_bucket(offsets, K, p);
+  const int i = in_maps[p], o = out_maps[p];
+  const int64_t row = by_in ? i : o;
+  tbl[row * kp + k] = by_in ? o : i;
+  atomicOr(&mask[row * mw + (k >> 5)], 1u << (k & 31));
+}
+
+__global__ void argsort_prepare_kernel(const uint32_t* __restrict__ mask, int mw, int64_t n,
+                                       uint32_t* __restrict__ keys, int32_t* __restrict__ iota) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    keys[i] = mask[i * mw];
+    iota[i] = (int32_t)i;
+  }
+}
+
+static inline int lanes_per_row(int kp) {
+  int l = 8;
+  while (l < kp && l < 64) l <<= 1;
+  return l;
+}
+
+}  // namespace wcn
+
+using namespace wcn;
+
+extern "C" {
+
+int wcn_abi_version(void) { return 1; }
+
+const char* wcn_status_string(int status) {
+  switch (status) {
+    case WCN_SUCCESS: return "Success";
+    case WCN_ERROR_PROBLEM_NOT_SUPPORTED: return "Problem size not supported";
+    case WCN_ERROR_KERNEL_INITIALIZATION: return "Kernel initialization failed";
+    case WCN_ERROR_KERNEL_EXECUTION: return "Kernel execution failed";
+    case WCN_ERROR_UNSUPPORTED_CONFIG: return "Unsupported precision/configuration";
+    case WCN_ERROR_INVALID_PARAMETERS: return "Invalid parameters";
+    case WCN_ERROR_MIXED_INPUT_UNSUPPORTED: return "Mixed input precision unsupported";
+    default: return "Unknown error";
+  }
+}
+
+static inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int wcn_hash_prepare(void* slots, int64_t capacity, wcn_stream_t stream) {
+  if (!slots || !is_pow2(capacity) || capacity > (1ll << 31)) return WCN_ERROR_INVALID_PARAMETERS;
+  hipLaunchKernelGGL(hash_prepare_kernel, dim3((unsigned)ceil_div(capacity, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (uint4*)slots, capacity);
+  return launch_status();
+}
+
+int wcn_hash_insert(void* slots, int64_t capacity, const int32_t* coords, int64_t n, int32_t* status,
+                    wcn_stream_t stream) {
+  if (!slots || !is_pow2(capacity) || capacity > (1ll << 31) || n < 0 || !status) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n == 0) return WCN_SUCCESS;
+  if (!coords) return WCN_ERROR_INVALID_PARAMETERS;
+  hipLaunchKernelGGL(hash_insert_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (Slot*)slots, (uint32_t)(capacity - 1), (const int4*)coords, n, status);
+  return launch_status();
+}
+
+int wcn_hash_search(const void* slots, int64_t capacity, const int32_t* queries, int64_t m, int32_t* results,
+                    wcn_stream_t stream) {
+  if (!slots || !is_pow2(capacity) || m < 0) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  if (!queries || !results) return WCN_ERROR_INVALID_PARAMETERS;
+  hipLaunchKernelGGL(hash_search_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const Slot*)slots, (uint32_t)(capacity - 1), (const int4*)queries, m, results);
+  return launch_status();
+}
+
+int32_t wcn_kmap_row_pitch(int32_t num_offsets) { return (num_offsets + 7) & ~7; }
+int32_t wcn_kmap_mask_words(int32_t num_offsets) { return (num_offsets + 31) / 32; }
+int64_t wcn_kmap_num_blocks(int64_t m) { return ceil_div(m, kBlockRows); }
+
+int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, int64_t m, const int32_t ksize[3],
+                   const int32_t stride[3], const int32_t dilation[3], int32_t* nbr, uint32_t* mask,
+                   int32_t* block_counts, wcn_stream_t stream) {
+  if (!slots || !is_pow2(capacity) || m < 0 || !ksize || !stride || !dilation) return WCN_ERROR_INVALID_PARAMETERS;
+  for (int d = 0; d < 3; ++d)
+    if (ksize[d] < 1 || stride[d] < 1 || dilation[d] < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  const int64_t K64 = (int64_t)ksize[0] * ksize[1] * ksize[2];
+  if (K64 > 4096) return WCN_ERROR_PROBLEM_NOT_SUPPORTED;
+  if (m == 0) return WCN_SUCCESS;
+  if (!query || !nbr || !mask || !block_counts) return WCN_ERROR_INVALID_PARAMETERS;
+  const int K = (int)K64, kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
+  ProbeGeom g;
+  g.kx = ksize[0]; g.ky = ksize[1]; g.kz = ksize[2];
+  g.cx = (g.kx & 1) ? g.kx / 2 : 0; g.cy = (g.ky & 1) ? g.ky / 2 : 0; g.cz = (g.kz & 1) ? g.kz / 2 : 0;
+  g.sx = stride[0]; g.sy = stride[1]; g.sz = stride[2];
+  g.dx = dilation[0]; g.dy = dilation[1]; g.dz = dilation[2];
+  const dim3 grid((unsigned)wcn_kmap_num_blocks(m)), block(kThreads);
+  const size_t shm = (size_t)K * sizeof(int);
+  const uint32_t cmask = (uint32_t)(capacity - 1);
+  hipStream_t s = (hipStream_t)stream;
+  switch (lanes_per_row(kp)) {
+    case 8:
+      hipLaunchKernelGGL(kmap_probe_kernel<8>, grid, block, shm, s, (const Slot*)slots, cmask, (const int4*)query, m, g, K,
+                         kp, mw, nbr, mask, block_counts);
+      break;
+    case 16:
+      hipLaunchKernelGGL(kmap_probe_kernel<16>, grid, block, shm, s, (const Slot*)slots, cmask, (const int4*)query, m, g,
+                         K, kp, mw, nbr, mask, block_counts);
+      break;
+    case 32:
+      hipLaunchKernelGGL(kmap_probe_kernel<32>, grid, block, shm, s, (const Slot*)slots, cmask, (const int4*)query, m, g,
+                         K, kp, mw, nbr, mask, block_counts);
+      break;
+    default:
+      hipLaunchKernelGGL(kmap_probe_kernel<64>, grid, block, shm, s, (const Slot*)slots, cmask, (const int4*)query, m, g,
+                         K, kp, mw, nbr, mask, block_counts);
+      break;
+  }
+  return launch_status();
+}
+
+int wcn_kmap_scan(int32_t* block_counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
+                  wcn_stream_t stream) {
+  if (num_blocks < 0 || num_offsets < 1 || num_offsets > 4096 || !offsets) return WCN_ERROR_INVALID_PARAMETERS;
+  if (num_blocks > 0 && !block_counts) return WCN_ERROR_INVALID_PARAMETERS;
+  hipLaunchKernelGGL(kmap_scan_kernel, dim3(1), dim3(1024), (size_t)num_offsets * sizeof(int), (hipStream_t)stream,
+                     block_counts, num_blocks, (int)num_offsets, offsets);
+  return launch_status();
+}
+
+int wcn_kmap_scatter(const int32_t* nbr, int64_t m, int32_t num_offsets, const int32_t* block_counts,
+                     const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
+                     int32_t* status, wcn_stream_t stream) {
+  if (m < 0 || num_offsets < 1 || num_offsets > 4096 || pair_capacity < 0 || !status) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  if (!nbr || !block_counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps)))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  const int K = num_offsets, kp = wcn_kmap_row_pitch(K);
+  hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)wcn_kmap_num_blocks(m)), dim3(kThreads),
+                     (size_t)4 * K * sizeof(int), (hipStream_t)stream, nbr, m, K, kp, block_counts, offsets, in_maps,
+                     out_maps, pair_capacity, status);
+  return launch_status();
+}
+
+int wcn_kmap_transpose(const int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* pair_table, wcn_stream_t stream) {
+  if (m < 0 || num_offsets < 1 || num_offsets > 4096) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  if (!nbr || !pair_table) return WCN_ERROR_INVALID_PARAMETERS;
+  const int kp = wcn_kmap_row_pitch(num_offsets);
+  hipLaunchKernelGGL(kmap_transpose_kernel, dim3((unsigned)ceil_div(m, 64)), dim3(kThreads),
+                     (size_t)64 * (kp + 1) * sizeof(int), (hipStream_t)stream, nbr, m, (int)num_offsets, kp, pair_table);
+  return launch_status();
+}
+
+static int pairs_to_table(const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets, int32_t K,
+                          int64_t max_pairs, int64_t rows, int by_in, int32_t* tbl, uint32_t* mask, hipStream_t s) {
+  if (K < 1 || K > 4096 || rows < 0 || max_pairs < 0 || !offsets) return WCN_ERROR_INVALID_PARAMETERS;
+  if (rows == 0) return WCN_SUCCESS;
+  if (!tbl || !mask) return WCN_ERROR_INVALID_PARAMETERS;
+  const int kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(rows * kp, 256)), dim3(256), 0, s, tbl, rows * kp, -1);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(rows * mw, 256)), dim3(256), 0, s, (int32_t*)mask,
+                     rows * mw, 0);
+  if (max_pairs > 0) {
+    if (!in_maps || !out_maps) return WCN_ERROR_INVALID_PARAMETERS;
+    hipLaunchKernelGGL(kmap_pairs_to_table_kernel, dim3((unsigned)ceil_div(max_pairs, 256)), dim3(256), 0, s, in_maps,
+                       out_maps, offsets, (int)K, kp, mw, max_pairs, by_in, tbl, mask);
+  }
+  return launch_status();
+}
+
+int wcn_kmap_reverse(const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets, int32_t num_offsets,
+                     int64_t max_pairs, int64_t n_in, int32_t* rev_nbr, uint32_t* rev_mask, wcn_stream_t stream) {
+  return pairs_to_table(in_maps, out_maps, offsets, num_offsets, max_pairs, n_in, 1, rev_nbr, rev_mask,
+                        (hipStream_t)stream);
+}
+
+int wcn_kmap_from_csr(const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets, int32_t num_offsets,
+                      int64_t max_pairs, int64_t n_out, int32_t* nbr, uint32_t* mask, wcn_stream_t stream) {
+  return pairs_to_table(in_maps, out_maps, offsets, num_offsets, max_pairs, n_out, 0, nbr, mask, (hipStream_t)stream);
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t rocprim_sort_bytes(int64_t n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs_desc((void*)nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                       (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 32u, (hipStream_t)0,
+                                       false);
+  return bytes;
+}
+
+size_t wcn_mask_argsort_workspace(int64_t n) {
+  if (n <= 0) return 256;
+  // keys_in, keys_out, iota + rocPRIM temporary storage
+  return 3 * align256((size_t)n * 4) + align256(rocprim_sort_bytes(n)) + 256;
+}
+
+int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int64_t n, int32_t* perm, void* workspace,
+                     size_t workspace_bytes, wcn_stream_t stream) {
+  if (n < 0 || mask_words < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n == 0) return WCN_SUCCESS;
+  if (!mask || !perm || !workspace || workspace_bytes < wcn_mask_argsort_workspace(n)) return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const size_t seg = align256((size_t)n * 4);
+  uint32_t* keys_in = (uint32_t*)ws;
+  uint32_t* keys_out = (uint32_t*)(ws + seg);
+  int32_t* iota = (int32_t*)(ws + 2 * seg);
+  void* tmp = ws + 3 * seg;
+  size_t tmp_bytes = rocprim_sort_bytes(n);
+  hipLaunchKernelGGL(argsort_prepare_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, mask, (int)mask_words, n,
+                     keys_in, iota);
+  hipError_t e = rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, (const uint32_t*)keys_in, keys_out, (const int32_t*)iota,
+                                                perm, (size_t)n, 0u, 32u, s, false);
+  if (e != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// wgrad_mfma.hip - AtB gather-gather GEMM:  dw[k] = sum_{p in bucket k} x[in_maps[p]]^T . dy[out_maps[p]]   (fp32 out)
+//
+// Design (gfx950, wave64):
+//   * the reduction runs over PAIRS, but gathered rows are contiguous along CHANNELS, so both MFMA
+//     operands are "k-strided".  Rows are gathered HBM -> LDS as full 16-B pieces by LDS-DMA
+//     (global_load_lds; the LDS image is the plain row-major [pair][channel] tile with a 16-B-chunk XOR
+//     swizzle applied on the SOURCE side), and fragments are read back TRANSPOSED with
+//     ds_read_b64_tr_b16 (gfx950 hardware transpose read): no register shuffles, no scalar LDS reads.
+//   * work split: a fixed grid of G workgroups cuts the global pair list [0, L) into G equal ranges
+//     (L is read from offsets[K] on the device - no host sync).  A range may span several offsets; the
+//     workgroup flushes its fp32 partial tile to workspace slab (g + k) whenever the offset changes.
+//     Slab ids are unique, so a second tiny kernel reduces the slabs of each offset in ascending g:
+//     deterministic, no fp32 atomics.
+//   * grid.y tiles the (Cin, Cout) plane in CIT x COT blocks; 4 waves = 2 x 2 sub-tiles.
+//
+// Reference semantics: warpconvnet/nn/functional/sparse_conv/detail/explicit.py:93-97; role of
+// _C.mask_gemm.wgrad (warpconvnet/csrc/bindings/mask_gemm_bindings.cu:2103-2116, split-K atomics there).
+#include "wcn_common.h"
+
+namespace wcn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kWgradGrid = 1024;  // G: pair ranges
+constexpr int kPairs = 64;        // pairs per pipeline step
+constexpr int kZeroPage = 1024;   // bytes of zeros at the start of the workspace (source for padded pairs)
+
+template <typename T> struct WFrag;
+template <> struct WFrag<__bf16> {
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct WFrag<_Float16> {
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// 16-B chunk swizzle (an involution on the chunk index) that spreads the four rows touched by one
+// 16-lane transpose-read group over different LDS bank groups.  CH = chunks per row.
+template <int CH>
+__device__ __forceinline__ int chunk_swizzle(int p) {
+  if (CH >= 16) return (p & 3) << 2;
+  if (CH == 8) return ((p >> 1) & 1) << 2;
+  return 0;
+}
+
+// Fragment for MFMA rows/cols [c0, c0+32) and pairs [p0, p0+16): lane (h, m) receives tile[p0+8h+j][c0+m], j<8.
+template <int CH>
+__device__ __forceinline__ s16x8 read_frag_tr(const char* tile, int p0, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int col = c0 + 16 * (g & 1) + 4 * (i & 3);  // 4 consecutive channels, inside one 16-B chunk
+  const int chunk = col >> 3, within = (col & 7) * 2;
+  s16x8 out;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int p = p0 + 8 * (g >> 1) + 4 * t + (i >> 2);
+    const char* addr = tile + p * (CH * 16) + ((chunk ^ chunk_swizzle<CH>(p)) << 4) + within;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)addr);
+    out[4 * t + 0] = v[0]; out[4 * t + 1] = v[1]; out[4 * t + 2] = v[2]; out[4 * t + 3] = v[3];
+  }
+  return out;
+}
+
+template <typename T, int CIT, int COT>
+struct Wgrad {
+  static constexpr int CHX = CIT / 8;   // 16-B chunks per staged x row
+  static constexpr int CHY = COT / 8;
+  static constexpr int XT_BYTES = kPairs * CIT * 2;
+  static constexpr int YT_BYTES = kPairs * COT * 2;
+  static constexpr int STAGE_BYTES = XT_BYTES + YT_BYTES;
+  static constexpr int MB = CIT / 64;   // 32x32 blocks per wave along ci (wave owns CIT/2 rows)
+  static constexpr int NBK = COT / 64;  // ... along co
+  static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES;
+  static_assert(CIT % 64 == 0 && COT % 64 == 0, "tile must be a multiple of 64 channels");
+};
+
+template <typename T, int CIT, int COT>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const int32_t* __restrict__ in_maps,
+                                                         const int32_t* __restrict__ out_maps,
+                                                         const int32_t* __restrict__ offsets, int K, int cin, int cout,
+                                                         const char* __restrict__ zero_page, float* __restrict__ slabs) {
+  typedef Wgrad<T, CIT, COT> W;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int G = gridDim.x, g = blockIdx.x;
+  const int tiles_co = cout / COT;
+  const int ci0 = (blockIdx.y / tiles_co) * CIT, co0 = (blockIdx.y % tiles_co) * COT;
+
+  const int64_t L = offsets[K];
+  int64_t Q = (L + G - 1) / G;
+  Q = ((Q + kPairs - 1) / kPairs) * kPairs;
+  const int64_t r_begin = (int64_t)g * Q;
+  const int64_t r_end = (r_begin + Q < L) ? (r_begin + Q) : L;
+  if (r_begin >= r_end) return;
+
+  // first bucket containing r_begin
+  int k = 0;
+  {
+    int lo = 0, hi = K;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)offsets[mid] <= r_begin) lo = mid; else hi = mid;
+    }
+    k = lo;
+  }
+
+  f32x16 acc[W::MB][W::NBK];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < W::MB; ++a)
+#pragma unroll
+      for (int b = 0; b < W::NBK; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  };
+  auto flush = [&](int kk) {
+    float* slab = slabs + (int64_t)(g + kk) * cin * cout;
+    const int h = lane >> 5, n = lane & 31;
+#pragma unroll
+    for (int a = 0; a < W::MB; ++a)
+#pragma unroll
+      for (int b = 0; b < W::NBK; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ci = ci0 + wm * (CIT / 2) + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          const int co = co0 + wn * (COT / 2) + b * 32 + n;
+          slab[(int64_t)ci * cout + co] = acc[a][b][q];
+        }
+  };
+
+  // stage `buf` <- pairs [p0, p0+64) clipped to [p0, seg_end): LDS-DMA, padded pairs read the zero page
+  auto stage = [&](int buf, int64_t p0, int64_t seg_end) {
+    char* xt = smem + (size_t)buf * W::STAGE_BYTES;
+    char* yt = xt + W::XT_BYTES;
+    constexpr int X_UNITS = W::XT_BYTES / 1024, Y_UNITS = W::YT_BYTES / 1024;
+#pragma unroll
+    for (int it = 0; it < (X_UNITS + 3) / 4; ++it) {
+      const int u = it * 4 + wave;
+      if (u < X_UNITS) {
+        const int piece = u * 64 + lane;         // LDS position: row p, chunk slot q'
+        const int p = piece / W::CHX, qs = piece % W::CHX;
+        const int q = qs ^ chunk_swizzle<W::CHX>(p);
+        const char* src = zero_page;
+        if (p0 + p < seg_end) src = reinterpret_cast<const char*>(x + (int64_t)in_maps[p0 + p] * cin + ci0) + q * 16;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)(xt + u * 1024), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < (Y_UNITS + 3) / 4; ++it) {
+      const int u = it * 4 + wave;
+      if (u < Y_UNITS) {
+        const int piece = u * 64 + lane;
+        const int p = piece / W::CHY, qs = piece % W::CHY;
+        const int q = qs ^ chunk_swizzle<W::CHY>(p);
+        const char* src = zero_page;
+        if (p0 + p < seg_end) src = reinterpret_cast<const char*>(dy + (int64_t)out_maps[p0 + p] * cout + co0) + q * 16;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)(yt + u * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const char* xt = smem + (size_t)buf * W::STAGE_BYTES;
+    const char* yt = xt + W::XT_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < kPairs / 16; ++ks) {
+      s16x8 af[W::MB], bf[W::NBK];
+#pragma unroll
+      for (int a = 0; a < W::MB; ++a) af[a] = read_frag_tr<W::CHX>(xt, ks * 16, wm * (CIT / 2) + a * 32, lane);
+#pragma unroll
+      for (int b = 0; b < W::NBK; ++b) bf[b] = read_frag_tr<W::CHY>(yt, ks * 16, wn * (COT / 2) + b * 32, lane);
+#pragma unroll
+      for (int a = 0; a < W::MB; ++a)
+#pragma unroll
+        for (int b = 0; b < W::NBK; ++b) acc[a][b] = WFrag<T>::mfma(af[a], bf[b], acc[a][b]);
+    }
+  };
+  auto sync_step = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  int64_t pos = r_begin;
+  while (pos < r_end) {
+    while ((int64_t)offsets[k + 1] <= pos) ++k;  // skip empty buckets
+    const int64_t seg_end = ((int64_t)offsets[k + 1] < r_end) ? (int64_t)offsets[k + 1] : r_end;
+    zero_acc();
+    // software pipeline over 64-pair steps of [pos, seg_end)
+    int buf = 0;
+    stage(0, pos, seg_end);
+    sync_step();
+    for (int64_t p0 = pos; p0 < seg_end; p0 += kPairs) {
+      const int64_t pn = p0 + kPairs;
+      if (pn < seg_end) stage(buf ^ 1, pn, seg_end);
+      compute(buf);
+      sync_step();
+      buf ^= 1;
+    }
+    flush(k);
+    pos = seg_end;
+  }
+}
+
+// dw[k][e] = sum over ranges g that intersect bucket k (ascending) of slab[g + k][e]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs,
+                                                           const int32_t* __restrict__ offsets, int K, int64_t ce, int G,
+                                                           float* __restrict__ dw) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (e >= ce) return;
+  const int64_t L = offsets[K];
+  int64_t Q = (L + G - 1) / G;
+  Q = ((Q + kPairs - 1) / kPairs) * kPairs;
+  const int64_t b = offsets[k], en = offsets[k + 1];
+  float s = 0.f;
+  if (en > b && Q > 0) {
+    const int g_lo = (int)(b / Q), g_hi = (int)((en - 1) / Q);
+    for (int g = g_lo; g <= g_hi; ++g) s += slabs[(int64_t)(g + k) * ce + e];
+  }
+  dw[(int64_t)k * ce + e] = s;
+}
+
+bool mfma_wgrad_supported(int cin, int cout, int dtype) {
+  if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
+  return cin % 64 == 0 && cout % 64 == 0;
+}
+
+size_t wgrad_mfma_workspace(int K, int cin, int cout) {
+  return (size_t)kZeroPage + (size_t)(kWgradGrid + K) * cin * cout * sizeof(float);
+}
+
+template <typename T, int CIT, int COT>
+static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                        const int32_t* offsets, int cin, int cout, int K, void* workspace, hipStream_t s) {
+  typedef Wgrad<T, CIT, COT> W;
+  auto kern = wgrad_mfma_kernel<T, CIT, COT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)W::LDS_BYTES) != hipSuccess)
+      return WCN_ERROR_KERNEL_INITIALIZATION;
+    attr_set = true;
+  }
+  char* zero_page = (char*)workspace;
+  float* slabs = (float*)((char*)workspace + kZeroPage);
+  if (hipMemsetAsync(zero_page, 0, kZeroPage, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
+  const dim3 grid(kWgradGrid, (cin / CIT) * (cout / COT));
+  hipLaunchKernelGGL(kern, grid, dim3(256), W::LDS_BYTES, s, (const T*)x, (const T*)dy, in_maps, out_maps, offsets, K, cin,
+                     cout, (const char*)zero_page, slabs);
+  const int64_t ce = (int64_t)cin * cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ce, 256), K), dim3(256), 0, s, (const float*)slabs,
+                     offsets, K, ce, kWgradGrid, dw);
+  return launch_status();
+}
+
+template <typename T>
+static int dispatch_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                          const int32_t* offsets, int cin, int cout, int K, void* workspace, hipStream_t s) {
+  // tile = largest of {128, 64} dividing each dimension
+  const int cit = (cin % 128 == 0) ? 128 : 64;
+  const int cot = (cout % 128 == 0) ? 128 : 64;
+  if (cit == 64 && cot == 64) return launch_wgrad<T, 64, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+  if (cit == 64 && cot == 128) return launch_wgrad<T, 64, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+  if (cit == 128 && cot == 64) return launch_wgrad<T, 128, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+  return launch_wgrad<T, 128, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+}
+
+int conv_wgrad_mfma(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                    const int32_t* offsets, int cin, int cout, int K, int dtype, void* workspace, size_t workspace_bytes,
+                    hipStream_t s) {
+  if (!mfma_wgrad_supported(cin, cout, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (!workspace || workspace_bytes < wgrad_mfma_workspace(K, cin, cout)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (dtype == WCN_BF16)
+    return dispatch_wgrad<__bf16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+  return dispatch_wgrad<_Float16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+}
+
+}  // namespace wcn

@@ -1,0 +1,29 @@
+"""Coordinate down-sampling for strided convolution.
+
+Reference: `warpconvnet/geometry/coords/ops/stride.py:18-56` (floor-divide, hash de-duplicate,
+``torch.unique`` of winner indices, UNSTABLE argsort by batch).  Here the surviving rows are the first
+occurrences in input order; because inputs are batch-sorted, so are the outputs - no argsort, and the
+output row order is deterministic.
+"""
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from warpconvnet_amd.geometry.coords.ops.batch_index import offsets_from_batch_index
+from warpconvnet_amd.utils.ntuple import ntuple
+from warpconvnet_amd.utils.unique import unique_first_indices
+
+
+@torch.no_grad()
+def stride_coords(batch_indexed_coords: Tensor, stride: Tuple[int, ...], order=None) -> Tuple[Tensor, Tensor]:
+    """[N, D+1] -> (unique floor(coords / stride) [M, D+1], CPU offsets [B+1])."""
+    nd = batch_indexed_coords.shape[1] - 1
+    stride = ntuple(stride, nd)
+    if all(s == 1 for s in stride):
+        return batch_indexed_coords, offsets_from_batch_index(batch_indexed_coords[:, 0])
+    div = torch.tensor([1, *stride], dtype=torch.int32, device=batch_indexed_coords.device)
+    coarse = torch.div(batch_indexed_coords, div, rounding_mode="floor").to(torch.int32)
+    idx = unique_first_indices(coarse)
+    out = coarse[idx].contiguous()
+    return out, offsets_from_batch_index(out[:, 0])

@@ -1,0 +1,213 @@
+"""Kernel-map generation (the integer half of the SparseConv3d hot path).
+
+Mirrors `warpconvnet/geometry/coords/search/torch_discrete.py:24-56, 296-432` (``kernel_offsets_from_size``,
+``generate_kernel_map``).  One call = hash build + probe (neighbour table, masks, per-block counts) +
+scan + deterministic per-offset compaction + mask argsort, all on the current HIP stream through the
+C-ABI, with ONE host read (offsets + status flags) where the reference does six.
+"""
+from typing import Literal, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from warpconvnet_amd import _lib
+from warpconvnet_amd.geometry.coords.search.packed_hashmap import PackedHashTable, _next_power_of_2
+from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+from warpconvnet_amd.utils.ntuple import ntuple
+
+
+@torch.no_grad()
+def kernel_offsets_from_size(
+    kernel_size: Tuple[int, ...],
+    kernel_dilation: Tuple[int, ...],
+    center_offset: Optional[Tuple[int, ...]] = None,
+    device: Optional[torch.device] = None,
+) -> Tensor:
+    """[K, D+1] int32 offsets, k = (i*ky + j)*kz + l, centre (s-1)//2 for odd s and 0 for even s."""
+    assert len(kernel_size) == len(kernel_dilation)
+    if center_offset is None:
+        center_offset = [(s - 1) // 2 if s % 2 == 1 else 0 for s in kernel_size]
+    assert len(center_offset) == len(kernel_size)
+    grids = np.indices(tuple(int(s) for s in kernel_size)).reshape(len(kernel_size), -1)  # C order: last axis fastest
+    cols = [np.zeros(grids.shape[1], dtype=np.int64)]
+    for d in range(len(kernel_size)):
+        cols.append((grids[d] - int(center_offset[d])) * int(kernel_dilation[d]))
+    out = torch.from_numpy(np.stack(cols, axis=1).astype(np.int32))
+    return out.to(device) if device is not None else out
+
+
+@torch.no_grad()
+def nbr_to_pair_table(nbr: Tensor, num_offsets: int) -> Tensor:
+    """Row-major neighbour table [M, kp] -> reference layout [K, M] (`cuhash_kernel_map.cu:133`)."""
+    M = nbr.shape[0]
+    out = torch.empty((num_offsets, M), dtype=torch.int32, device=nbr.device)
+    _lib.check(
+        _lib.lib().wcn_kmap_transpose(_lib.ptr(nbr), M, num_offsets, _lib.ptr(out), _lib.stream_handle(nbr.device)),
+        "wcn_kmap_transpose",
+    )
+    return out
+
+
+@torch.no_grad()
+def mask_argsort(mask: Tensor) -> Tensor:
+    """Rows sorted by descending neighbour mask (word 0), stable."""
+    n, mw = mask.shape
+    perm = torch.empty(n, dtype=torch.int32, device=mask.device)
+    if n == 0:
+        return perm
+    L = _lib.lib()
+    ws_bytes = L.wcn_mask_argsort_workspace(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mask.device)
+    _lib.check(
+        L.wcn_mask_argsort(_lib.ptr(mask), mw, n, _lib.ptr(perm), _lib.ptr(ws), ws_bytes, _lib.stream_handle(mask.device)),
+        "wcn_mask_argsort",
+    )
+    return perm
+
+
+@torch.no_grad()
+def attach_tables_from_csr(kmap: IntSearchResult, num_in: int, num_out: int) -> IntSearchResult:
+    """Build nbr / mask / perm for a map that only has its CSR form (swapped or user-made maps).
+
+    Role of the reference's `_build_pair_table` + `_build_mask_and_argsort`
+    (`nn/functional/sparse_conv/detail/mask_gemm.py:127-254`).
+    """
+    if kmap._nbr is not None:
+        return kmap
+    dev = kmap.in_maps.device
+    K = len(kmap)
+    L = _lib.lib()
+    kp, mw = L.wcn_kmap_row_pitch(K), L.wcn_kmap_mask_words(K)
+    nbr = torch.empty((num_out, kp), dtype=torch.int32, device=dev)
+    mask = torch.empty((num_out, mw), dtype=torch.int32, device=dev)
+    offsets_dev = kmap.offsets.to(device=dev, dtype=torch.int32)
+    _lib.check(
+        L.wcn_kmap_from_csr(_lib.ptr(kmap.in_maps), _lib.ptr(kmap.out_maps), _lib.ptr(offsets_dev), K,
+                            kmap.in_maps.shape[0], num_out, _lib.ptr(nbr), _lib.ptr(mask), _lib.stream_handle(dev)),
+        "wcn_kmap_from_csr",
+    )
+    kmap._nbr, kmap._mask, kmap._offsets_dev = nbr, mask, offsets_dev
+    kmap._perm = mask_argsort(mask)
+    kmap._num_in, kmap._num_out = num_in, num_out
+    return kmap
+
+
+@torch.no_grad()
+def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """(rev_nbr [N_in, kp], rev_mask, rev_perm) for dgrad; cached on the map.
+
+    Role of `_build_reverse_mask_data` (`mask_gemm.py:279-350`).
+    """
+    if kmap._rev is None:
+        dev = kmap.in_maps.device
+        K = len(kmap)
+        L = _lib.lib()
+        kp, mw = L.wcn_kmap_row_pitch(K), L.wcn_kmap_mask_words(K)
+        rev_nbr = torch.empty((num_in, kp), dtype=torch.int32, device=dev)
+        rev_mask = torch.empty((num_in, mw), dtype=torch.int32, device=dev)
+        if kmap._offsets_dev is None:
+            kmap._offsets_dev = kmap.offsets.to(device=dev, dtype=torch.int32)
+        _lib.check(
+            L.wcn_kmap_reverse(_lib.ptr(kmap.in_maps), _lib.ptr(kmap.out_maps), _lib.ptr(kmap._offsets_dev), K,
+                               kmap.in_maps.shape[0], num_in, _lib.ptr(rev_nbr), _lib.ptr(rev_mask),
+                               _lib.stream_handle(dev)),
+            "wcn_kmap_reverse",
+        )
+        kmap._rev = (rev_nbr, rev_mask, mask_argsort(rev_mask))
+    return kmap._rev
+
+
+@torch.no_grad()
+def generate_kernel_map(
+    batch_indexed_in_coords: Tensor,
+    batch_indexed_out_coords: Tensor,
+    in_to_out_stride_ratio: Tuple[int, ...],
+    kernel_size: Tuple[int, ...],
+    kernel_dilation: Optional[Tuple[int, ...]] = None,
+    kernel_center_offset: Optional[Tuple[int, ...]] = None,
+    method: Literal["offset", "size"] = "size",
+    skip_symmetric_kernel_map: bool = False,
+    **kwargs,
+) -> IntSearchResult:
+    """Kernel map between integer coordinate sets: ``in = out * stride + offset[k]``.
+
+    Returns an ``IntSearchResult`` whose buckets are ordered by output row (deterministic).
+    """
+    dev = batch_indexed_in_coords.device
+    assert dev == batch_indexed_out_coords.device
+    assert batch_indexed_in_coords.dtype == torch.int32 and batch_indexed_out_coords.dtype == torch.int32
+    if not batch_indexed_in_coords.is_cuda:
+        raise RuntimeError(
+            "generate_kernel_map runs on the GPU through libwcn_hip.so; got CPU coordinates (no CPU fallback)"
+        )
+    if skip_symmetric_kernel_map:
+        raise NotImplementedError("skip_symmetric_kernel_map is not implemented in this build")
+    if kernel_center_offset is not None:
+        raise NotImplementedError("custom kernel_center_offset is not implemented in this build")
+    same_tensor = (
+        batch_indexed_in_coords.data_ptr() == batch_indexed_out_coords.data_ptr()
+        and batch_indexed_in_coords.shape == batch_indexed_out_coords.shape
+    )
+    # 2-D convolution: pad [b, x, y] -> [b, x, y, 0] (reference torch_discrete.py:328-342)
+    if batch_indexed_in_coords.shape[1] == 3:
+        batch_indexed_in_coords = torch.nn.functional.pad(batch_indexed_in_coords, (0, 1), value=0)
+        batch_indexed_out_coords = (
+            batch_indexed_in_coords if same_tensor else torch.nn.functional.pad(batch_indexed_out_coords, (0, 1), value=0)
+        )
+        kernel_size = tuple(kernel_size) + (1,)
+        in_to_out_stride_ratio = tuple(in_to_out_stride_ratio) + (1,)
+        if kernel_dilation is not None:
+            kernel_dilation = tuple(kernel_dilation) + (1,)
+    assert batch_indexed_in_coords.shape[1] == 4, "expected batch-indexed 3-D coordinates [N, 4]"
+    ksize = ntuple(kernel_size, 3)
+    stride = ntuple(in_to_out_stride_ratio, 3)
+    dilation = ntuple(kernel_dilation if kernel_dilation is not None else 1, 3)
+    K = int(np.prod(ksize))
+
+    in_coords = batch_indexed_in_coords.contiguous()
+    out_coords = in_coords if same_tensor else batch_indexed_out_coords.contiguous()
+    N, M = in_coords.shape[0], out_coords.shape[0]
+    L = _lib.lib()
+    stream = _lib.stream_handle(dev)
+    kp, mw = L.wcn_kmap_row_pitch(K), L.wcn_kmap_mask_words(K)
+    nblk = L.wcn_kmap_num_blocks(M)
+
+    # meta[0:K+1] = offsets, meta[K+1] = status flags -> one D2H copy
+    meta = torch.zeros(K + 2, dtype=torch.int32, device=dev)
+    table = PackedHashTable(max(16, 2 * N), device=dev)
+    table._launch_insert(in_coords, meta[K + 1 :])
+    nbr = torch.empty((M, kp), dtype=torch.int32, device=dev)
+    mask = torch.empty((M, mw), dtype=torch.int32, device=dev)
+    block_counts = torch.empty((max(nblk, 1), K), dtype=torch.int32, device=dev)
+    _lib.check(
+        L.wcn_kmap_probe(_lib.ptr(table.slots_tensor), table.capacity, _lib.ptr(out_coords), M, _lib.i3(ksize),
+                         _lib.i3(stride), _lib.i3(dilation), _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(block_counts),
+                         stream),
+        "wcn_kmap_probe",
+    )
+    _lib.check(L.wcn_kmap_scan(_lib.ptr(block_counts), nblk, K, _lib.ptr(meta), stream), "wcn_kmap_scan")
+    meta_host = meta.cpu()  # the single host sync of the build
+    PackedHashTable.raise_for_flags(int(meta_host[K + 1]), N, table.capacity)
+    offsets_host = meta_host[: K + 1].clone()
+    num_pairs = int(offsets_host[-1])
+    in_maps = torch.empty(num_pairs, dtype=torch.int32, device=dev)
+    out_maps = torch.empty(num_pairs, dtype=torch.int32, device=dev)
+    _lib.check(
+        L.wcn_kmap_scatter(_lib.ptr(nbr), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
+                           _lib.ptr(out_maps), num_pairs, _lib.ptr(meta[K + 1 :]), stream),
+        "wcn_kmap_scatter",
+    )
+    perm = mask_argsort(mask)
+
+    odd = all(k % 2 == 1 for k in ksize)
+    unit_stride = all(s == 1 for s in stride)
+    identity = K // 2 if (odd and unit_stride and N == M) else None
+    result = IntSearchResult(in_maps, out_maps, offsets_host, identity_map_index=identity)
+    result._nbr, result._mask, result._perm = nbr, mask, perm
+    result._offsets_dev = meta[: K + 1]
+    result._symmetric = bool(same_tensor and odd and unit_stride)
+    result._num_in, result._num_out = N, M
+    result._hashtable = table
+    result._kernel_size = ksize
+    return result

@@ -1,0 +1,96 @@
+"""Point cloud with real coordinates (reference `warpconvnet/geometry/types/points.py:33-326`).
+
+Only the surface needed by the sparse-conv hot path and its immediate callers is provided
+(construction, neighbour search, voxel down-sampling, conversion to ``Voxels``); orderings, sinusoidal
+encodings and patch ops belong to other model families (out of scope).
+"""
+from typing import List, Optional, Union
+
+import torch
+from torch import Tensor
+
+from warpconvnet_amd.geometry.base.coords import Coords
+from warpconvnet_amd.geometry.base.geometry import Geometry
+from warpconvnet_amd.geometry.coords.real import RealCoords
+from warpconvnet_amd.geometry.features.cat import CatFeatures, to_batched_features
+
+
+class Points(Geometry):
+    def __init__(
+        self,
+        batched_coordinates: Union[List[Tensor], Tensor, RealCoords],
+        batched_features: Union[List[Tensor], Tensor, CatFeatures],
+        offsets: Optional[Tensor] = None,
+        device: Optional[str] = None,
+        **kwargs,
+    ):
+        if isinstance(batched_coordinates, list):
+            assert isinstance(batched_features, list), "If coords is a list, features must be a list too."
+            assert len(batched_coordinates) == len(batched_features)
+            assert all(len(c) == len(f) for c, f in zip(batched_coordinates, batched_features)), (
+                "All elements in coords and features must have same length"
+            )
+            batched_coordinates = RealCoords(batched_coordinates, device=device)
+        elif isinstance(batched_coordinates, Tensor):
+            assert isinstance(batched_features, Tensor) and offsets is not None, (
+                "If coordinate is a tensor, features must be a tensor and offsets must be provided."
+            )
+            batched_coordinates = RealCoords(batched_coordinates, offsets=offsets, device=device)
+        if isinstance(batched_features, list):
+            batched_features = CatFeatures(batched_features, device=device)
+        elif isinstance(batched_features, Tensor):
+            batched_features = to_batched_features(batched_features, batched_coordinates.offsets, device=device)
+        Geometry.__init__(self, batched_coordinates, batched_features, **kwargs)
+
+    @property
+    def voxel_size(self):
+        return self._extra_attributes.get("voxel_size", None)
+
+    def neighbors(self, search_args, query_coords: Optional[Coords] = None):
+        """CSR neighbour lists (``RealSearchResult``); cached per (config, offsets) like the reference."""
+        from warpconvnet_amd.geometry.coords.search.continuous import neighbor_search
+
+        if query_coords is None:
+            query_coords = self.batched_coordinates
+        assert isinstance(query_coords, Coords), "query_coords must be Coords"
+        cache = self._extra_attributes.setdefault("_cache", {})
+        key = (search_args, tuple(self.offsets.tolist()), tuple(query_coords.offsets.tolist()))
+        if key not in cache:
+            cache[key] = neighbor_search(
+                self.coordinate_tensor, self.offsets, query_coords.batched_tensor, query_coords.offsets, search_args
+            )
+        return cache[key]
+
+    def voxel_downsample(self, voxel_size: float) -> "Points":
+        """One (first) point per voxel of edge ``voxel_size``."""
+        from warpconvnet_amd.geometry.coords.ops.voxel import voxel_downsample_random_indices
+
+        idx, offsets = voxel_downsample_random_indices(self.coordinate_tensor, self.offsets, voxel_size)
+        return self.__class__(
+            RealCoords(self.coordinate_tensor[idx], offsets),
+            CatFeatures(self.batched_features.batched_tensor[idx], offsets),
+            **{**self.extra_attributes, "voxel_size": voxel_size},
+        )
+
+    def to_voxels(self, voxel_size: float, reduction: str = "mean"):
+        """Quantise to integer voxels, reducing the features of points that share a voxel."""
+        from warpconvnet_amd.geometry.coords.integer import IntCoords
+        from warpconvnet_amd.geometry.coords.ops.batch_index import batch_indexed_coordinates, offsets_from_batch_index
+        from warpconvnet_amd.geometry.types.voxels import Voxels
+
+        q = torch.floor(self.coordinate_tensor / voxel_size).to(torch.int32)
+        bq = batch_indexed_coordinates(q, self.offsets)
+        uniq, inverse = torch.unique(bq, dim=0, return_inverse=True)  # lexicographic => batch-sorted
+        feats = self.batched_features.batched_tensor
+        out = torch.zeros((uniq.shape[0], feats.shape[1]), dtype=feats.dtype, device=feats.device)
+        if reduction in ("mean", "sum"):
+            out.index_add_(0, inverse, feats)
+            if reduction == "mean":
+                counts = torch.bincount(inverse, minlength=uniq.shape[0]).clamp_min(1).to(feats.dtype)
+                out = out / counts.unsqueeze(1)
+        elif reduction == "max":
+            out = torch.full_like(out, float("-inf")).scatter_reduce(0, inverse[:, None].expand_as(feats), feats, "amax")
+        else:
+            raise ValueError(f"unsupported reduction {reduction!r}")
+        offsets = offsets_from_batch_index(uniq[:, 0], num_batches=self.batch_size)
+        return Voxels(IntCoords(uniq[:, 1:].contiguous(), offsets), CatFeatures(out, offsets), voxel_size=voxel_size)

@@ -1,0 +1,129 @@
+"""Backend registry of the sparse-conv dispatch.
+
+Same plug-in interface as the reference (`warpconvnet/nn/functional/sparse_conv/detail/backends.py:90-131,
+443-510`): ``FORWARD_BACKENDS[name](FwdCtx) -> Tensor | int``, ``BACKWARD_BACKENDS[name](BwdCtx) ->
+(Tensor | int | None, Tensor | None)``; a non-zero int status becomes a ``RuntimeError`` in
+``run_forward`` / ``run_backward``.  Registered names: ``explicit_gemm``, ``hip_ref``, ``hip_mfma``,
+``auto`` (static shape-class choice between the two HIP paths).
+"""
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from warpconvnet_amd import _lib
+from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+
+from . import hip_gemm
+from .explicit import _explicit_gemm_backward_logic, _explicit_gemm_forward_logic
+
+
+@dataclass
+class FwdCtx:
+    in_features: Tensor
+    weight: Tensor
+    kernel_map: IntSearchResult
+    num_out_coords: int
+    compute_dtype: Optional[torch.dtype]
+    params: Dict[str, Any]
+    fwd_block_size: Optional[int] = None
+    groups: int = 1
+    use_fp16_accum: bool = False
+
+
+@dataclass
+class BwdCtx:
+    grad_output: Tensor
+    in_features: Tensor
+    weight: Tensor
+    kernel_map: IntSearchResult
+    num_out_coords: int
+    compute_dtype: Optional[torch.dtype]
+    device: torch.device
+    needs_input_grad: Tuple[bool, ...]
+    params: Dict[str, Any]
+    weight_T: Optional[Tensor] = None
+    groups: int = 1
+    use_fp16_accum: bool = False
+    scratch: Optional[Dict[int, Any]] = None
+
+
+FwdFn = Callable[[FwdCtx], Any]
+BwdFn = Callable[[BwdCtx], Tuple[Any, Any]]
+
+
+def _fwd_explicit(ctx: FwdCtx):
+    return _explicit_gemm_forward_logic(ctx.in_features, ctx.weight, ctx.kernel_map, ctx.num_out_coords, ctx.compute_dtype)
+
+
+def _bwd_explicit(ctx: BwdCtx):
+    return _explicit_gemm_backward_logic(ctx.grad_output, ctx.in_features, ctx.weight, ctx.kernel_map, ctx.compute_dtype,
+                                         ctx.device, needs_input_grad=tuple(ctx.needs_input_grad[:2]))
+
+
+def _make_hip_fwd(algo: str) -> FwdFn:
+    def fn(ctx: FwdCtx):
+        if ctx.groups != 1:
+            return -1  # WCN_ERROR_PROBLEM_NOT_SUPPORTED: grouped conv is not covered by the HIP kernels yet
+        dt = ctx.compute_dtype or ctx.in_features.dtype
+        out = hip_gemm.hip_forward(ctx.in_features.to(dt), ctx.weight.to(dt), ctx.kernel_map, ctx.num_out_coords, algo)
+        return out.to(ctx.in_features.dtype) if ctx.compute_dtype is not None else out
+
+    return fn
+
+
+def _make_hip_bwd(algo: str) -> BwdFn:
+    def fn(ctx: BwdCtx):
+        if ctx.groups != 1:
+            return -1, None
+        dt = ctx.compute_dtype or ctx.in_features.dtype
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dy = ctx.grad_output.to(dt)
+        dx = dw = None
+        if need_dx:
+            dx = hip_gemm.hip_dgrad(dy, ctx.weight.to(dt), ctx.kernel_map, ctx.in_features.shape[0], algo)
+            dx = dx.to(ctx.in_features.dtype)
+        if need_dw:
+            dw = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape), algo)
+            dw = dw.to(ctx.weight.dtype)
+        return dx, dw
+
+    return fn
+
+
+FORWARD_BACKENDS: Dict[str, FwdFn] = {
+    "explicit_gemm": _fwd_explicit,
+    "hip_ref": _make_hip_fwd("hip_ref"),
+    "hip_mfma": _make_hip_fwd("hip_mfma"),
+    "auto": _make_hip_fwd("auto"),
+}
+
+BACKWARD_BACKENDS: Dict[str, BwdFn] = {
+    "explicit_gemm": _bwd_explicit,
+    "hip_ref": _make_hip_bwd("hip_ref"),
+    "hip_mfma": _make_hip_bwd("hip_mfma"),
+    "auto": _make_hip_bwd("auto"),
+}
+
+
+def run_forward(algo: str, ctx: FwdCtx):
+    try:
+        fn = FORWARD_BACKENDS[algo]
+    except KeyError:
+        raise ValueError(f"Unsupported forward algorithm: {algo}")
+    result = fn(ctx)
+    if isinstance(result, int) and result != 0:
+        raise RuntimeError(f"{algo} fwd error: {_lib.status_string(result)}")
+    return result
+
+
+def run_backward(algo: str, ctx: BwdCtx):
+    try:
+        fn = BACKWARD_BACKENDS[algo]
+    except KeyError:
+        raise ValueError(f"Unsupported backward algorithm: {algo}")
+    result = fn(ctx)
+    if isinstance(result[0], int) and result[0] != 0:
+        raise RuntimeError(f"{algo} bwd error: {_lib.status_string(result[0])}")
+    return result

@@ -1,0 +1,109 @@
+"""Autograd function of the sparse convolution.
+
+Counterpart of `UnifiedSpatiallySparseConvFunction` (`warpconvnet/nn/functional/sparse_conv/detail/
+unified.py:143-785`) with the same call signature and the same backward contract: ``(in_features,
+weight)`` are saved (already in compute precision), read from ``ctx.saved_tensors`` exactly once, dgrad
+and wgrad are dispatched independently, grads return in the dtypes of the inputs.  Differences: the
+algorithm is resolved statically (no run-time autotune sweep, so ranks never diverge) and a failing
+backend raises instead of silently falling back to ``explicit_gemm``.
+"""
+from enum import Enum
+from typing import Any, Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+from warpconvnet_amd.utils.ntuple import _pad_values
+
+from .backends import BwdCtx, FwdCtx, run_backward, run_forward
+
+
+class SPARSE_CONV_AB_ALGO_MODE(Enum):
+    EXPLICIT_GEMM = "explicit_gemm"
+    HIP_REF = "hip_ref"
+    HIP_MFMA = "hip_mfma"
+    AUTO = "auto"
+
+
+class SPARSE_CONV_ATB_ALGO_MODE(Enum):
+    EXPLICIT_GEMM = "explicit_gemm"
+    HIP_REF = "hip_ref"
+    HIP_MFMA = "hip_mfma"
+    AUTO = "auto"
+
+
+def _algo_name(algo: Any, on_gpu: bool) -> str:
+    if isinstance(algo, Enum):
+        algo = algo.value
+    if isinstance(algo, (list, tuple)):
+        algo = algo[0].value if isinstance(algo[0], Enum) else algo[0]
+    algo = str(algo).lower()
+    if algo == "auto" and not on_gpu:
+        # CPU tensors can only run the torch-op backend; "auto" resolves to it explicitly (config 1 plumbing)
+        return "explicit_gemm"
+    return algo
+
+
+class UnifiedSpatiallySparseConvFunction(Function):
+    @staticmethod
+    def forward(
+        ctx,
+        in_features: Tensor,
+        weight: Tensor,
+        kernel_map: IntSearchResult,
+        num_out_coords: int,
+        fwd_algo: Any = "auto",
+        dgrad_algo: Any = "auto",
+        wgrad_algo: Any = "auto",
+        compute_dtype: Optional[torch.dtype] = None,
+        fwd_block_size: Optional[int] = None,
+        bwd_block_size: Optional[int] = None,
+        voxel_size: Optional[Tuple[int, ...]] = None,
+        conv_cache_metadata: Optional[dict] = None,
+        groups: int = 1,
+        use_fp16_accum: bool = False,
+    ) -> Tensor:
+        on_gpu = in_features.is_cuda
+        ctx.kernel_map = kernel_map
+        ctx.num_out_coords = num_out_coords
+        ctx.compute_dtype = compute_dtype
+        ctx.groups = groups
+        ctx.dgrad_algo = _algo_name(dgrad_algo, on_gpu)
+        ctx.wgrad_algo = _algo_name(wgrad_algo, on_gpu)
+        ctx.save_for_backward(in_features, weight)
+        cout = weight.shape[-1] * (groups if weight.ndim == 4 else 1)
+        if num_out_coords == 0 or in_features.shape[0] == 0 or in_features.shape[1] == 0 or cout == 0:
+            return torch.zeros((num_out_coords, cout), dtype=in_features.dtype, device=in_features.device)
+        fctx = FwdCtx(in_features, weight, kernel_map, num_out_coords, compute_dtype, {}, fwd_block_size, groups,
+                      bool(use_fp16_accum))
+        return run_forward(_algo_name(fwd_algo, on_gpu), fctx)
+
+    @staticmethod
+    def backward(ctx, grad_output: Tensor):
+        in_features, weight = ctx.saved_tensors  # read exactly once (activation-checkpointing contract)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        grad_in = grad_w = None
+        empty = ctx.num_out_coords == 0 or in_features.shape[0] == 0 or grad_output.shape[1] == 0
+        if empty or not (need_dx or need_dw):
+            if need_dx:
+                grad_in = torch.zeros_like(in_features)
+            if need_dw:
+                grad_w = torch.zeros_like(weight)
+        else:
+            grad_output = grad_output.contiguous()
+
+            def _ctx(needs):
+                return BwdCtx(grad_output, in_features, weight, ctx.kernel_map, ctx.num_out_coords, ctx.compute_dtype,
+                              grad_output.device, needs, {}, None, ctx.groups, False, {})
+
+            if ctx.dgrad_algo == ctx.wgrad_algo:
+                grad_in, grad_w = run_backward(ctx.dgrad_algo, _ctx((need_dx, need_dw)))
+            else:
+                if need_dx:
+                    grad_in, _ = run_backward(ctx.dgrad_algo, _ctx((True, False)))
+                if need_dw:
+                    _, grad_w = run_backward(ctx.wgrad_algo, _ctx((False, True)))
+        ctx.kernel_map = None  # release eagerly (reference unified.py:779-783)
+        return _pad_values(14, grad_in, grad_w)

@@ -1,0 +1,198 @@
+"""Orchestration of one sparse convolution: output coordinates, kernel-map cache, dtype policy, GEMM dispatch.
+
+Counterpart of `warpconvnet/nn/functional/sparse_conv/helper.py:147-567` (``spatially_sparse_conv``,
+``generate_output_coords_and_kernel_map``) with the same argument surface.  Not built (out of the hot-path
+scope): generative convolution, ``REDUCE_AND_STRIDE`` pooling and non-random output orderings
+raise ``NotImplementedError``.
+"""
+from enum import Enum
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from warpconvnet_amd.constants import get_fp16_accum
+from warpconvnet_amd.geometry.base.geometry import Geometry
+from warpconvnet_amd.geometry.coords.integer import IntCoords
+from warpconvnet_amd.geometry.coords.ops.stride import stride_coords
+from warpconvnet_amd.geometry.coords.search.cache import IntSearchCache, IntSearchCacheKey
+from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+from warpconvnet_amd.geometry.types.voxels import Voxels
+from warpconvnet_amd.utils.ntuple import ntuple
+
+from .detail.unified import (
+    SPARSE_CONV_AB_ALGO_MODE,
+    SPARSE_CONV_ATB_ALGO_MODE,
+    UnifiedSpatiallySparseConvFunction,
+)
+
+
+class STRIDED_CONV_MODE(Enum):
+    REDUCE_AND_STRIDE = "reduce_and_stride"
+    STRIDE_ONLY = "stride_only"
+
+
+def _swap(kernel_map: IntSearchResult) -> IntSearchResult:
+    """Transposed convolution uses the forward map with in/out exchanged (reference helper.py:487-497)."""
+    return IntSearchResult(in_maps=kernel_map.out_maps, out_maps=kernel_map.in_maps, offsets=kernel_map.offsets)
+
+
+def _cpu_kernel_map(in_coords: Tensor, out_coords: Tensor, stride, kernel_size, kernel_dilation) -> IntSearchResult:
+    raise RuntimeError(
+        "kernel-map construction needs GPU coordinates (HIP path, no CPU fallback). Move the Voxels to a GPU, or "
+        "attach a pre-built IntSearchResult to the input's cache."
+    )
+
+
+@torch.no_grad()
+def generate_output_coords_and_kernel_map(
+    input_sparse_tensor: Voxels,
+    kernel_size: Tuple[int, ...],
+    kernel_dilation: Tuple[int, ...],
+    stride: Tuple[int, ...],
+    generative: bool = False,
+    transposed: bool = False,
+    output_spatially_sparse_tensor: Optional[Voxels] = None,
+    stride_mode: STRIDED_CONV_MODE = STRIDED_CONV_MODE.STRIDE_ONLY,
+    order=None,
+    kernel_search_batch_size: Optional[int] = None,
+    out_code_backend: Optional[str] = None,
+) -> Tuple[Tensor, Tensor, IntSearchResult]:
+    """Returns ``(batch_indexed_out_coords [M, D+1], out_offsets (CPU), kernel_map)``."""
+    if generative:
+        raise NotImplementedError("generative convolution is outside the built hot path (SURVEY.md §8f rank 3)")
+    if stride_mode != STRIDED_CONV_MODE.STRIDE_ONLY and any(s != 1 for s in stride):
+        raise NotImplementedError("REDUCE_AND_STRIDE is outside the built hot path (SURVEY.md §2a P9)")
+    bcoords_in = input_sparse_tensor.batch_indexed_coordinates
+    if bcoords_in.dtype != torch.int32:
+        bcoords_in = bcoords_in.to(torch.int32)
+
+    if output_spatially_sparse_tensor is not None:
+        bcoords_out = output_spatially_sparse_tensor.batch_indexed_coordinates.to(torch.int32)
+        out_offsets = output_spatially_sparse_tensor.offsets
+    elif any(s != 1 for s in stride):
+        bcoords_out, out_offsets = stride_coords(bcoords_in, stride)
+    else:
+        bcoords_out, out_offsets = bcoords_in, input_sparse_tensor.offsets
+
+    key = IntSearchCacheKey(kernel_size, kernel_dilation, transposed, generative, str(stride_mode), False,
+                            input_sparse_tensor.offsets, out_offsets)
+    if input_sparse_tensor.cache is not None:
+        hit = input_sparse_tensor.cache.get(key)
+        if hit is not None:
+            return bcoords_out, out_offsets, hit
+
+    if transposed:
+        # the forward (fine -> coarse) map may sit in either tensor's cache; reuse it swapped
+        fwd_key = IntSearchCacheKey(kernel_size, kernel_dilation, False, generative, str(stride_mode), False,
+                                    out_offsets, input_sparse_tensor.offsets)
+        for source in (input_sparse_tensor, output_spatially_sparse_tensor):
+            if source is not None and source.cache is not None:
+                fwd = source.cache.get(fwd_key)
+                if fwd is not None:
+                    return bcoords_out, out_offsets, _swap(fwd)
+        kernel_map = _swap(generate_kernel_map(bcoords_out, bcoords_in, stride, kernel_size, kernel_dilation))
+    else:
+        kernel_map = generate_kernel_map(bcoords_in, bcoords_out, stride, kernel_size, kernel_dilation)
+
+    if input_sparse_tensor.cache is None:
+        input_sparse_tensor._extra_attributes["_cache"] = IntSearchCache()
+    input_sparse_tensor.cache.put(key, kernel_map)
+    return bcoords_out, out_offsets, kernel_map
+
+
+def spatially_sparse_conv(
+    input_sparse_tensor: Geometry,
+    weight: Tensor,
+    kernel_size: Union[int, List[int], Tuple[int, ...]],
+    stride: Union[int, List[int], Tuple[int, ...]] = 1,
+    kernel_dilation: Union[int, List[int], Tuple[int, ...]] = 1,
+    bias: Optional[Tensor] = None,
+    groups: int = 1,
+    use_fp16_accum: Optional[bool] = None,
+    kernel_matmul_batch_size: int = 2,
+    generative: bool = False,
+    output_spatially_sparse_tensor: Optional[Geometry] = None,
+    transposed: bool = False,
+    fwd_algo=SPARSE_CONV_AB_ALGO_MODE.AUTO,
+    dgrad_algo=SPARSE_CONV_AB_ALGO_MODE.AUTO,
+    wgrad_algo=SPARSE_CONV_ATB_ALGO_MODE.AUTO,
+    stride_mode: STRIDED_CONV_MODE = STRIDED_CONV_MODE.STRIDE_ONLY,
+    stride_reduce: str = "max",
+    order=None,
+    compute_dtype: Optional[torch.dtype] = None,
+    implicit_matmul_fwd_block_size: Optional[int] = 16,
+    implicit_matmul_bwd_block_size: Optional[int] = 16,
+) -> Geometry:
+    if not isinstance(input_sparse_tensor, Voxels):
+        raise TypeError(f"spatially_sparse_conv expects input_sparse_tensor of type Voxels, got {type(input_sparse_tensor)}")
+    if output_spatially_sparse_tensor is not None and not isinstance(output_spatially_sparse_tensor, Voxels):
+        raise TypeError(
+            f"spatially_sparse_conv expects output_spatially_sparse_tensor of type Voxels or None, got {type(output_spatially_sparse_tensor)}"
+        )
+    nd = input_sparse_tensor.num_spatial_dims
+    _kernel_size = ntuple(kernel_size, ndim=nd)
+    _dilation = ntuple(kernel_dilation, ndim=nd)
+    _stride = ntuple(stride, ndim=nd)
+
+    # 1x1 kernel, stride 1: a plain matmul on the features (reference helper.py:206-213)
+    if int(np.prod(_kernel_size)) == 1 and int(np.prod(_stride)) == 1:
+        feats = input_sparse_tensor.feature_tensor
+        out = feats @ weight[0].to(feats.dtype)
+        if bias is not None:
+            out = out + bias.to(out.dtype)
+        return input_sparse_tensor.replace(batched_features=out)
+
+    in_tensor_stride = input_sparse_tensor.tensor_stride or ntuple(1, ndim=nd)
+    if transposed and not generative:
+        assert output_spatially_sparse_tensor is not None, (
+            "Output spatially sparse tensor is required for transposed convolution without generative"
+        )
+    if not transposed:
+        out_tensor_stride = tuple(o * s for o, s in zip(_stride, in_tensor_stride))
+    elif generative:
+        out_tensor_stride = tuple(i // s for i, s in zip(in_tensor_stride, _stride))
+    else:
+        out_tensor_stride = output_spatially_sparse_tensor.tensor_stride or ntuple(1, ndim=nd)
+        assert any(o < i for o, i in zip(out_tensor_stride, in_tensor_stride)), "Output stride is larger than input stride"
+
+    # compute dtype: explicit argument > autocast dtype > feature dtype (reference helper.py:246-254)
+    if compute_dtype is not None:
+        effective_dtype = compute_dtype
+    elif torch.is_autocast_enabled():
+        effective_dtype = torch.get_autocast_dtype("cuda")
+    else:
+        effective_dtype = input_sparse_tensor.feature_tensor.dtype
+    if use_fp16_accum is None:
+        use_fp16_accum = get_fp16_accum()  # accepted for API parity: MFMA accumulates in fp32 regardless
+
+    bcoords_out, out_offsets, kernel_map = generate_output_coords_and_kernel_map(
+        input_sparse_tensor, _kernel_size, _dilation, _stride, generative=generative, transposed=transposed,
+        output_spatially_sparse_tensor=output_spatially_sparse_tensor, stride_mode=stride_mode, order=order,
+    )
+    num_out = bcoords_out.shape[0]
+
+    # cast BEFORE Function.apply so the tensors saved for backward are in compute precision
+    feats = input_sparse_tensor.feature_tensor
+    if feats.dtype != effective_dtype:
+        feats = feats.to(effective_dtype)
+    w = weight if weight.dtype == effective_dtype else weight.to(effective_dtype)
+
+    out_feats = UnifiedSpatiallySparseConvFunction.apply(
+        feats, w, kernel_map, num_out, fwd_algo, dgrad_algo, wgrad_algo, effective_dtype,
+        implicit_matmul_fwd_block_size, implicit_matmul_bwd_block_size, in_tensor_stride,
+        {"conv_stride": _stride, "transposed": transposed, "generative": generative,
+         "stride_mode": getattr(stride_mode, "value", str(stride_mode))},
+        groups, use_fp16_accum,
+    )
+    if bias is not None:
+        out_feats = out_feats + bias.to(out_feats.dtype)
+
+    out_offsets_cpu = out_offsets.cpu().int() if out_offsets.dtype != torch.int32 or out_offsets.device.type != "cpu" else out_offsets
+    return input_sparse_tensor.replace(
+        batched_coordinates=IntCoords(bcoords_out[:, 1:], offsets=out_offsets_cpu),
+        batched_features=out_feats,
+        tensor_stride=out_tensor_stride,
+    )
