@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""Headline benchmark: M active voxels / s, forward + backward of SparseConv3d(64 -> 128, k=3), bf16.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = the whole hot path on one resident ~1M-voxel scene per GPU (BASELINE.json configs[1]):
+kernel-map build (hash + probe + per-offset bucketing + mask sort) + AB forward + ABt dgrad + AtB wgrad,
+through the SparseConv3d module under bf16 autocast, then (N > 1) one RCCL all-reduce of the weight/bias
+gradients.  Inputs (coordinates, features, grad_out, fp32 master weights) are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+CIN, COUT, KVOL = 64, 128, 27
+
+
+def scene_u(n, seed):
+    """Reference-style uniform scene (scripts/populate_benchmark_cache.py:283-309): extent 2*ceil(n^(1/3)),
+    draw 1.3n coordinates, unique, truncate to n.  Occupancy ~0.15, L/N ~4.7."""
+    rng = np.random.default_rng(seed)
+    extent = 2 * int(np.ceil(n ** (1.0 / 3.0)))
+    c = rng.integers(0, extent, size=(int(1.3 * n), 3))
+    _, first = np.unique(c, axis=0, return_index=True)
+    return c[np.sort(first)][:n].astype(np.int32)
+
+
+def algorithmic_bytes(N, L, cin=CIN, cout=COUT, K=KVOL, e=2):
+    """SURVEY.md §8(d) per-iteration algorithmic bytes (N_in = N_out = N)."""
+    cap = 1 << int(np.ceil(np.log2(max(16, 2 * N))))
+    kmap = 16 * N + 12 * cap + 12 * N + 16 * N + 8 * K * N + 4 * L + 4 * K * N + 8 * L
+    fwd = L * cin * e + K * cin * cout * e + N * cout * e + 4 * K * N
+    dgrad = L * cout * e + K * cin * cout * e + N * cin * e + 4 * K * N
+    wgrad = L * (cin + cout) * e + 4 * K * cin * cout + 4 * K * N
+    return dict(kmap=kmap, fwd=fwd, dgrad=dgrad, wgrad=wgrad)
+
+
+def time_events(fn, iters, warmup=2):
+    """Average milliseconds per call measured with HIP events on the current stream."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def cpu_baseline(n_sample, seed):
+    """The oracle (CPU port of the reference's explicit path) timed on the host cores: C kernel-map restatement
+    (1 thread) + torch fp32 gather-matmul-scatter forward/backward (all threads) on a bounded sample."""
+    from oracle import conv as oconv
+    from oracle import kmap as okmap
+
+    c = scene_u(n_sample, seed)
+    bc = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(len(c), CIN, generator=g)
+    W = torch.randn(KVOL, CIN, COUT, generator=g) * 0.05
+    dY = torch.randn(len(c), COUT, generator=g)
+    t0 = time.perf_counter()
+    r = okmap.kernel_map(bc, bc, (3, 3, 3))
+    t1 = time.perf_counter()
+    oconv.forward(X, W, r["in_maps"], r["out_maps"], r["offsets"], len(c), 13)  # warm-up (thread pool, pages)
+    t2 = time.perf_counter()
+    oconv.forward(X, W, r["in_maps"], r["out_maps"], r["offsets"], len(c), 13)
+    oconv.backward(dY, X, W, r["in_maps"], r["out_maps"], r["offsets"], 13)
+    t3 = time.perf_counter()
+    total = (t1 - t0) + (t3 - t2)
+    return dict(value=round(len(c) / total / 1e6, 4), unit="M voxels/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(c)} voxels of the same generator, 64->128 k=3 fp32: kernel map {t1 - t0:.2f}s (C, 1 thread) "
+                       f"+ fwd+bwd {t3 - t2:.2f}s (torch CPU, {torch.get_num_threads()} threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--voxels", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from warpconvnet_amd import _lib
+    from warpconvnet_amd.dist import allreduce_gradients
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    _lib.lib()  # fail loudly if the HIP extension is missing
+
+    # ---- resident inputs: one scene per GPU (weak scaling), identical weights on every rank ----
+    coords = torch.from_numpy(scene_u(args.voxels, seed=1000 + rank)).to(dev)
+    N = coords.shape[0]
+    g = torch.Generator().manual_seed(rank)
+    feats = torch.randn(N, CIN, generator=g).to(dev)
+    grad_out = torch.randn(N, COUT, generator=g).to(dev, torch.bfloat16)
+    offsets = torch.tensor([0, N], dtype=torch.int32)
+    torch.manual_seed(0)
+    conv = SparseConv3d(CIN, COUT, 3, bias=True).to(dev)
+    params = [p for p in conv.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        x = Voxels(coords, feats, offsets=offsets)  # fresh geometry -> kernel map rebuilt every step
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(x)
+        y.batched_features.batched_tensor.backward(grad_out)
+        if world > 1:
+            allreduce_gradients(params)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = N * world * args.steps / elapsed / 1e6
+
+    result = None
+    if rank == 0:
+        # ---- per-phase / per-kernel timing with HIP events on the launch stream (rank 0) ----
+        from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+        bcoords = torch.cat([torch.zeros(N, 1, dtype=torch.int32, device=dev), coords], 1).contiguous()
+        km = generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3))
+        L = int(km.offsets[-1])
+        X = feats.to(torch.bfloat16)
+        W = conv.weight.detach().to(torch.bfloat16)
+        it = max(5, args.steps)
+        t_kmap = time_events(lambda: generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3)), it)
+        t_fwd = time_events(lambda: hip_gemm.hip_forward(X, W, km, N, "hip_mfma"), it)
+        t_dgrad = time_events(lambda: hip_gemm.hip_dgrad(grad_out, W, km, N, "hip_mfma"), it)
+        t_wgrad = time_events(lambda: hip_gemm.hip_wgrad(X, grad_out, km, (KVOL, CIN, COUT), "hip_mfma"), it)
+        # dominant kernel alone: exactly one launch per event pair (weights pre-packed)
+        Lc = _lib.lib()
+        stream = _lib.stream_handle(dev)
+        wp_f = hip_gemm.pack_weight(W, False, False)
+        wp_d = hip_gemm.pack_weight(W, True, True)
+        y_buf = torch.empty(N, COUT, dtype=torch.bfloat16, device=dev)
+        dx_buf = torch.empty(N, CIN, dtype=torch.bfloat16, device=dev)
+
+        def k_fwd():
+            Lc.wcn_conv_gather_gemm(_lib.ptr(X), _lib.ptr(wp_f), _lib.ptr(y_buf), _lib.ptr(km._nbr), _lib.ptr(km._mask),
+                                    _lib.ptr(km._perm), N, N, CIN, COUT, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 0, 0, stream)
+
+        def k_dgrad():
+            Lc.wcn_conv_gather_gemm(_lib.ptr(grad_out), _lib.ptr(wp_d), _lib.ptr(dx_buf), _lib.ptr(km._nbr), _lib.ptr(km._mask),
+                                    _lib.ptr(km._perm), N, N, COUT, CIN, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 1, 1, stream)
+
+        tk_fwd, tk_dgrad = time_events(k_fwd, it), time_events(k_dgrad, it)
+        ab = algorithmic_bytes(N, L)
+        kernels = {
+            "gather_gemm_mfma_kernel<bf16,64,128> (fwd)": (tk_fwd, ab["fwd"]),
+            "gather_gemm_mfma_kernel<bf16,64,64> (dgrad)": (tk_dgrad, ab["dgrad"]),
+            "wgrad_mfma_kernel<bf16,64,128> (+reduce)": (t_wgrad, ab["wgrad"]),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dom_ms, dom_bytes = kernels[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        total_bytes = sum(ab.values())
+        result = {
+            "metric": "M active voxels/sec fwd+bwd, SparseConv3d 64->128 k=3",
+            "value": round(value, 3),
+            "unit": "M voxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: one {N}-voxel uniform (U) scene per GPU, SparseConv3d 64->128 k=3, bf16 autocast, "
+                            "kernel-map build + AB fwd + ABt dgrad + AtB wgrad per step",
+                "voxels_per_gpu": N, "pairs_per_scene": L, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
+            },
+            "phases_ms": {"kmap": round(t_kmap, 4), "fwd": round(t_fwd, 4), "dgrad": round(t_dgrad, 4), "wgrad": round(t_wgrad, 4),
+                          "fwd_kernel_only": round(tk_fwd, 4), "dgrad_kernel_only": round(tk_dgrad, 4)},
+            "whole_step_hbm_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,292 @@
+"""GPU: the three sparse-conv GEMMs (HIP, through the C-ABI) vs the CPU oracle and the golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import conv as oconv
+from oracle import kmap as okmap
+from tests.util import rel_max_err, scene_surface, scene_u
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances of the reference's own tests (tests/nn/test_kernel_correctness.py:64-65, 139-145):
+# max|d| / max|ref| < 1e-3 for fp32, < 2e-2 for fp16 / bf16.
+TOL = {torch.float32: 1e-3, torch.float16: 2e-2, torch.bfloat16: 2e-2}
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _kmap(in_np, out_np, ksize, stride=(1, 1, 1), same=False):
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+    a = torch.from_numpy(in_np).to(_dev())
+    b = a if same else torch.from_numpy(out_np).to(_dev())
+    return generate_kernel_map(a, b, stride, ksize)
+
+
+def _run_all(km, X, W, dY, algo, num_in, num_out):
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    Y = hip_gemm.hip_forward(X, W, km, num_out, algo)
+    dX = hip_gemm.hip_dgrad(dY, W, km, num_in, algo)
+    dW = hip_gemm.hip_wgrad(X, dY, km, tuple(W.shape), algo)
+    return Y, dX, dW
+
+
+def _oracle(r, X, W, dY, num_out, iden=None):
+    """fp64 oracle on the values the GPU actually saw (inputs already rounded to the storage dtype)."""
+    Xd, Wd, dYd = X.double().cpu(), W.double().cpu(), dY.double().cpu()
+    Y = oconv.forward(Xd, Wd, r["in_maps"], r["out_maps"], r["offsets"], num_out, iden)
+    dX, dW = oconv.backward(dYd, Xd, Wd, r["in_maps"], r["out_maps"], r["offsets"], iden)
+    return Y, dX, dW
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "explicit_*f32*.npz"))))
+@pytest.mark.parametrize("algo", ["hip_ref", "auto"])
+def test_golden_vectors_fp32(golden_dir, name, algo):
+    g = np.load(os.path.join(golden_dir, name))
+    same = g["in_coords"].shape == g["out_coords"].shape and (g["in_coords"] == g["out_coords"]).all()
+    km = _kmap(g["in_coords"], g["out_coords"], tuple(g["ksize"]), tuple(g["stride"]), same=same)
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), g["in_maps"])
+    np.testing.assert_array_equal(km.out_maps.cpu().numpy(), g["out_maps"])
+    dev = _dev()
+    X, W, dY = (torch.from_numpy(g[k]).to(dev) for k in ("X", "W", "dY"))
+    Y, dX, dW = _run_all(km, X, W, dY, algo, len(g["in_coords"]), len(g["out_coords"]))
+    for got, want in ((Y, g["Y"]), (dX, g["dX"]), (dW, g["dW"])):
+        assert rel_max_err(got, torch.from_numpy(want)) < TOL[torch.float32]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (32, 32), (16, 32), (96, 96), (64, 256), (256, 64), (128, 128)])
+def test_mfma_vs_oracle_submanifold(dtype, cin, cout):
+    s = np.concatenate([scene_u(3000, 21, 0), scene_u(1500, 22, 1)], 0)
+    km = _kmap(s, s, (3, 3, 3), same=True)
+    r = okmap.kernel_map(s, s, (3, 3, 3))
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin * 1000 + cout)
+    X = torch.randn(len(s), cin, generator=g).to(dev, dtype)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev, dtype)
+    dY = torch.randn(len(s), cout, generator=g).to(dev, dtype)
+    Y, dX, dW = _run_all(km, X, W, dY, "hip_mfma" if (cin % 64 == 0 and cout % 64 == 0) else "auto", len(s), len(s))
+    assert Y.dtype == dtype and dX.dtype == dtype and dW.dtype == torch.float32
+    Yr, dXr, dWr = _oracle(r, X, W, dY, len(s))
+    assert rel_max_err(Y, Yr) < TOL[dtype]
+    assert rel_max_err(dX, dXr) < TOL[dtype]
+    assert rel_max_err(dW, dWr) < TOL[dtype]
+    # hip_ref on the same inputs agrees too (fp32 accumulate, storage-dtype rounding only at the end)
+    Y2, dX2, dW2 = _run_all(km, X, W, dY, "hip_ref", len(s), len(s))
+    assert rel_max_err(Y2, Yr) < TOL[dtype] and rel_max_err(dX2, dXr) < TOL[dtype] and rel_max_err(dW2, dWr) < 1e-3
+
+
+@pytest.mark.parametrize("ksize,stride", [((2, 2, 2), (2, 2, 2)), ((3, 3, 3), (2, 2, 2))])
+def test_mfma_strided_and_transposed(ksize, stride):
+    from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+
+    s = scene_u(6000, 31)
+    coarse, _ = okmap.stride_coords(s, stride)
+    km = _kmap(s, coarse, ksize, stride)
+    r = okmap.kernel_map(s, coarse, ksize, stride)
+    dev, dtype = _dev(), torch.bfloat16
+    K = int(np.prod(ksize))
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(len(s), 64, generator=g).to(dev, dtype)
+    W = (torch.randn(K, 64, 128, generator=g) * 0.05).to(dev, dtype)
+    dY = torch.randn(len(coarse), 128, generator=g).to(dev, dtype)
+    Y, dX, dW = _run_all(km, X, W, dY, "hip_mfma", len(s), len(coarse))
+    Yr, dXr, dWr = _oracle(r, X, W, dY, len(coarse))
+    assert rel_max_err(Y, Yr) < 2e-2 and rel_max_err(dX, dXr) < 2e-2 and rel_max_err(dW, dWr) < 2e-2
+    # transposed conv = same map with in/out swapped (coarse -> fine), weight [K, 128, 64]
+    sw = IntSearchResult(km.out_maps, km.in_maps, km.offsets)
+    rs = dict(in_maps=r["out_maps"], out_maps=r["in_maps"], offsets=r["offsets"])
+    Xt = torch.randn(len(coarse), 128, generator=g).to(dev, dtype)
+    Wt = (torch.randn(K, 128, 64, generator=g) * 0.05).to(dev, dtype)
+    dYt = torch.randn(len(s), 64, generator=g).to(dev, dtype)
+    Y, dX, dW = _run_all(sw, Xt, Wt, dYt, "hip_mfma", len(coarse), len(s))
+    Yr, dXr, dWr = _oracle(rs, Xt, Wt, dYt, len(s))
+    assert rel_max_err(Y, Yr) < 2e-2 and rel_max_err(dX, dXr) < 2e-2 and rel_max_err(dW, dWr) < 2e-2
+
+
+def test_known_answer_patterns_gpu(golden_dir):
+    """Hand-made weight / feature patterns (reference tests/nn/test_kernel_deterministic.py:128-183):
+    fp32 rtol 1e-4 / atol 1e-3, fp16 rtol 8e-3 / atol 5e-2 (:81-84)."""
+    from tests.golden.make_golden import make_feats, make_grad_out, make_weight
+
+    g = np.load(os.path.join(golden_dir, "known_answer.npz"))
+    s = g["coords"]
+    km = _kmap(s, s, (3, 3, 3), same=True)
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), g["in_maps"])
+    dev, n = _dev(), len(s)
+    for cin, cout in [(8, 8), (7, 13), (32, 16)]:
+        for wp in ["ones", "triu", "tril", "eye", "center_eye"]:
+            for fp in ["ones", "range", "row_index"]:
+                tag = f"{cin}x{cout}_{wp}_{fp}"
+                W = make_weight(27, cin, cout, wp, torch.float32).to(dev)
+                X = make_feats(n, cin, fp, torch.float32).to(dev)
+                dY = make_grad_out(n, cout, torch.float32).to(dev)
+                Y, dX, dW = _run_all(km, X, W, dY, "auto", n, n)
+                torch.testing.assert_close(Y.cpu(), torch.from_numpy(g[f"Y_{tag}"]), rtol=1e-4, atol=1e-3)
+                torch.testing.assert_close(dX.cpu(), torch.from_numpy(g[f"dX_{tag}"]), rtol=1e-4, atol=1e-3)
+                torch.testing.assert_close(dW.cpu(), torch.from_numpy(g[f"dW_{tag}"]), rtol=1e-4, atol=2e-2)
+    # half precision on an MFMA-covered shape: a centre-identity weight is an exact pass-through
+    W = make_weight(27, 64, 64, "center_eye", torch.float32).to(dev, torch.float16)
+    X = make_feats(n, 64, "row_index", torch.float32).to(dev, torch.float16)
+    Y, _, _ = _run_all(km, X, W, make_grad_out(n, 64, torch.float32).to(dev, torch.float16), "hip_mfma", n, n)
+    assert torch.equal(Y, X)
+    W = make_weight(27, 64, 64, "triu", torch.float32).to(dev, torch.float16)
+    Y, dX, dW = _run_all(km, X, W, make_grad_out(n, 64, torch.float32).to(dev, torch.float16), "hip_mfma", n, n)
+    r = okmap.kernel_map(s, s, (3, 3, 3))
+    Yr, dXr, dWr = _oracle(r, X, W, make_grad_out(n, 64, torch.float32).to(dev, torch.float16), n)
+    torch.testing.assert_close(Y.double().cpu(), Yr, rtol=8e-3, atol=5e-2)
+    torch.testing.assert_close(dX.double().cpu(), dXr, rtol=8e-3, atol=5e-2)
+
+
+def test_module_forward_backward_amp():
+    """SparseConv3d under autocast(bf16): module API end to end, dtype policy, cache reuse, grads vs oracle
+    (mean relative diff < 0.02, reference tests/nn/test_sparse_conv.py:921-923)."""
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    parts = [scene_u(4000, 41)[:, 1:], scene_u(3000, 42)[:, 1:]]
+    feats = [torch.randn(len(p), 64) for p in parts]
+    vox = Voxels([torch.from_numpy(p) for p in parts], feats, device=dev)
+    torch.manual_seed(0)
+    conv = SparseConv3d(64, 128, 3).to(dev)
+    x = vox.replace(batched_features=vox.feature_tensor.detach().clone().requires_grad_(True))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(x)
+    assert y.feature_tensor.dtype == torch.bfloat16 or y.batched_features.dtype == torch.bfloat16
+    assert len(x.cache) == 1 and y.cache is x.cache
+    loss = (y.batched_features.batched_tensor.float() ** 2).mean()
+    loss.backward()
+    assert conv.weight.grad.dtype == torch.float32 and conv.weight.grad.shape == conv.weight.shape
+    assert x.batched_features.batched_tensor.grad.shape == (7000, 64)
+    # oracle in fp64 on the fp32 master values
+    bc = vox.batch_indexed_coordinates.cpu().numpy().astype(np.int32)
+    r = okmap.kernel_map(bc, bc, (3, 3, 3))
+    X = vox.feature_tensor.detach().double().cpu()
+    Wd = conv.weight.detach().double().cpu()
+    Yr = oconv.forward(X, Wd, r["in_maps"], r["out_maps"], r["offsets"], len(bc)) + conv.bias.detach().double().cpu()
+    got = y.batched_features.batched_tensor.detach().double().cpu()
+    assert ((got - Yr).abs().mean() / Yr.abs().mean()).item() < 0.02
+    dY = (2.0 / Yr.numel()) * got  # d(mean(y^2))/dy at the GPU's y
+    dXr, dWr = oconv.backward(dY, X, Wd, r["in_maps"], r["out_maps"], r["offsets"])
+    gw = conv.weight.grad.double().cpu()
+    assert ((gw - dWr).abs().mean() / dWr.abs().mean()).item() < 0.02
+    gx = x.batched_features.batched_tensor.grad.double().cpu()
+    assert ((gx - dXr).abs().mean() / dXr.abs().mean()).item() < 0.02
+    assert ((conv.bias.grad.double().cpu() - dY.sum(0)).abs().max() / dY.sum(0).abs().max()).item() < 0.02
+    # second layer at the same resolution reuses the cached map (no rebuild)
+    conv2 = SparseConv3d(128, 64, 3).to(dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        z = conv2(y)
+    assert len(x.cache) == 1 and z.num_channels == 64
+
+
+def test_unet_style_down_up():
+    """Strided conv then transposed conv back onto the encoder tensor (MinkUNet ConvBlock / ConvTrBlock,
+    reference models/mink_unet.py:83-90, 286-339): shapes, tensor strides, map reuse, explicit-vs-HIP agreement."""
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    p = scene_surface(100, 3)[:, 1:]
+    vox = Voxels([torch.from_numpy(p)], [torch.randn(len(p), 32)], device=dev)
+    torch.manual_seed(1)
+    down = SparseConv3d(32, 64, 2, stride=2).to(dev)
+    up = SparseConv3d(64, 32, 2, stride=2, transposed=True).to(dev)
+    outs = {}
+    for algo in ("explicit_gemm", "auto"):
+        for m in (down, up):
+            m.fwd_algo = m.dgrad_algo = type(m.fwd_algo)(algo)
+            m.wgrad_algo = type(m.wgrad_algo)(algo)
+            m.zero_grad()
+        x = vox.replace(batched_features=vox.feature_tensor.detach().clone().to(torch.bfloat16).requires_grad_(True))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            d = down(x)
+            u = up(d, x)
+        assert d.tensor_stride == (2, 2, 2) and u.tensor_stride == (1, 1, 1)
+        assert u.batched_features.batched_tensor.shape == (len(p), 32)
+        assert torch.equal(u.coordinate_tensor, x.coordinate_tensor)
+        u.batched_features.batched_tensor.float().square().sum().backward()
+        outs[algo] = (u.batched_features.batched_tensor.detach().float(), down.weight.grad.clone(), up.weight.grad.clone(),
+                      x.batched_features.batched_tensor.grad.float())
+    for a, b in zip(outs["explicit_gemm"], outs["auto"]):
+        assert rel_max_err(b, a) < 3e-2
+
+
+def test_empty_inputs_and_errors():
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+    from warpconvnet_amd.nn.functional.sparse_conv.detail.backends import FwdCtx, run_forward
+
+    dev = _dev()
+    e = np.zeros((0, 4), np.int32)
+    km = _kmap(e, e, (3, 3, 3), same=True)
+    W = torch.randn(27, 64, 128, device=dev, dtype=torch.bfloat16)
+    Y = hip_gemm.hip_forward(torch.zeros(0, 64, device=dev, dtype=torch.bfloat16), W, km, 0)
+    assert Y.shape == (0, 128)
+    dW = hip_gemm.hip_wgrad(torch.zeros(0, 64, device=dev, dtype=torch.bfloat16), torch.zeros(0, 128, device=dev, dtype=torch.bfloat16), km, (27, 64, 128))
+    assert dW.shape == (27, 64, 128) and float(dW.abs().max()) == 0.0
+    s = scene_u(100, 1)
+    km = _kmap(s, s, (3, 3, 3), same=True)
+    with pytest.raises(RuntimeError):  # explicit request for the MFMA path on an uncovered shape fails loudly
+        hip_gemm.hip_forward(torch.zeros(100, 7, device=dev, dtype=torch.bfloat16), torch.zeros(27, 7, 13, device=dev, dtype=torch.bfloat16), km, 100, "hip_mfma")
+    with pytest.raises(RuntimeError):  # mixed precision inputs
+        hip_gemm.hip_forward(torch.zeros(100, 64, device=dev), W, km, 100)
+    with pytest.raises(ValueError):
+        run_forward("no_such_algo", FwdCtx(torch.zeros(1, 1), torch.zeros(1, 1, 1), km, 1, None, {}))
+    with pytest.raises(RuntimeError):  # CPU tensors never reach a HIP kernel
+        hip_gemm.hip_forward(torch.zeros(100, 64, dtype=torch.bfloat16), W.cpu(), km, 100)
+
+
+def test_full_size_properties():
+    """BASELINE config 2 shape (1M voxels, 64 -> 128, bf16): size-independent properties instead of the serial
+    oracle - linearity in X, pass-through of a centre-identity weight, dW consistency with an fp32
+    torch reference on one offset, sub-sampled rows against the oracle."""
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    dev, dtype = _dev(), torch.bfloat16
+    s = scene_u(1_000_000, 0)
+    km = _kmap(s, s, (3, 3, 3), same=True)
+    N = len(s)
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N, 64, generator=g).to(dev, dtype)
+    W = (torch.randn(27, 64, 128, generator=g) * 0.05).to(dev, dtype)
+    dY = torch.randn(N, 128, generator=g).to(dev, dtype)
+    Y = hip_gemm.hip_forward(X, W, km, N, "hip_mfma")
+    # (1) linearity: conv(2X) == 2 conv(X) exactly (power-of-two scaling commutes with rounding)
+    assert torch.equal(hip_gemm.hip_forward(X * 2, W, km, N, "hip_mfma"), Y * 2)
+    # (2) centre identity weight is a pass-through
+    We = torch.zeros(27, 64, 128, device=dev, dtype=dtype)
+    We[13, :, :64] = torch.eye(64, device=dev, dtype=dtype)
+    Ye = hip_gemm.hip_forward(X, We, km, N, "hip_mfma")
+    assert torch.equal(Ye[:, :64], X) and float(Ye[:, 64:].abs().max()) == 0.0
+    # (3) sub-sampled rows against the fp64 oracle (explicit formula per row from the pair table)
+    pt = km._pair_table
+    rows = torch.randint(0, N, (512,), generator=g).to(dev)
+    ref = torch.zeros(512, 128, dtype=torch.float64, device=dev)
+    for k in range(27):
+        idx = pt[k][rows].long()
+        valid = (idx >= 0).double().unsqueeze(1)
+        ref += (X[idx.clamp_min(0)].double() * valid) @ W[k].double()
+    assert rel_max_err(Y[rows], ref) < 2e-2
+    # (4) dgrad is the adjoint of forward: <conv(X), dY> == <X, dgrad(dY)>
+    dX = hip_gemm.hip_dgrad(dY, W, km, N, "hip_mfma")
+    lhs = (Y.double() * dY.double()).sum().item()
+    rhs = (X.double() * dX.double()).sum().item()
+    assert abs(lhs - rhs) / abs(lhs) < 2e-2
+    # (5) wgrad: <W, dW> == <conv(X), dY>; and bucket 13 equals the dense X^T dY
+    dW = hip_gemm.hip_wgrad(X, dY, km, (27, 64, 128), "hip_mfma")
+    assert abs((W.double() * dW.double()).sum().item() - lhs) / abs(lhs) < 2e-2
+    dense = X.float().T @ dY.float()
+    assert rel_max_err(dW[13], dense) < 2e-2
+    # (6) run-to-run determinism of all three kernels
+    assert torch.equal(hip_gemm.hip_forward(X, W, km, N, "hip_mfma"), Y)
+    assert torch.equal(hip_gemm.hip_dgrad(dY, W, km, N, "hip_mfma"), dX)
+    assert torch.equal(hip_gemm.hip_wgrad(X, dY, km, (27, 64, 128), "hip_mfma"), dW)

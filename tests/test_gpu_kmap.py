@@ -1,0 +1,176 @@
+"""GPU: HIP kernel-map construction vs the oracle (bit-exact indices), through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kmap as okmap
+from tests.util import scene_surface, scene_u, sort_buckets
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _gen(in_np, out_np, ksize, stride=(1, 1, 1), dilation=None, same=False):
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+    dev = _dev()
+    a = torch.from_numpy(in_np).to(dev)
+    b = a if same else torch.from_numpy(out_np).to(dev)
+    return generate_kernel_map(a, b, stride, ksize, dilation)
+
+
+def _check_against_oracle(km, in_np, out_np, ksize, stride=(1, 1, 1), dilation=(1, 1, 1)):
+    r = okmap.kernel_map(in_np, out_np, ksize, stride, dilation)
+    K = len(r["offsets"]) - 1
+    # pair table bit-exact (reference layout [K, M])
+    np.testing.assert_array_equal(km._pair_table.cpu().numpy(), r["found"])
+    # row-major table: same content, pad columns are -1
+    nbr = km._nbr.cpu().numpy()
+    np.testing.assert_array_equal(nbr[:, :K].T, r["found"])
+    assert (nbr[:, K:] == -1).all()
+    np.testing.assert_array_equal(km.offsets.numpy(), r["offsets"])
+    np.testing.assert_array_equal(km._offsets_dev.cpu().numpy(), r["offsets"])
+    # buckets come out ordered by output row -> equal to the canonical oracle order without sorting
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+    np.testing.assert_array_equal(km.out_maps.cpu().numpy(), r["out_maps"])
+    np.testing.assert_array_equal(km._mask.cpu().numpy().view(np.uint32), r["mask"])
+    # permutation: a permutation of all rows, masks non-increasing along it
+    perm = km._perm.cpu().numpy()
+    assert sorted(perm.tolist()) == list(range(len(out_np)))
+    m0 = r["mask"][:, 0][perm].astype(np.int64)
+    assert (np.diff(m0) <= 0).all()
+    return r
+
+
+@pytest.mark.parametrize("n,ksize", [(5000, (3, 3, 3)), (3000, (5, 5, 5)), (4000, (3, 1, 2)), (2000, (2, 2, 2)), (777, (3, 3, 1))])
+def test_submanifold_map_bit_exact(n, ksize):
+    s = np.concatenate([scene_u(n, 1, 0), scene_u(n // 2, 2, 1)], 0)
+    km = _gen(s, s, ksize, same=True)
+    K = int(np.prod(ksize))
+    r = _check_against_oracle(km, s, s, ksize)
+    if all(k % 2 == 1 for k in ksize):
+        assert km.identity_map_index == K // 2 and km._symmetric
+        np.testing.assert_array_equal(km._pair_table.cpu().numpy()[K // 2], np.arange(len(s)))
+    else:
+        assert km.identity_map_index is None and not km._symmetric
+    assert len(km) == K and km.numel(0) == r["offsets"][1]
+
+
+@pytest.mark.parametrize("ksize,stride", [((2, 2, 2), (2, 2, 2)), ((3, 3, 3), (2, 2, 2)), ((2, 2, 2), (4, 4, 4)), ((3, 3, 3), (1, 2, 1))])
+def test_strided_map_bit_exact(ksize, stride):
+    from warpconvnet_amd.geometry.coords.ops.stride import stride_coords
+
+    s = np.concatenate([scene_u(6000, 3, 0), scene_u(5000, 4, 1), scene_u(10, 5, 2)], 0)
+    s[:, 1:] -= 7  # negative coordinates
+    want, _ = okmap.stride_coords(s, stride)
+    got, offs = stride_coords(torch.from_numpy(s).to(_dev()), stride)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)  # first-occurrence order is deterministic
+    np.testing.assert_array_equal(offs.numpy(), np.concatenate([[0], np.cumsum(np.bincount(want[:, 0], minlength=3))]))
+    km = _gen(s, want, ksize, stride)
+    _check_against_oracle(km, s, want, ksize, stride)
+    assert km.identity_map_index is None and not km._symmetric
+
+
+def test_dilation_and_2d():
+    s = scene_u(3000, 9)
+    km = _gen(s, s, (3, 3, 3), dilation=(2, 2, 2), same=True)
+    _check_against_oracle(km, s, s, (3, 3, 3), dilation=(2, 2, 2))
+    s2 = np.unique(s[:, :3], axis=0)  # [b, x, y]
+    km2 = _gen(s2, s2, (3, 3), stride=(1, 1), same=True)
+    s2p = np.concatenate([s2, np.zeros((len(s2), 1), np.int32)], 1)
+    _check_against_oracle(km2, s2p, s2p, (3, 3, 1))
+
+
+def test_reverse_table_and_from_csr():
+    from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import attach_tables_from_csr, reverse_tables
+
+    s = scene_u(5000, 11)
+    coarse, _ = okmap.stride_coords(s, (2, 2, 2))
+    km = _gen(s, coarse, (2, 2, 2), (2, 2, 2))
+    r = okmap.kernel_map(s, coarse, (2, 2, 2), (2, 2, 2))
+    rev_nbr, rev_mask, rev_perm = reverse_tables(km, len(s))
+    np.testing.assert_array_equal(rev_nbr.cpu().numpy()[:, :8].T, r["rev"])
+    np.testing.assert_array_equal(rev_mask.cpu().numpy().view(np.uint32), r["rev_mask"])
+    assert sorted(rev_perm.cpu().tolist()) == list(range(len(s)))
+    # a swapped (transposed-conv) map rebuilt from its CSR form
+    sw = IntSearchResult(km.out_maps, km.in_maps, km.offsets)
+    attach_tables_from_csr(sw, len(coarse), len(s))
+    np.testing.assert_array_equal(sw._nbr.cpu().numpy()[:, :8].T, r["rev"])
+    np.testing.assert_array_equal(sw._mask.cpu().numpy().view(np.uint32), r["rev_mask"])
+
+
+def test_hash_table_contract_gpu():
+    from warpconvnet_amd.geometry.coords.search.packed_hashmap import PackedHashTable
+
+    dev = _dev()
+    c = scene_u(20000, 3)
+    t = PackedHashTable.from_coords(torch.from_numpy(c).to(dev))
+    assert t.capacity == 65536 and t.num_entries == len(c)
+    np.testing.assert_array_equal(t.search(torch.from_numpy(c).to(dev)).cpu().numpy(), np.arange(len(c)))
+    miss = c.copy(); miss[:, 1] += 100000
+    assert (t.search(torch.from_numpy(miss).to(dev)) == -1).all()
+    # duplicates: the smallest row index wins -> identical to the oracle's first-occurrence rule
+    dup = np.concatenate([c[:1000], c[:1000][::-1], c[1000:2000]], 0)
+    td = PackedHashTable.from_coords(torch.from_numpy(dup).to(dev))
+    np.testing.assert_array_equal(td.search(torch.from_numpy(dup).to(dev)).cpu().numpy(), okmap.HashTable(dup).search(dup))
+    uniq = td.unique_index.cpu().numpy()
+    np.testing.assert_array_equal(uniq, np.concatenate([np.arange(1000), np.arange(2000, 3000)]))
+    assert (t.keys_tensor != 0).sum().item() == len(c) and (t.values_tensor >= 0).sum().item() == len(c)
+    edge = np.array([[511, 131071, -131072, 0], [0, -131072, 131071, 5]], np.int32)
+    te = PackedHashTable.from_coords(torch.from_numpy(edge).to(dev))
+    np.testing.assert_array_equal(te.search(torch.from_numpy(edge).to(dev)).cpu().numpy(), [0, 1])
+    for bad in ([[512, 0, 0, 0]], [[-1, 0, 0, 0]], [[0, 131072, 0, 0]], [[0, 0, -131073, 0]]):
+        with pytest.raises(ValueError):
+            PackedHashTable.from_coords(torch.tensor(bad, dtype=torch.int32, device=dev))
+    full = PackedHashTable(32, device=dev)
+    with pytest.raises(AssertionError):
+        full.insert(torch.from_numpy(c[:40]).to(dev))  # N <= capacity/2 rule
+    with pytest.raises(RuntimeError):
+        PackedHashTable.from_coords(torch.from_numpy(c[:5]).cpu())  # no CPU path
+
+
+def test_empty_and_tiny_inputs():
+    dev = _dev()
+    e = np.zeros((0, 4), np.int32)
+    km = _gen(e, e, (3, 3, 3), same=True)
+    assert km.offsets.tolist() == [0] * 28 and km.in_maps.numel() == 0
+    one = np.array([[0, 5, 5, 5]], np.int32)
+    km1 = _gen(one, one, (3, 3, 3), same=True)
+    assert km1.offsets.tolist() == [0] * 14 + [1] * 14 and km1.in_maps.tolist() == [0]
+
+
+def test_large_scene_invariants():
+    """Full-size scene (1M voxels): invariants instead of the serial oracle (which takes ~10 s on the same
+    data, so the oracle comparison runs on a 200k subsample of the table)."""
+    s = scene_u(1_000_000, 0)
+    km = _gen(s, s, (3, 3, 3), same=True)
+    N = len(s)
+    offs = km.offsets.numpy()
+    assert offs[-1] == km.in_maps.numel() == km.out_maps.numel()
+    t = torch.from_numpy(s).to(_dev())
+    ko = torch.tensor([[0, i - 1, j - 1, l - 1] for i in range(3) for j in range(3) for l in range(3)], dtype=torch.int32, device=_dev())
+    for k in (0, 5, 13, 26):
+        i, o = km[k]
+        assert (t[i.long()] == t[o.long()] + ko[k]).all()
+        assert (o[1:] > o[:-1]).all()
+    pt = km._pair_table
+    assert (pt[13] == torch.arange(N, device=_dev(), dtype=torch.int32)).all()
+    # symmetry: found[k][i] = j  <=>  found[26-k][j] = i
+    for k in (0, 7, 12):
+        rows = torch.nonzero(pt[k] >= 0).squeeze(1)
+        assert (pt[26 - k][pt[k][rows].long()] == rows.int()).all()
+    assert int((pt >= 0).sum()) == offs[-1]
+    # oracle on a subsample of rows
+    r = okmap.kernel_map(s, s[:200000], (3, 3, 3))
+    np.testing.assert_array_equal(pt[:, :200000].cpu().numpy(), r["found"])
+
+
+def test_surface_scene_map():
+    s = scene_surface(160, 2)
+    km = _gen(s, s, (3, 3, 3), same=True)
+    _check_against_oracle(km, s, s, (3, 3, 3))

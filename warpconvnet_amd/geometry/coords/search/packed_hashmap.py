@@ -115,7 +115,8 @@ class PackedHashTable:
             )
 
     def insert(self, coords: Tensor) -> None:
-        assert coords.is_cuda, "coords must be on a GPU"
+        if not coords.is_cuda:
+            raise RuntimeError("PackedHashTable lives on the GPU (HIP path, no CPU fallback); got CPU coordinates")
         assert coords.ndim == 2 and coords.shape[1] == 4
         coords = coords.contiguous().to(dtype=torch.int32)
         n = coords.shape[0]
