@@ -83,26 +83,29 @@ int wcn_hash_search(const void* slots, int64_t capacity, const int32_t* queries,
  */
 int32_t wcn_kmap_row_pitch(int32_t num_offsets);
 int32_t wcn_kmap_mask_words(int32_t num_offsets);
-/* number of count blocks the probe kernel uses for m query rows (rows of block_counts) */
+/* number of 64-row count blocks for m query rows; the counts buffer holds K * (num_blocks + 1) int32 */
 int64_t wcn_kmap_num_blocks(int64_t m);
 
 /* reference: _C.cuhash.packed_kernel_map_size + packed_kernel_map_offset (cuhash_kernel_map.cu:68-134)
- * fused with build_pair_mask (mask_data_kernels.cu:23-44) and the per-offset count of
- * postprocess_count (cuhash_kernel_map.cu:508-544).
- *   query   int32 [m,4]      mask         uint32 [m, mask_words]  (bit k <=> nbr[m][k] >= 0)
- *   nbr     int32 [m,kp]     block_counts int32  [num_blocks, K]  (valid pairs per block of rows)
+ * fused with build_pair_mask (mask_data_kernels.cu:23-44).
+ *   query   int32 [m,4]      mask   uint32 [m, mask_words]  (bit k <=> nbr[m][k] >= 0)
+ *   nbr     int32 [m,kp]
  */
 int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, int64_t m,
                    const int32_t ksize[3], const int32_t stride[3], const int32_t dilation[3],
-                   int32_t* nbr, uint32_t* mask, int32_t* block_counts, wcn_stream_t stream);
-/* exclusive scan of block_counts over blocks (in place) and over offsets -> offsets int32 [K+1].
+                   int32_t* nbr, uint32_t* mask, wcn_stream_t stream);
+/* counts[k][b] = pairs of offset k in the 64-row block b (k-major, from the masks).
+ * reference: _C.cuhash.postprocess_count (cuhash_kernel_map.cu:508-544). */
+int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream);
+/* exclusive scan of counts over blocks (in place, one workgroup per offset) and over offsets ->
+ * offsets int32 [K+1].  counts must hold K * (num_blocks + 1) int32 (the tail receives the bucket totals).
  * reference: host torch.cumsum in torch_discrete.py:268-272. */
-int wcn_kmap_scan(int32_t* block_counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
+int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
                   wcn_stream_t stream);
 /* deterministic compaction (pairs of one offset ordered by output row).
  * reference: _C.cuhash.postprocess_scatter (cuhash_kernel_map.cu:546-599, order there is racy).
  * pair_capacity = length of in_maps/out_maps; sets WCN_FLAG_PAIR_OVERFLOW in *status if too small. */
-int wcn_kmap_scatter(const int32_t* nbr, int64_t m, int32_t num_offsets, const int32_t* block_counts,
+int wcn_kmap_scatter(const int32_t* nbr, int64_t m, int32_t num_offsets, const int32_t* counts,
                      const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
                      int32_t* status, wcn_stream_t stream);
 /* nbr [m,kp] -> pair_table [K,m]   (the reference layout, cuhash_kernel_map.cu:133) */

@@ -35,8 +35,9 @@ SIGNATURES = {
     "wcn_kmap_num_blocks": (c_int64, [c_int64]),
     "wcn_kmap_probe": (
         c_int,
-        [c_void_p, c_int64, c_void_p, c_int64, _3I, _3I, _3I, c_void_p, c_void_p, c_void_p, c_void_p],
+        [c_void_p, c_int64, c_void_p, c_int64, _3I, _3I, _3I, c_void_p, c_void_p, c_void_p],
     ),
+    "wcn_kmap_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scatter": (
         c_int,

@@ -17,7 +17,8 @@
 
 namespace wcn {
 
-constexpr int kBlockRows = 256;  // rows per count block (probe + scatter must agree)
+constexpr int kBlockRows = 256;  // rows per probe workgroup
+constexpr int kCountRows = 64;   // rows per count block (= one wavefront of the count / scatter kernels)
 constexpr int kThreads = 256;
 
 // ------------------------------------------------------------------------------------------------
@@ -74,13 +75,8 @@ template <int LPR>  // lanes per row: 8, 16, 32 or 64
 __global__ __launch_bounds__(kThreads) void kmap_probe_kernel(const Slot* __restrict__ slots, uint32_t capacity_mask,
                                                               const int4* __restrict__ query, int64_t m, ProbeGeom g,
                                                               int K, int kp, int mw, int32_t* __restrict__ nbr,
-                                                              uint32_t* __restrict__ mask,
-                                                              int32_t* __restrict__ block_counts) {
-  extern __shared__ int s_counts[];  // [K]
+                                                              uint32_t* __restrict__ mask) {
   const int tid = threadIdx.x;
-  for (int k = tid; k < K; k += kThreads) s_counts[k] = 0;
-  __syncthreads();
-
   constexpr int kRowsPerIter = 64 / LPR;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -98,7 +94,6 @@ __global__ __launch_bounds__(kThreads) void kmap_probe_kernel(const Slot* __rest
     const int j = (k / g.kz) % g.ky;
     const int i = k / (g.kz * g.ky);
     const int ox = (i - g.cx) * g.dx, oy = (j - g.cy) * g.dy, oz = (l - g.cz) * g.dz;
-    int cnt = 0;
 #pragma unroll 4
     for (int it = 0; it < 64 / kRowsPerIter; ++it) {
       const int64_t row = wave_row0 + it * kRowsPerIter + rsel;
@@ -110,7 +105,6 @@ __global__ __launch_bounds__(kThreads) void kmap_probe_kernel(const Slot* __rest
       }
       if (row < m && k_store) nbr[row * kp + k] = found;
       const unsigned long long ball = __ballot(found >= 0);
-      cnt += found >= 0;
       if (row < m && sub == 0) {
         const unsigned long long bits = (LPR == 64) ? ball : ((ball >> (rsel * LPR)) & ((1ull << (LPR & 63)) - 1ull));
         const int w0 = (kc * LPR) >> 5;
@@ -118,87 +112,123 @@ __global__ __launch_bounds__(kThreads) void kmap_probe_kernel(const Slot* __rest
         if (LPR == 64 && w0 + 1 < mw) mask[row * mw + w0 + 1] = (uint32_t)(bits >> 32);
       }
     }
-    if (k_real && cnt) atomicAdd(&s_counts[k], cnt);
   }
-  __syncthreads();
-  for (int k = tid; k < K; k += kThreads) block_counts[(int64_t)blockIdx.x * K + k] = s_counts[k];
 }
 
 // ------------------------------------------------------------------------------------------------
-// scan: block_counts (in place, exclusive over blocks) and offsets[K+1]
+// count: counts[k][wb] = number of rows of 64-row block wb that have offset k   (k-major for the scan)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ bc, int64_t num_blocks, int K,
-                                                         int32_t* __restrict__ offsets) {
-  extern __shared__ int s_tot[];  // [K]
+__global__ __launch_bounds__(kThreads) void kmap_count_kernel(const uint32_t* __restrict__ mask, int64_t m, int K,
+                                                              int mw, int64_t nwb, int32_t* __restrict__ counts) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int nwaves = blockDim.x >> 6;
-  for (int k = wave; k < K; k += nwaves) {
-    int running = 0;
-    for (int64_t b0 = 0; b0 < num_blocks; b0 += 64) {
-      const int64_t b = b0 + lane;
-      const int v = b < num_blocks ? bc[b * K + k] : 0;
-      int incl = v;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-      }
-      if (b < num_blocks) bc[b * K + k] = running + incl - v;
-      running += __shfl(incl, 63);
+  const int64_t wb = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (wb >= nwb) return;
+  const int64_t row = wb * kCountRows + lane;
+  for (int w = 0; w < mw; ++w) {
+    const uint32_t bits = row < m ? mask[row * mw + w] : 0u;
+    const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;
+    int mine = 0;
+    for (int b = 0; b < kend; ++b) {
+      const int c = __popcll(__ballot((bits >> b) & 1u));
+      if (lane == b) mine = c;
     }
-    if (lane == 0) s_tot[k] = running;
+    if (lane < kend) counts[(int64_t)(w * 32 + lane) * nwb + wb] = mine;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan: one workgroup per offset k scans counts[k][0..nwb) in place (exclusive); totals[k] = bucket size.
+// A second single-wave kernel turns the totals into offsets[K+1].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ counts, int64_t nwb, int K,
+                                                         int32_t* __restrict__ totals) {
+  __shared__ int s_part[16];
+  int32_t* c = counts + (int64_t)blockIdx.x * nwb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t chunk = (nwb + 1023) / 1024;
+  const int64_t b0 = (int64_t)tid * chunk;
+  const int64_t b1 = (b0 + chunk < nwb) ? (b0 + chunk) : nwb;
+  int sum = 0;
+  for (int64_t b = b0; b < b1; ++b) sum += c[b];
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) s_part[wave] = incl;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  int wave_base = 0;
+  for (int w = 0; w < wave; ++w) wave_base += s_part[w];
+  int run = wave_base + incl - sum;
+  for (int64_t b = b0; b < b1; ++b) {
+    const int v = c[b];
+    c[b] = run;
+    run += v;
+  }
+  if (tid == 1023) totals[blockIdx.x] = wave_base + incl;
+}
+
+__global__ void kmap_offsets_kernel(const int32_t* __restrict__ totals, int K, int32_t* __restrict__ offsets) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
     int acc = 0;
     offsets[0] = 0;
     for (int k = 0; k < K; ++k) {
-      acc += s_tot[k];
+      acc += totals[k];
       offsets[k + 1] = acc;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// scatter: deterministic compaction, one thread per output row, wave ballot ranking
+// scatter: deterministic compaction.  One wavefront per 64-row block, one LANE per (row, offset) like the
+// probe kernel, so the neighbour rows are read as contiguous 128-B lines; the rank of a pair inside its
+// bucket is  offsets[k] + scanned count of the block + running count of the wave + ballot popcount.
 // ------------------------------------------------------------------------------------------------
+template <int LPR>
 __global__ __launch_bounds__(kThreads) void kmap_scatter_kernel(const int32_t* __restrict__ nbr, int64_t m, int K,
-                                                                int kp, const int32_t* __restrict__ bc,
+                                                                int kp, int64_t nwb,
+                                                                const int32_t* __restrict__ counts,
                                                                 const int32_t* __restrict__ offsets,
                                                                 int32_t* __restrict__ in_maps,
                                                                 int32_t* __restrict__ out_maps, int64_t pair_capacity,
                                                                 int32_t* __restrict__ status) {
-  extern __shared__ int s_wcnt[];  // [4][K] per-wave valid counts
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t row = (int64_t)blockIdx.x * kBlockRows + tid;
-  const bool in_range = row < m;
-  const int32_t* my = nbr + row * kp;
-  // phase 1: per-wave counts for every offset
-  for (int k = 0; k < K; ++k) {
-    const bool v = in_range && my[k] >= 0;
-    const unsigned long long ball = __ballot(v);
-    if (lane == 0) s_wcnt[wave * K + k] = __popcll(ball);
+  constexpr int kRowsPerIter = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int64_t wb = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (wb >= nwb) return;
+  const int sub = lane % LPR, rsel = lane / LPR;
+  // lanes that hold the same offset: bit (r*LPR + sub) for r = 0..kRowsPerIter-1
+  unsigned long long same_k = 0ull, lower_k = 0ull;
+#pragma unroll
+  for (int r = 0; r < kRowsPerIter; ++r) {
+    const unsigned long long bit = 1ull << (r * LPR + sub);
+    same_k |= bit;
+    if (r < rsel) lower_k |= bit;
   }
-  __syncthreads();
-  // phase 2: write pairs
-  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int num_chunks = (K + LPR - 1) / LPR;
   bool overflow = false;
-  for (int k = 0; k < K; ++k) {
-    const int in_row = in_range ? my[k] : -1;
-    const bool v = in_row >= 0;
-    const unsigned long long ball = __ballot(v);
-    if (ball == 0ull) continue;
-    if (v) {
-      int base = offsets[k] + bc[(int64_t)blockIdx.x * K + k];
-      for (int w = 0; w < wave; ++w) base += s_wcnt[w * K + k];
-      const int64_t pos = (int64_t)base + __popcll(ball & lt);
-      if (pos < pair_capacity) {
-        in_maps[pos] = in_row;
-        out_maps[pos] = (int32_t)row;
-      } else {
-        overflow = true;
+  for (int kc = 0; kc < num_chunks; ++kc) {
+    const int k = kc * LPR + sub;
+    const bool k_real = k < K;
+    int64_t run = 0;
+    if (k_real) run = (int64_t)offsets[k] + counts[(int64_t)k * nwb + wb];
+#pragma unroll 4
+    for (int it = 0; it < 64 / kRowsPerIter; ++it) {
+      const int64_t row = wb * kCountRows + it * kRowsPerIter + rsel;
+      int v = -1;
+      if (row < m && k_real) v = nbr[row * kp + k];
+      const unsigned long long ball = __ballot(v >= 0);
+      if (v >= 0) {
+        const int64_t pos = run + __popcll(ball & lower_k);
+        if (pos < pair_capacity) {
+          in_maps[pos] = v;
+          out_maps[pos] = (int32_t)row;
+        } else {
+          overflow = true;
+        }
       }
+      run += __popcll(ball & same_k);
     }
   }
   if (overflow) atomicOr(status, (int)WCN_FLAG_PAIR_OVERFLOW);
@@ -316,69 +346,89 @@ int wcn_hash_search(const void* slots, int64_t capacity, const int32_t* queries,
 
 int32_t wcn_kmap_row_pitch(int32_t num_offsets) { return (num_offsets + 7) & ~7; }
 int32_t wcn_kmap_mask_words(int32_t num_offsets) { return (num_offsets + 31) / 32; }
-int64_t wcn_kmap_num_blocks(int64_t m) { return ceil_div(m, kBlockRows); }
+int64_t wcn_kmap_num_blocks(int64_t m) { return ceil_div(m, kCountRows); }
 
 int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, int64_t m, const int32_t ksize[3],
                    const int32_t stride[3], const int32_t dilation[3], int32_t* nbr, uint32_t* mask,
-                   int32_t* block_counts, wcn_stream_t stream) {
+                   wcn_stream_t stream) {
   if (!slots || !is_pow2(capacity) || m < 0 || !ksize || !stride || !dilation) return WCN_ERROR_INVALID_PARAMETERS;
   for (int d = 0; d < 3; ++d)
     if (ksize[d] < 1 || stride[d] < 1 || dilation[d] < 1) return WCN_ERROR_INVALID_PARAMETERS;
   const int64_t K64 = (int64_t)ksize[0] * ksize[1] * ksize[2];
   if (K64 > 4096) return WCN_ERROR_PROBLEM_NOT_SUPPORTED;
   if (m == 0) return WCN_SUCCESS;
-  if (!query || !nbr || !mask || !block_counts) return WCN_ERROR_INVALID_PARAMETERS;
+  if (!query || !nbr || !mask) return WCN_ERROR_INVALID_PARAMETERS;
   const int K = (int)K64, kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
   ProbeGeom g;
   g.kx = ksize[0]; g.ky = ksize[1]; g.kz = ksize[2];
   g.cx = (g.kx & 1) ? g.kx / 2 : 0; g.cy = (g.ky & 1) ? g.ky / 2 : 0; g.cz = (g.kz & 1) ? g.kz / 2 : 0;
   g.sx = stride[0]; g.sy = stride[1]; g.sz = stride[2];
   g.dx = dilation[0]; g.dy = dilation[1]; g.dz = dilation[2];
-  const dim3 grid((unsigned)wcn_kmap_num_blocks(m)), block(kThreads);
-  const size_t shm = (size_t)K * sizeof(int);
+  const dim3 grid((unsigned)ceil_div(m, kBlockRows)), block(kThreads);
+  const size_t shm = 0;
   const uint32_t cmask = (uint32_t)(capacity - 1);
   hipStream_t s = (hipStream_t)stream;
   switch (lanes_per_row(kp)) {
     case 8:
       hipLaunchKernelGGL(kmap_probe_kernel<8>, grid, block, shm, s, (const Slot*)slots, cmask, (const int4*)query, m, g, K,
-                         kp, mw, nbr, mask, block_counts);
+                         kp, mw, nbr, mask);
       break;
     case 16:
       hipLaunchKernelGGL(kmap_probe_kernel<16>, grid, block, shm, s, (const Slot*)slots, cmask, (const int4*)query, m, g,
-                         K, kp, mw, nbr, mask, block_counts);
+                         K, kp, mw, nbr, mask);
       break;
     case 32:
       hipLaunchKernelGGL(kmap_probe_kernel<32>, grid, block, shm, s, (const Slot*)slots, cmask, (const int4*)query, m, g,
-                         K, kp, mw, nbr, mask, block_counts);
+                         K, kp, mw, nbr, mask);
       break;
     default:
       hipLaunchKernelGGL(kmap_probe_kernel<64>, grid, block, shm, s, (const Slot*)slots, cmask, (const int4*)query, m, g,
-                         K, kp, mw, nbr, mask, block_counts);
+                         K, kp, mw, nbr, mask);
       break;
   }
   return launch_status();
 }
 
-int wcn_kmap_scan(int32_t* block_counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
-                  wcn_stream_t stream) {
-  if (num_blocks < 0 || num_offsets < 1 || num_offsets > 4096 || !offsets) return WCN_ERROR_INVALID_PARAMETERS;
-  if (num_blocks > 0 && !block_counts) return WCN_ERROR_INVALID_PARAMETERS;
-  hipLaunchKernelGGL(kmap_scan_kernel, dim3(1), dim3(1024), (size_t)num_offsets * sizeof(int), (hipStream_t)stream,
-                     block_counts, num_blocks, (int)num_offsets, offsets);
+int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream) {
+  if (m < 0 || num_offsets < 1 || num_offsets > 4096) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  if (!mask || !counts) return WCN_ERROR_INVALID_PARAMETERS;
+  const int64_t nwb = wcn_kmap_num_blocks(m);
+  hipLaunchKernelGGL(kmap_count_kernel, dim3((unsigned)ceil_div(nwb, kThreads / 64)), dim3(kThreads), 0,
+                     (hipStream_t)stream, mask, m, (int)num_offsets, wcn_kmap_mask_words(num_offsets), nwb, counts);
   return launch_status();
 }
 
-int wcn_kmap_scatter(const int32_t* nbr, int64_t m, int32_t num_offsets, const int32_t* block_counts,
-                     const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
-                     int32_t* status, wcn_stream_t stream) {
+int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, wcn_stream_t stream) {
+  if (num_blocks < 0 || num_offsets < 1 || num_offsets > 4096 || !offsets || !counts) return WCN_ERROR_INVALID_PARAMETERS;
+  // totals live in the last K ints of the counts buffer (the caller allocates K * (num_blocks + 1) ints)
+  int32_t* totals = counts + (int64_t)num_offsets * num_blocks;
+  hipLaunchKernelGGL(kmap_scan_kernel, dim3((unsigned)num_offsets), dim3(1024), 0, (hipStream_t)stream, counts,
+                     num_blocks, (int)num_offsets, totals);
+  hipLaunchKernelGGL(kmap_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int32_t*)totals,
+                     (int)num_offsets, offsets);
+  return launch_status();
+}
+
+int wcn_kmap_scatter(const int32_t* nbr, int64_t m, int32_t num_offsets, const int32_t* counts, const int32_t* offsets,
+                     int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status, wcn_stream_t stream) {
   if (m < 0 || num_offsets < 1 || num_offsets > 4096 || pair_capacity < 0 || !status) return WCN_ERROR_INVALID_PARAMETERS;
   if (m == 0) return WCN_SUCCESS;
-  if (!nbr || !block_counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps)))
-    return WCN_ERROR_INVALID_PARAMETERS;
+  if (!nbr || !counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps))) return WCN_ERROR_INVALID_PARAMETERS;
   const int K = num_offsets, kp = wcn_kmap_row_pitch(K);
-  hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)wcn_kmap_num_blocks(m)), dim3(kThreads),
-                     (size_t)4 * K * sizeof(int), (hipStream_t)stream, nbr, m, K, kp, block_counts, offsets, in_maps,
-                     out_maps, pair_capacity, status);
+  const int64_t nwb = wcn_kmap_num_blocks(m);
+  const dim3 grid((unsigned)ceil_div(nwb, kThreads / 64)), block(kThreads);
+  hipStream_t s = (hipStream_t)stream;
+#define WCN_SCATTER(L)                                                                                              \
+  hipLaunchKernelGGL(kmap_scatter_kernel<L>, grid, block, 0, s, nbr, m, K, kp, nwb, counts, offsets, in_maps, out_maps, \
+                     pair_capacity, status)
+  switch (lanes_per_row(kp)) {
+    case 8: WCN_SCATTER(8); break;
+    case 16: WCN_SCATTER(16); break;
+    case 32: WCN_SCATTER(32); break;
+    default: WCN_SCATTER(64); break;
+  }
+#undef WCN_SCATTER
   return launch_status();
 }
 

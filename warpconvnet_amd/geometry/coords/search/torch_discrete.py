@@ -179,13 +179,13 @@ def generate_kernel_map(
     table._launch_insert(in_coords, meta[K + 1 :])
     nbr = torch.empty((M, kp), dtype=torch.int32, device=dev)
     mask = torch.empty((M, mw), dtype=torch.int32, device=dev)
-    block_counts = torch.empty((max(nblk, 1), K), dtype=torch.int32, device=dev)
+    block_counts = torch.empty(K * (nblk + 1), dtype=torch.int32, device=dev)  # k-major counts + K totals
     _lib.check(
         L.wcn_kmap_probe(_lib.ptr(table.slots_tensor), table.capacity, _lib.ptr(out_coords), M, _lib.i3(ksize),
-                         _lib.i3(stride), _lib.i3(dilation), _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(block_counts),
-                         stream),
+                         _lib.i3(stride), _lib.i3(dilation), _lib.ptr(nbr), _lib.ptr(mask), stream),
         "wcn_kmap_probe",
     )
+    _lib.check(L.wcn_kmap_count(_lib.ptr(mask), M, K, _lib.ptr(block_counts), stream), "wcn_kmap_count")
     _lib.check(L.wcn_kmap_scan(_lib.ptr(block_counts), nblk, K, _lib.ptr(meta), stream), "wcn_kmap_scan")
     meta_host = meta.cpu()  # the single host sync of the build
     PackedHashTable.raise_for_flags(int(meta_host[K + 1]), N, table.capacity)
