@@ -94,6 +94,18 @@ int64_t wcn_kmap_num_blocks(int64_t m);
 int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, int64_t m,
                    const int32_t ksize[3], const int32_t stride[3], const int32_t dilation[3],
                    int32_t* nbr, uint32_t* mask, wcn_stream_t stream);
+/* LDS-binned neighbour search for SUBMANIFOLD maps (query coords == input coords, stride 1): replaces
+ * wcn_hash_insert + wcn_kmap_probe.  Voxels are binned into 16^3 blocks through a block-level hash table
+ * (`slots`, capacity >= 2n, power of two; prepared by the call), then every block and its halo are staged in an
+ * LDS grid and all K probes are answered from LDS.  Same outputs as the hash path (bit-exact), incl. the
+ * range flags in *status.  Returns WCN_ERROR_PROBLEM_NOT_SUPPORTED when the kernel halo exceeds 4 cells
+ * (wcn_kmap_binned_supported == 0): the caller then uses the hash path.
+ * reference being replaced: cuhash_hash_table.cu:179-220 + cuhash_kernel_map.cu:93-134. */
+size_t wcn_kmap_binned_workspace(int64_t n);
+int wcn_kmap_binned_supported(const int32_t ksize[3], const int32_t dilation[3]);
+int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[3], const int32_t dilation[3],
+                          void* slots, int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* nbr,
+                          uint32_t* mask, int32_t* status, wcn_stream_t stream);
 /* counts[k][b] = pairs of offset k in the 64-row block b (k-major, from the masks).
  * reference: _C.cuhash.postprocess_count (cuhash_kernel_map.cu:508-544). */
 int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream);

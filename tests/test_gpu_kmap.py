@@ -46,9 +46,16 @@ def _check_against_oracle(km, in_np, out_np, ksize, stride=(1, 1, 1), dilation=(
     return r
 
 
-@pytest.mark.parametrize("n,ksize", [(5000, (3, 3, 3)), (3000, (5, 5, 5)), (4000, (3, 1, 2)), (2000, (2, 2, 2)), (777, (3, 3, 1))])
-def test_submanifold_map_bit_exact(n, ksize):
+@pytest.fixture(params=["binned", "hash"])
+def kmap_method(request, monkeypatch):
+    monkeypatch.setenv("WARPCONVNET_AMD_KMAP_METHOD", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("n,ksize", [(5000, (3, 3, 3)), (3000, (5, 5, 5)), (4000, (3, 1, 2)), (2000, (2, 2, 2)), (777, (3, 3, 1)), (900, (7, 7, 7))])
+def test_submanifold_map_bit_exact(n, ksize, kmap_method):
     s = np.concatenate([scene_u(n, 1, 0), scene_u(n // 2, 2, 1)], 0)
+    s[:, 1:] -= 9  # blocks straddle the origin
     km = _gen(s, s, ksize, same=True)
     K = int(np.prod(ksize))
     r = _check_against_oracle(km, s, s, ksize)
@@ -75,7 +82,35 @@ def test_strided_map_bit_exact(ksize, stride):
     assert km.identity_map_index is None and not km._symmetric
 
 
-def test_dilation_and_2d():
+def test_binned_edge_cases(kmap_method):
+    """Duplicates (smallest row wins), coordinates at the limits of the packed range (18-bit wrap of the probe
+    key, reference hash_functions.cuh:40-44), far-apart clusters, several batch indices."""
+    rng = np.random.default_rng(5)
+    base = scene_u(1500, 4)[:, 1:]
+    far = base + np.array([131071 - 30, -131072, 60000], np.int32)  # touches +x and -y limits
+    far = far[(far[:, 0] <= 131071)]
+    wrap_partner = np.array([[-131072, -131072 + 5, 60000 + 3], [131071, 131071, 0], [-131072, 131071, 0]], np.int32)
+    pts = np.concatenate([base, far, wrap_partner, base[:200]], 0)  # last 200 rows are duplicates
+    b = rng.integers(0, 3, size=len(pts)).astype(np.int32)
+    b[-200:] = b[:200]
+    b[len(base) + len(far) : len(base) + len(far) + 3] = 1  # the wrap partners share a batch index
+    order = np.argsort(b, kind="stable")
+    s = np.concatenate([b[order, None], pts[order]], 1).astype(np.int32)
+    km = _gen(s, s, (3, 3, 3), same=True)
+    r = okmap.kernel_map(s, s, (3, 3, 3))
+    np.testing.assert_array_equal(km._pair_table.cpu().numpy(), r["found"])
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+    np.testing.assert_array_equal(km._mask.cpu().numpy().view(np.uint32), r["mask"])
+    # the x = 131071 voxel sees the x = -131072 voxel through the 18-bit wrap, exactly like the reference's packed key
+    i_hi = int(np.nonzero((s[:, 1] == 131071) & (s[:, 2] == 131071))[0][0])
+    i_lo = int(np.nonzero((s[:, 1] == -131072) & (s[:, 2] == 131071))[0][0])
+    assert r["found"][22, i_hi] == i_lo  # k = 22 is offset (+1, 0, 0)
+    bad = s.copy(); bad[3, 2] = 131072
+    with pytest.raises(ValueError):
+        _gen(bad, bad, (3, 3, 3), same=True)
+
+
+def test_dilation_and_2d(kmap_method):
     s = scene_u(3000, 9)
     km = _gen(s, s, (3, 3, 3), dilation=(2, 2, 2), same=True)
     _check_against_oracle(km, s, s, (3, 3, 3), dilation=(2, 2, 2))
@@ -144,7 +179,7 @@ def test_empty_and_tiny_inputs():
     assert km1.offsets.tolist() == [0] * 14 + [1] * 14 and km1.in_maps.tolist() == [0]
 
 
-def test_large_scene_invariants():
+def test_large_scene_invariants(kmap_method):
     """Full-size scene (1M voxels): invariants instead of the serial oracle (which takes ~10 s on the same
     data, so the oracle comparison runs on a 200k subsample of the table)."""
     s = scene_u(1_000_000, 0)
@@ -170,7 +205,7 @@ def test_large_scene_invariants():
     np.testing.assert_array_equal(pt[:, :200000].cpu().numpy(), r["found"])
 
 
-def test_surface_scene_map():
+def test_surface_scene_map(kmap_method):
     s = scene_surface(160, 2)
     km = _gen(s, s, (3, 3, 3), same=True)
     _check_against_oracle(km, s, s, (3, 3, 3))

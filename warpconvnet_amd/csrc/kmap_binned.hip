@@ -1,0 +1,343 @@
+// kmap_binned.hip - LDS-binned neighbour search for submanifold kernel maps (output coords == input coords).
+//
+// A global hash probe per (voxel, offset) is 27 random 16-B reads per voxel (27 M for a 1 M-voxel scene): HBM /
+// fabric latency bound.  Here voxels are first BINNED into 16x16x16 blocks (a small block-level hash table
+// assigns dense block ids; counting sort by block), then one workgroup per block stages the block and its
+// one-cell... H-cell halo (taken from the 26 neighbouring bins) into a dense LDS grid and answers all
+// K probes of its voxels from LDS.  Global traffic becomes streaming bin reads + full-line row writes.
+//
+//   pass 1  bin_insert   voxel -> block slot (CAS on block key), position inside the bin (atomic counter)
+//   pass 2  bin_assign   dense block id -> slot, bin size
+//   pass 3  bin_scan     exclusive scan of bin sizes
+//   pass 4  bin_scatter  voxels -> binned array {x, y, z, row}
+//   pass 5  bin_neighbors  per block: LDS grid of (16+2H)^3 row ids (atomicMin => duplicates keep the smallest
+//                          row, same rule as the hash path), then one LANE per (voxel, offset): the neighbour row
+//                          is written as one contiguous line and the mask is a wave ballot.
+//
+// Semantics equal wcn_hash_insert + wcn_kmap_probe with stride 1 (incl. 18-bit coordinate wrap of the packed
+// key: neighbour blocks are looked up with wrapped block coordinates, positions are block-relative).
+// Reference behaviour replaced: warpconvnet/csrc/cuhash_hash_table.cu:179-220, cuhash_kernel_map.cu:93-134.
+#include "wcn_common.h"
+
+namespace wcn {
+
+constexpr int kBlkShift = 4;
+constexpr int kBlk = 1 << kBlkShift;  // 16 cells per axis
+constexpr int kMaxHalo = 4;
+constexpr int kBinThreads = 256;
+constexpr int kBlkCoordBits = kCoordBits - kBlkShift;  // 14-bit signed block coordinates
+
+struct BinGeom {
+  int kx, ky, kz, cx, cy, cz, dx, dy, dz;
+  int hx, hy, hz;  // halo per axis (max |offset|)
+  int gx, gy, gz;  // LDS grid extent per axis
+};
+
+__device__ __forceinline__ int wrap_blk(int v) {  // wrap to the signed range of the block coordinate field
+  const int bits = kBlkCoordBits;
+  v &= (1 << bits) - 1;
+  return (v ^ (1 << (bits - 1))) - (1 << (bits - 1));
+}
+
+__device__ __forceinline__ uint64_t block_key(int b, int bx, int by, int bz) { return pack_key(b, bx, by, bz); }
+
+// slot of an existing block key, or -1
+__device__ __forceinline__ int block_find(const Slot* __restrict__ slots, uint32_t cmask, uint64_t key) {
+  uint32_t s = hash_slot(key, cmask);
+  for (uint32_t a = 0; a <= cmask; ++a) {
+    const uint64_t k = slots[s].key;
+    if (k == 0ull) return -1;
+    if (k == key) return (int)s;
+    s = (s + 1) & cmask;
+  }
+  return -1;
+}
+
+__global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, const int4* __restrict__ coords, int64_t n,
+                                  int32_t* __restrict__ vox_slot, int32_t* __restrict__ vox_pos,
+                                  int32_t* __restrict__ blk_slot, int32_t* __restrict__ nblk,
+                                  int32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  if (!coord_in_range(c.x, c.y, c.z, c.w)) {
+    atomicOr(status, (int)WCN_FLAG_COORD_RANGE);
+    vox_slot[i] = -1;
+    return;
+  }
+  const uint64_t key = block_key(c.x, c.y >> kBlkShift, c.z >> kBlkShift, c.w >> kBlkShift);
+  uint32_t s = hash_slot(key, cmask);
+  int found = -1;
+  for (uint32_t a = 0; a <= cmask; ++a) {
+    unsigned long long* kp = reinterpret_cast<unsigned long long*>(&slots[s].key);
+    unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0ull) {
+      cur = atomicCAS(kp, 0ull, (unsigned long long)key);
+      if (cur == 0ull) {  // this thread created the block: give it a dense id
+        const int id = atomicAdd(nblk, 1);
+        blk_slot[id] = (int)s;
+        found = (int)s;
+        break;
+      }
+    }
+    if (cur == key) { found = (int)s; break; }
+    s = (s + 1) & cmask;
+  }
+  if (found < 0) {
+    atomicOr(status, (int)WCN_FLAG_TABLE_FULL);
+    vox_slot[i] = -1;
+    return;
+  }
+  vox_slot[i] = found;
+  vox_pos[i] = atomicAdd(&slots[found].pad, 1);  // pad doubles as the bin counter (zeroed by wcn_hash_prepare)
+}
+
+__global__ void bin_assign_kernel(Slot* __restrict__ slots, const int32_t* __restrict__ blk_slot,
+                                  const int32_t* __restrict__ nblk, int64_t max_blocks, int32_t* __restrict__ blk_cnt) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= max_blocks || id >= *nblk) return;
+  const int s = blk_slot[id];
+  blk_cnt[id] = slots[s].pad;
+  slots[s].value = (int32_t)id;
+}
+
+// single workgroup: exclusive scan of blk_cnt[0..nblk) -> blk_off[0..nblk]
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const int32_t* __restrict__ blk_cnt,
+                                                        const int32_t* __restrict__ nblk,
+                                                        int32_t* __restrict__ blk_off) {
+  __shared__ int s_part[16];
+  const int n = *nblk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (n + 1023) / 1024;
+  const int b0 = tid * chunk;
+  const int b1 = (b0 + chunk < n) ? (b0 + chunk) : n;
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += blk_cnt[b];
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_part[w];
+  int run = base + incl - sum;
+  for (int b = b0; b < b1; ++b) {
+    blk_off[b] = run;
+    run += blk_cnt[b];
+  }
+  if (tid == 1023) blk_off[n] = base + incl;
+}
+
+__global__ void bin_scatter_kernel(const Slot* __restrict__ slots, const int4* __restrict__ coords, int64_t n,
+                                   const int32_t* __restrict__ vox_slot, const int32_t* __restrict__ vox_pos,
+                                   const int32_t* __restrict__ blk_off, int4* __restrict__ binned) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = vox_slot[i];
+  if (s < 0) return;
+  const int id = slots[s].value;
+  const int4 c = coords[i];
+  binned[blk_off[id] + vox_pos[i]] = make_int4(c.y, c.z, c.w, (int)i);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* __restrict__ slots, uint32_t cmask,
+                                                                    const int32_t* __restrict__ blk_slot,
+                                                                    const int32_t* __restrict__ nblk,
+                                                                    const int32_t* __restrict__ blk_off,
+                                                                    const int4* __restrict__ binned, BinGeom g, int K,
+                                                                    int kp, int mw, int32_t* __restrict__ nbr,
+                                                                    uint32_t* __restrict__ mask) {
+  extern __shared__ unsigned int s_grid[];  // [gx*gy*gz] row ids, 0xFFFFFFFF = empty; then 27*3 ints of bin info
+  const int cells = g.gx * g.gy * g.gz;
+  int* s_nb_beg = reinterpret_cast<int*>(s_grid + cells);  // [27] first entry of neighbour bin
+  int* s_nb_pre = s_nb_beg + 27;                            // [28] prefix of neighbour bin sizes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nblocks = *nblk;
+  constexpr int kVoxPerIter = kBinThreads / LPR;
+  const int sub = tid % LPR, vsel = tid / LPR;
+
+  for (int id = blockIdx.x; id < nblocks; id += gridDim.x) {
+    const uint64_t key = slots[blk_slot[id]].key;
+    const int b = (int)((key >> 54) & kBatchMask);
+    const int bx = wrap_blk((int)((key >> 36) & kCoordMask));
+    const int by = wrap_blk((int)((key >> 18) & kCoordMask));
+    const int bz = wrap_blk((int)(key & kCoordMask));
+    // ---- neighbour bins (27 lanes probe the block table) ----
+    if (tid < 27) {
+      const int ddx = tid / 9 - 1, ddy = (tid / 3) % 3 - 1, ddz = tid % 3 - 1;
+      const bool needed = (ddx == 0 || g.hx > 0) && (ddy == 0 || g.hy > 0) && (ddz == 0 || g.hz > 0);
+      int beg = 0, cnt = 0;
+      if (needed) {
+        const int s = block_find(slots, cmask, block_key(b, wrap_blk(bx + ddx), wrap_blk(by + ddy), wrap_blk(bz + ddz)));
+        if (s >= 0) {
+          const int nid = slots[s].value;
+          beg = blk_off[nid];
+          cnt = blk_off[nid + 1] - beg;
+        }
+      }
+      s_nb_beg[tid] = beg;
+      s_nb_pre[tid + 1] = cnt;
+    }
+    for (int c = tid; c < cells; c += kBinThreads) s_grid[c] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (tid == 0) {
+      s_nb_pre[0] = 0;
+      for (int q = 0; q < 27; ++q) s_nb_pre[q + 1] += s_nb_pre[q];
+    }
+    __syncthreads();
+    // ---- fill the grid from the 27 bins ----
+    const int total = s_nb_pre[27];
+    for (int e = tid; e < total; e += kBinThreads) {
+      int q = 0;
+#pragma unroll
+      for (int t = 1; t < 27; ++t) q += (e >= s_nb_pre[t]);
+      const int4 v = binned[s_nb_beg[q] + (e - s_nb_pre[q])];
+      const int ddx = q / 9 - 1, ddy = (q / 3) % 3 - 1, ddz = q % 3 - 1;
+      const int lx = (v.x & (kBlk - 1)) + kBlk * ddx + g.hx;
+      const int ly = (v.y & (kBlk - 1)) + kBlk * ddy + g.hy;
+      const int lz = (v.z & (kBlk - 1)) + kBlk * ddz + g.hz;
+      if (lx >= 0 && lx < g.gx && ly >= 0 && ly < g.gy && lz >= 0 && lz < g.gz)
+        atomicMin(&s_grid[(lx * g.gy + ly) * g.gz + lz], (unsigned int)v.w);
+    }
+    __syncthreads();
+    // ---- answer the K probes of the block's own voxels: one lane per (voxel, offset) ----
+    const int own_beg = s_nb_beg[13], own_cnt = s_nb_pre[14] - s_nb_pre[13];
+    const int num_chunks = (kp + LPR - 1) / LPR;
+    for (int kc = 0; kc < num_chunks; ++kc) {
+      const int k = kc * LPR + sub;
+      const bool k_real = k < K, k_store = k < kp;
+      const int l = k % g.kz, j = (k / g.kz) % g.ky, i = k / (g.kz * g.ky);
+      const int ox = (i - g.cx) * g.dx, oy = (j - g.cy) * g.dy, oz = (l - g.cz) * g.dz;
+      for (int e0 = 0; e0 < own_cnt; e0 += kVoxPerIter) {
+        const int e = e0 + vsel;
+        int found = -1;
+        int row = -1;
+        if (e < own_cnt) {
+          const int4 v = binned[own_beg + e];
+          row = v.w;
+          if (k_real) {
+            const int lx = (v.x & (kBlk - 1)) + g.hx + ox, ly = (v.y & (kBlk - 1)) + g.hy + oy,
+                      lz = (v.z & (kBlk - 1)) + g.hz + oz;
+            found = (int)s_grid[(lx * g.gy + ly) * g.gz + lz];  // 0xFFFFFFFF -> -1
+          }
+          if (k_store) nbr[(int64_t)row * kp + k] = found;
+        }
+        const unsigned long long ball = __ballot(found >= 0);
+        if (row >= 0 && sub == 0) {
+          const int lsel = lane / LPR;  // voxel slot inside this wavefront
+          const unsigned long long bits = (LPR == 64) ? ball : ((ball >> (lsel * LPR)) & ((1ull << (LPR & 63)) - 1ull));
+          const int w0 = (kc * LPR) >> 5;
+          if (w0 < mw) mask[(int64_t)row * mw + w0] = (uint32_t)bits;
+          if (LPR == 64 && w0 + 1 < mw) mask[(int64_t)row * mw + w0 + 1] = (uint32_t)(bits >> 32);
+        }
+      }
+    }
+    __syncthreads();  // grid is reused by the next block
+  }
+}
+
+static inline size_t align256b(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct BinWorkspace {
+  int32_t *vox_slot, *vox_pos, *blk_slot, *blk_cnt, *blk_off, *nblk;
+  int4* binned;
+  size_t bytes;
+};
+
+static BinWorkspace carve(void* ws, int64_t n) {
+  BinWorkspace w;
+  char* p = (char*)ws;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off += align256b(bytes); return q; };
+  w.nblk = (int32_t*)take(256);
+  w.vox_slot = (int32_t*)take((size_t)n * 4);
+  w.vox_pos = (int32_t*)take((size_t)n * 4);
+  w.blk_slot = (int32_t*)take((size_t)n * 4);
+  w.blk_cnt = (int32_t*)take((size_t)n * 4);
+  w.blk_off = (int32_t*)take((size_t)(n + 1) * 4);
+  w.binned = (int4*)take((size_t)n * 16);
+  w.bytes = off;
+  return w;
+}
+
+static inline int lanes_per_row_b(int kp) {
+  int l = 8;
+  while (l < kp && l < 64) l <<= 1;
+  return l;
+}
+
+}  // namespace wcn
+
+using namespace wcn;
+
+extern "C" {
+
+size_t wcn_kmap_binned_workspace(int64_t n) { return carve(nullptr, n < 0 ? 0 : n).bytes; }
+
+int wcn_kmap_binned_supported(const int32_t ksize[3], const int32_t dilation[3]) {
+  if (!ksize || !dilation) return 0;
+  for (int d = 0; d < 3; ++d) {
+    if (ksize[d] < 1 || dilation[d] < 1) return 0;
+    const int c = (ksize[d] & 1) ? ksize[d] / 2 : 0;
+    const int lo = c * dilation[d], hi = (ksize[d] - 1 - c) * dilation[d];
+    if ((lo > hi ? lo : hi) > kMaxHalo) return 0;
+  }
+  return (int64_t)ksize[0] * ksize[1] * ksize[2] <= 4096 ? 1 : 0;
+}
+
+int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[3], const int32_t dilation[3],
+                          void* slots, int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* nbr,
+                          uint32_t* mask, int32_t* status, wcn_stream_t stream) {
+  if (n < 0 || !status || !slots || capacity <= 0 || (capacity & (capacity - 1)) != 0 || capacity > (1ll << 31))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  if (!wcn_kmap_binned_supported(ksize, dilation)) return WCN_ERROR_PROBLEM_NOT_SUPPORTED;
+  if (n == 0) return WCN_SUCCESS;
+  if (capacity < 2 * n && capacity < (1ll << 31)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (!coords || !nbr || !mask || !workspace || workspace_bytes < wcn_kmap_binned_workspace(n))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  const BinWorkspace w = carve(workspace, n);
+  const int K = ksize[0] * ksize[1] * ksize[2];
+  const int kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
+  BinGeom g;
+  g.kx = ksize[0]; g.ky = ksize[1]; g.kz = ksize[2];
+  g.cx = (g.kx & 1) ? g.kx / 2 : 0; g.cy = (g.ky & 1) ? g.ky / 2 : 0; g.cz = (g.kz & 1) ? g.kz / 2 : 0;
+  g.dx = dilation[0]; g.dy = dilation[1]; g.dz = dilation[2];
+  auto halo = [](int ks, int c, int d) { const int lo = c * d, hi = (ks - 1 - c) * d; return lo > hi ? lo : hi; };
+  g.hx = halo(g.kx, g.cx, g.dx); g.hy = halo(g.ky, g.cy, g.dy); g.hz = halo(g.kz, g.cz, g.dz);
+  g.gx = kBlk + 2 * g.hx; g.gy = kBlk + 2 * g.hy; g.gz = kBlk + 2 * g.hz;
+
+  if (hipMemsetAsync(w.nblk, 0, 256, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
+  int rc = wcn_hash_prepare(slots, capacity, stream);
+  if (rc != WCN_SUCCESS) return rc;
+  const uint32_t cmask = (uint32_t)(capacity - 1);
+  const unsigned gn = (unsigned)ceil_div(n, 256);
+  hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n,
+                     w.vox_slot, w.vox_pos, w.blk_slot, w.nblk, status);
+  hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, (const int32_t*)w.blk_slot,
+                     (const int32_t*)w.nblk, n, w.blk_cnt);
+  hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)w.blk_cnt, (const int32_t*)w.nblk,
+                     w.blk_off);
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(gn), dim3(256), 0, s, (const Slot*)slots, (const int4*)coords, n,
+                     (const int32_t*)w.vox_slot, (const int32_t*)w.vox_pos, (const int32_t*)w.blk_off, w.binned);
+  const size_t shm = (size_t)g.gx * g.gy * g.gz * 4 + 64 * 4;
+  const int64_t want = n / 64 + 1;  // never more workgroups than could have work
+  const dim3 grid((unsigned)(want < 4096 ? want : 4096)), block(kBinThreads);
+#define WCN_BIN_NB(L)                                                                                                  \
+  hipLaunchKernelGGL(bin_neighbors_kernel<L>, grid, block, shm, s, (const Slot*)slots, cmask, (const int32_t*)w.blk_slot, \
+                     (const int32_t*)w.nblk, (const int32_t*)w.blk_off, (const int4*)w.binned, g, K, kp, mw, nbr, mask)
+  switch (lanes_per_row_b(kp)) {
+    case 8: WCN_BIN_NB(8); break;
+    case 16: WCN_BIN_NB(16); break;
+    case 32: WCN_BIN_NB(32); break;
+    default: WCN_BIN_NB(64); break;
+  }
+#undef WCN_BIN_NB
+  return launch_status();
+}
+
+}  // extern "C"

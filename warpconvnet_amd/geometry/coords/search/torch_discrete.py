@@ -5,6 +5,7 @@ Mirrors `warpconvnet/geometry/coords/search/torch_discrete.py:24-56, 296-432` (`
 scan + deterministic per-offset compaction + mask argsort, all on the current HIP stream through the
 C-ABI, with ONE host read (offsets + status flags) where the reference does six.
 """
+import os
 from typing import Literal, Optional, Sequence, Tuple
 
 import numpy as np
@@ -175,20 +176,41 @@ def generate_kernel_map(
 
     # meta[0:K+1] = offsets, meta[K+1] = status flags -> one D2H copy
     meta = torch.zeros(K + 2, dtype=torch.int32, device=dev)
-    table = PackedHashTable(max(16, 2 * N), device=dev)
-    table._launch_insert(in_coords, meta[K + 1 :])
     nbr = torch.empty((M, kp), dtype=torch.int32, device=dev)
     mask = torch.empty((M, mw), dtype=torch.int32, device=dev)
     block_counts = torch.empty(K * (nblk + 1), dtype=torch.int32, device=dev)  # k-major counts + K totals
-    _lib.check(
-        L.wcn_kmap_probe(_lib.ptr(table.slots_tensor), table.capacity, _lib.ptr(out_coords), M, _lib.i3(ksize),
-                         _lib.i3(stride), _lib.i3(dilation), _lib.ptr(nbr), _lib.ptr(mask), stream),
-        "wcn_kmap_probe",
+    unit_stride = all(s == 1 for s in stride)
+    method_env = os.environ.get("WARPCONVNET_AMD_KMAP_METHOD", "auto").strip().lower()
+    use_binned = (
+        method_env != "hash" and same_tensor and unit_stride
+        and bool(L.wcn_kmap_binned_supported(_lib.i3(ksize), _lib.i3(dilation)))
     )
+    if method_env == "binned" and not use_binned:
+        raise RuntimeError("WARPCONVNET_AMD_KMAP_METHOD=binned needs a submanifold map (same coordinate tensor, stride 1, halo <= 4)")
+    table = PackedHashTable(max(16, 2 * N), device=dev)
+    if use_binned:
+        # LDS-binned path: block-level hash + counting sort + LDS grid probes (csrc/kmap_binned.hip)
+        table._slots = torch.empty((table.capacity, 2), dtype=torch.int64, device=dev)
+        ws_bytes = L.wcn_kmap_binned_workspace(N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(
+            L.wcn_kmap_build_binned(_lib.ptr(in_coords), N, _lib.i3(ksize), _lib.i3(dilation), _lib.ptr(table._slots),
+                                    table.capacity, _lib.ptr(ws), ws_bytes, _lib.ptr(nbr), _lib.ptr(mask),
+                                    _lib.ptr(meta[K + 1 :]), stream),
+            "wcn_kmap_build_binned",
+        )
+        table = None  # the block table is not a voxel table
+    else:
+        table._launch_insert(in_coords, meta[K + 1 :])
+        _lib.check(
+            L.wcn_kmap_probe(_lib.ptr(table.slots_tensor), table.capacity, _lib.ptr(out_coords), M, _lib.i3(ksize),
+                             _lib.i3(stride), _lib.i3(dilation), _lib.ptr(nbr), _lib.ptr(mask), stream),
+            "wcn_kmap_probe",
+        )
     _lib.check(L.wcn_kmap_count(_lib.ptr(mask), M, K, _lib.ptr(block_counts), stream), "wcn_kmap_count")
     _lib.check(L.wcn_kmap_scan(_lib.ptr(block_counts), nblk, K, _lib.ptr(meta), stream), "wcn_kmap_scan")
     meta_host = meta.cpu()  # the single host sync of the build
-    PackedHashTable.raise_for_flags(int(meta_host[K + 1]), N, table.capacity)
+    PackedHashTable.raise_for_flags(int(meta_host[K + 1]), N, _next_power_of_2(max(16, 2 * N)))
     offsets_host = meta_host[: K + 1].clone()
     num_pairs = int(offsets_host[-1])
     in_maps = torch.empty(num_pairs, dtype=torch.int32, device=dev)
@@ -201,7 +223,6 @@ def generate_kernel_map(
     perm = mask_argsort(mask)
 
     odd = all(k % 2 == 1 for k in ksize)
-    unit_stride = all(s == 1 for s in stride)
     identity = K // 2 if (odd and unit_stride and N == M) else None
     result = IntSearchResult(in_maps, out_maps, offsets_host, identity_map_index=identity)
     result._nbr, result._mask, result._perm = nbr, mask, perm
