@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kWgradGrid = 1024;  // G: pair ranges
+constexpr int kWgradGrid = 512;   // G: pair ranges (2 workgroups per CU)
 constexpr int kPairs = 64;        // pairs per pipeline step
 constexpr int kZeroPage = 1024;   // bytes of zeros at the start of the workspace (source for padded pairs)
 
@@ -67,6 +67,9 @@ __device__ __forceinline__ s16x8 read_frag_tr(const char* tile, int p0, int c0, 
   return out;
 }
 
+constexpr int kStages = 3;     // data ring: one stage computing, two in flight / landing
+constexpr int kIdxSlots = 4;   // index ring (64 in + 64 out rows per slot)
+
 template <typename T, int CIT, int COT>
 struct Wgrad {
   static constexpr int CHX = CIT / 8;   // 16-B chunks per staged x row
@@ -74,12 +77,50 @@ struct Wgrad {
   static constexpr int XT_BYTES = kPairs * CIT * 2;
   static constexpr int YT_BYTES = kPairs * COT * 2;
   static constexpr int STAGE_BYTES = XT_BYTES + YT_BYTES;
+  static constexpr int X_UNITS = XT_BYTES / 1024, Y_UNITS = YT_BYTES / 1024;  // 1 KiB per wave-instruction
+  static constexpr int DATA_OPS = (X_UNITS + Y_UNITS) / 4;                    // DMA instructions per wave per stage
   static constexpr int MB = CIT / 64;   // 32x32 blocks per wave along ci (wave owns CIT/2 rows)
   static constexpr int NBK = COT / 64;  // ... along co
-  static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES;
+  static constexpr int IDX_BYTES = kIdxSlots * 2 * kPairs * 4;
+  static constexpr size_t LDS_BYTES = (size_t)kStages * STAGE_BYTES + IDX_BYTES;
   static_assert(CIT % 64 == 0 && COT % 64 == 0, "tile must be a multiple of 64 channels");
+  static_assert(X_UNITS % 4 == 0 && Y_UNITS % 4 == 0, "every wave must issue the same number of DMA instructions");
 };
 
+// LDS-DMA issued through inline asm: hipcc neither counts these in its own s_waitcnt bookkeeping nor orders
+// later LDS reads behind them (with the builtin it drains vmcnt(0) before the first ds_read of every step, which
+// serialises the ring).  Completion is tracked by the counted s_waitcnt vmcnt(N) below.  M0 (LDS destination base)
+// is written and restored inside the statement; `lds_addr` must be wave-uniform.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Pipeline (per 64-pair step i of a segment; every wave issues the same instruction counts so the counted
+// vmcnt below means the same thing in all waves):
+//   A  index DMA for step i+3   (2 instructions: 16 in-rows + 16 out-rows per wave, 4 B per lane)
+//   B  data DMA for step i+2    (DATA_OPS instructions; row addresses come from the index ring in LDS)
+//   C  MFMA on step i           (transpose reads from stage i % 3)
+//   D  s_waitcnt vmcnt(DATA_OPS)  -> everything but B of this step has landed (data i+1, indices i+3)
+//      s_barrier                  -> ... and is visible to all waves; stage (i % 3) may be overwritten
 template <typename T, int CIT, int COT>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const int32_t* __restrict__ in_maps,
@@ -88,6 +129,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
                                                          const char* __restrict__ zero_page, float* __restrict__ slabs) {
   typedef Wgrad<T, CIT, COT> W;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_idx = smem + (size_t)kStages * W::STAGE_BYTES;  // [kIdxSlots][2][64] int32
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int G = gridDim.x, g = blockIdx.x;
@@ -101,8 +143,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
   const int64_t r_end = (r_begin + Q < L) ? (r_begin + Q) : L;
   if (r_begin >= r_end) return;
 
-  // first bucket containing r_begin
-  int k = 0;
+  int k = 0;  // first bucket containing r_begin
   {
     int lo = 0, hi = K;
     while (hi - lo > 1) {
@@ -136,40 +177,48 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
         }
   };
 
-  // stage `buf` <- pairs [p0, p0+64) clipped to [p0, seg_end): LDS-DMA, padded pairs read the zero page
-  auto stage = [&](int buf, int64_t p0, int64_t seg_end) {
-    char* xt = smem + (size_t)buf * W::STAGE_BYTES;
-    char* yt = xt + W::XT_BYTES;
-    constexpr int X_UNITS = W::XT_BYTES / 1024, Y_UNITS = W::YT_BYTES / 1024;
-#pragma unroll
-    for (int it = 0; it < (X_UNITS + 3) / 4; ++it) {
-      const int u = it * 4 + wave;
-      if (u < X_UNITS) {
-        const int piece = u * 64 + lane;         // LDS position: row p, chunk slot q'
-        const int p = piece / W::CHX, qs = piece % W::CHX;
-        const int q = qs ^ chunk_swizzle<W::CHX>(p);
-        const char* src = zero_page;
-        if (p0 + p < seg_end) src = reinterpret_cast<const char*>(x + (int64_t)in_maps[p0 + p] * cin + ci0) + q * 16;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                         (void __attribute__((address_space(3)))*)(xt + u * 1024), 16, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < (Y_UNITS + 3) / 4; ++it) {
-      const int u = it * 4 + wave;
-      if (u < Y_UNITS) {
-        const int piece = u * 64 + lane;
-        const int p = piece / W::CHY, qs = piece % W::CHY;
-        const int q = qs ^ chunk_swizzle<W::CHY>(p);
-        const char* src = zero_page;
-        if (p0 + p < seg_end) src = reinterpret_cast<const char*>(dy + (int64_t)out_maps[p0 + p] * cout + co0) + q * 16;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                         (void __attribute__((address_space(3)))*)(yt + u * 1024), 16, 0, 0);
-      }
+  // A: indices of step `st` -> index ring.  Wave w moves rows [16w, 16w+16) of in_maps and of out_maps.
+  auto dma_idx = [&](int st, int64_t seg_begin, int64_t seg_end) {
+    char* slot = s_idx + (size_t)(st % kIdxSlots) * (2 * kPairs * 4);
+    int64_t p = seg_begin + (int64_t)st * kPairs + wave * 16 + (lane & 15);
+    if (p >= seg_end) p = seg_end - 1;  // padded rows: any valid index (their data comes from the zero page)
+    const uint32_t d_in = __builtin_amdgcn_readfirstlane(lds_addr_of(slot + wave * 64));
+    const uint32_t d_out = __builtin_amdgcn_readfirstlane(lds_addr_of(slot + kPairs * 4 + wave * 64));
+    if (lane < 16) {
+      glds4(in_maps + p, d_in);
+      glds4(out_maps + p, d_out);
     }
   };
-  auto compute = [&](int buf) {
-    const char* xt = smem + (size_t)buf * W::STAGE_BYTES;
+  // B: gathered rows of step `st` -> data ring (row-major [pair][channel] tiles, chunk-swizzled on the source side)
+  auto dma_data = [&](int st, int64_t seg_begin, int64_t seg_end) {
+    char* xt = smem + (size_t)(st % kStages) * W::STAGE_BYTES;
+    char* yt = xt + W::XT_BYTES;
+    const int* idx_in = reinterpret_cast<const int*>(s_idx + (size_t)(st % kIdxSlots) * (2 * kPairs * 4));
+    const int* idx_out = idx_in + kPairs;
+    const int64_t p0 = seg_begin + (int64_t)st * kPairs;
+#pragma unroll
+    for (int it = 0; it < W::X_UNITS / 4; ++it) {
+      const int u = it * 4 + wave;
+      const int piece = u * 64 + lane;
+      const int p = piece / W::CHX, qs = piece % W::CHX;
+      const int q = qs ^ chunk_swizzle<W::CHX>(p);
+      const char* src = zero_page;
+      if (p0 + p < seg_end) src = reinterpret_cast<const char*>(x + (int64_t)idx_in[p] * cin + ci0) + q * 16;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(xt + u * 1024)));
+    }
+#pragma unroll
+    for (int it = 0; it < W::Y_UNITS / 4; ++it) {
+      const int u = it * 4 + wave;
+      const int piece = u * 64 + lane;
+      const int p = piece / W::CHY, qs = piece % W::CHY;
+      const int q = qs ^ chunk_swizzle<W::CHY>(p);
+      const char* src = zero_page;
+      if (p0 + p < seg_end) src = reinterpret_cast<const char*>(dy + (int64_t)idx_out[p] * cout + co0) + q * 16;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(yt + u * 1024)));
+    }
+  };
+  auto compute = [&](int st) {
+    const char* xt = smem + (size_t)(st % kStages) * W::STAGE_BYTES;
     const char* yt = xt + W::XT_BYTES;
 #pragma unroll
     for (int ks = 0; ks < kPairs / 16; ++ks) {
@@ -184,49 +233,70 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
         for (int b = 0; b < W::NBK; ++b) acc[a][b] = WFrag<T>::mfma(af[a], bf[b], acc[a][b]);
     }
   };
-  auto sync_step = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  auto barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   };
 
   int64_t pos = r_begin;
   while (pos < r_end) {
     while ((int64_t)offsets[k + 1] <= pos) ++k;  // skip empty buckets
     const int64_t seg_end = ((int64_t)offsets[k + 1] < r_end) ? (int64_t)offsets[k + 1] : r_end;
+    const int nsteps = (int)((seg_end - pos + kPairs - 1) / kPairs);
     zero_acc();
-    // software pipeline over 64-pair steps of [pos, seg_end)
-    int buf = 0;
-    stage(0, pos, seg_end);
-    sync_step();
-    for (int64_t p0 = pos; p0 < seg_end; p0 += kPairs) {
-      const int64_t pn = p0 + kPairs;
-      if (pn < seg_end) stage(buf ^ 1, pn, seg_end);
-      compute(buf);
-      sync_step();
-      buf ^= 1;
+    // ---- prologue: indices of steps 0..2, data of steps 0..1 ----
+    dma_idx(0, pos, seg_end);
+    if (nsteps > 1) dma_idx(1, pos, seg_end);
+    if (nsteps > 2) dma_idx(2, pos, seg_end);
+    wait_vmcnt<0>();
+    barrier();
+    dma_data(0, pos, seg_end);
+    if (nsteps > 1) {
+      dma_data(1, pos, seg_end);
+      wait_vmcnt<W::DATA_OPS>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    barrier();
+    // ---- steady state ----
+    for (int i = 0; i < nsteps; ++i) {
+      if (i + 3 < nsteps) dma_idx(i + 3, pos, seg_end);
+      const bool more = i + 2 < nsteps;
+      if (more) dma_data(i + 2, pos, seg_end);
+      compute(i);
+      if (more) {
+        wait_vmcnt<W::DATA_OPS>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      barrier();
     }
     flush(k);
     pos = seg_end;
   }
 }
 
-// dw[k][e] = sum over ranges g that intersect bucket k (ascending) of slab[g + k][e]
+// dw[k][e] = sum over ranges g that intersect bucket k (ascending) of slab[g + k][e].
+// 4 threads share an element (g mod 4), combined through LDS in a fixed order => deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs,
                                                            const int32_t* __restrict__ offsets, int K, int64_t ce, int G,
                                                            float* __restrict__ dw) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float s_part[4][64];
+  const int part = threadIdx.x >> 6, el = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 64 + el;
   const int k = blockIdx.y;
-  if (e >= ce) return;
   const int64_t L = offsets[K];
   int64_t Q = (L + G - 1) / G;
   Q = ((Q + kPairs - 1) / kPairs) * kPairs;
   const int64_t b = offsets[k], en = offsets[k + 1];
   float s = 0.f;
-  if (en > b && Q > 0) {
+  if (e < ce && en > b && Q > 0) {
     const int g_lo = (int)(b / Q), g_hi = (int)((en - 1) / Q);
-    for (int g = g_lo; g <= g_hi; ++g) s += slabs[(int64_t)(g + k) * ce + e];
+    for (int g = g_lo + part; g <= g_hi; g += 4) s += slabs[(int64_t)(g + k) * ce + e];
   }
-  dw[(int64_t)k * ce + e] = s;
+  s_part[part][el] = s;
+  __syncthreads();
+  if (part == 0 && e < ce) dw[(int64_t)k * ce + e] = (s_part[0][el] + s_part[1][el]) + (s_part[2][el] + s_part[3][el]);
 }
 
 bool mfma_wgrad_supported(int cin, int cout, int dtype) {
@@ -257,7 +327,7 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
   hipLaunchKernelGGL(kern, grid, dim3(256), W::LDS_BYTES, s, (const T*)x, (const T*)dy, in_maps, out_maps, offsets, K, cin,
                      cout, (const char*)zero_page, slabs);
   const int64_t ce = (int64_t)cin * cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ce, 256), K), dim3(256), 0, s, (const float*)slabs,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ce, 64), K), dim3(256), 0, s, (const float*)slabs,
                      offsets, K, ce, kWgradGrid, dw);
   return launch_status();
 }
