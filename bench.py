@@ -120,7 +120,7 @@ def main():
     coords = torch.from_numpy(scene_u(args.voxels, seed=1000 + rank)).to(dev)
     N = coords.shape[0]
     g = torch.Generator().manual_seed(rank)
-    feats = torch.randn(N, CIN, generator=g).to(dev)
+    feats = torch.randn(N, CIN, generator=g).to(dev, torch.bfloat16)  # bf16 features resident in HBM
     grad_out = torch.randn(N, COUT, generator=g).to(dev, torch.bfloat16)
     offsets = torch.tensor([0, N], dtype=torch.int32)
     torch.manual_seed(0)
@@ -166,7 +166,7 @@ def main():
         bcoords = torch.cat([torch.zeros(N, 1, dtype=torch.int32, device=dev), coords], 1).contiguous()
         km = generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3))
         L = int(km.offsets[-1])
-        X = feats.to(torch.bfloat16)
+        X = feats
         W = conv.weight.detach().to(torch.bfloat16)
         it = max(5, args.steps)
         t_kmap = time_events(lambda: generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3)), it)
@@ -183,11 +183,11 @@ def main():
 
         def k_fwd():
             Lc.wcn_conv_gather_gemm(_lib.ptr(X), _lib.ptr(wp_f), _lib.ptr(y_buf), _lib.ptr(km._nbr), _lib.ptr(km._mask),
-                                    _lib.ptr(km._perm), N, N, CIN, COUT, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 0, 0, stream)
+                                    _lib.ptr(km._perm), None, N, N, CIN, COUT, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 0, 0, stream)
 
         def k_dgrad():
             Lc.wcn_conv_gather_gemm(_lib.ptr(grad_out), _lib.ptr(wp_d), _lib.ptr(dx_buf), _lib.ptr(km._nbr), _lib.ptr(km._mask),
-                                    _lib.ptr(km._perm), N, N, COUT, CIN, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 1, 1, stream)
+                                    _lib.ptr(km._perm), None, N, N, COUT, CIN, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 1, 1, stream)
 
         tk_fwd, tk_dgrad = time_events(k_fwd, it), time_events(k_dgrad, it)
         ab = algorithmic_bytes(N, L)

@@ -170,13 +170,20 @@ int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cou
 
 /* y = gather-GEMM over a neighbour table.  Serves forward (x, packed w) and dgrad (dy, packed w^T).
  *   in   [n_in, cin]   out [n_out, cout]   nbr [n_out, kp]   mask [n_out, mw]   perm [n_out] or NULL
+ *   bias fp32 [cout] or NULL: fused epilogue out += bias (reference adds it afterwards, helper.py:339-342)
  *   w:   for WCN_ALGO_REF the plain [K, cin, cout] tensor (or [K, cout', cin'] with w_transposed=1),
  *        for WCN_ALGO_MFMA the image made by wcn_pack_weight.
  * reference: _C.mask_gemm.fwd / .dgrad (mask_gemm_bindings.cu:2074-2101). */
 int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t* nbr,
-                         const uint32_t* mask, const int32_t* perm, int64_t n_in, int64_t n_out,
-                         int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype, int32_t algo,
-                         int32_t w_transposed, int32_t k_flip, wcn_stream_t stream);
+                         const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_in,
+                         int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
+                         int32_t algo, int32_t w_transposed, int32_t k_flip, wcn_stream_t stream);
+
+/* out[c] = sum_r in[r][c] in fp32 (bias gradient; reference: autograd of `out + bias`, helper.py:339-342).
+ * Deterministic two-pass reduction; workspace: wcn_colsum_workspace(channels) bytes. */
+size_t wcn_colsum_workspace(int32_t channels);
+int wcn_colsum(const void* in, int64_t n, int32_t channels, int32_t dtype, float* out, void* workspace,
+               size_t workspace_bytes, wcn_stream_t stream);
 
 /* dw [K, cin, cout] fp32 (overwritten).  workspace: wcn_conv_wgrad_workspace(...) bytes.
  * reference: _C.mask_gemm.wgrad (mask_gemm_bindings.cu:2103-2116), fp32 output. */

@@ -3,14 +3,17 @@
 
 namespace wcn {
 // conv_ref.hip
-int conv_gather_gemm_ref(const void* in, const void* w, void* out, const int32_t* nbr, int64_t n_out, int cin, int cout,
-                         int K, int dtype, int w_transposed, int k_flip, hipStream_t s);
+int conv_gather_gemm_ref(const void* in, const void* w, void* out, const int32_t* nbr, const float* bias, int64_t n_out,
+                         int cin, int cout, int K, int dtype, int w_transposed, int k_flip, hipStream_t s);
+size_t colsum_workspace(int c);
+int colsum(const void* in, int64_t n, int c, int dtype, float* out, void* workspace, size_t workspace_bytes, hipStream_t s);
 int conv_wgrad_ref(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                    const int32_t* offsets, int cin, int cout, int K, int dtype, hipStream_t s);
 // conv_mfma.hip
 bool mfma_gather_supported(int cin, int cout, int K, int dtype);
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                          const int32_t* perm, int64_t n_out, int cin, int cout, int K, int dtype, hipStream_t s);
+                          const int32_t* perm, const float* bias, int64_t n_out, int cin, int cout, int K, int dtype,
+                          hipStream_t s);
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s);
 // wgrad_mfma.hip
@@ -48,9 +51,9 @@ int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cou
 }
 
 int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t* nbr, const uint32_t* mask,
-                         const int32_t* perm, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout,
-                         int32_t num_offsets, int32_t dtype, int32_t algo, int32_t w_transposed, int32_t k_flip,
-                         wcn_stream_t stream) {
+                         const int32_t* perm, const float* bias, int64_t n_in, int64_t n_out, int32_t cin,
+                         int32_t cout, int32_t num_offsets, int32_t dtype, int32_t algo, int32_t w_transposed,
+                         int32_t k_flip, wcn_stream_t stream) {
   if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || !dtype_ok(dtype))
     return WCN_ERROR_INVALID_PARAMETERS;
   if (n_out == 0) return WCN_SUCCESS;
@@ -58,15 +61,24 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
   hipStream_t s = (hipStream_t)stream;
   switch (algo) {
     case WCN_ALGO_REF:
-      return conv_gather_gemm_ref(in, w, out, nbr, n_out, cin, cout, num_offsets, dtype, w_transposed, k_flip, s);
+      return conv_gather_gemm_ref(in, w, out, nbr, bias, n_out, cin, cout, num_offsets, dtype, w_transposed, k_flip, s);
     case WCN_ALGO_MFMA:
       // `w` must be the packed image (wcn_pack_weight already applied transpose / flip)
       if (!mask) return WCN_ERROR_INVALID_PARAMETERS;
-      return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, n_out, cin, cout, num_offsets, dtype, s);
+      return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, s);
     default:
       // AUTO cannot be resolved here because the two algorithms take different weight images.
       return WCN_ERROR_INVALID_PARAMETERS;
   }
+}
+
+size_t wcn_colsum_workspace(int32_t channels) { return channels > 0 ? colsum_workspace(channels) : 0; }
+
+int wcn_colsum(const void* in, int64_t n, int32_t channels, int32_t dtype, float* out, void* workspace,
+               size_t workspace_bytes, wcn_stream_t stream) {
+  if (n < 0 || channels < 1 || !dtype_ok(dtype) || !out) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n > 0 && !in) return WCN_ERROR_INVALID_PARAMETERS;
+  return colsum(in, n, channels, dtype, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 size_t wcn_conv_wgrad_workspace(int32_t num_offsets, int32_t cin, int32_t cout, int32_t algo) {

@@ -91,7 +91,8 @@ template <typename T, int CIC, int CO, int RB>
 __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __restrict__ in, const T* __restrict__ wp,
                                                                T* __restrict__ out, const int32_t* __restrict__ nbr,
                                                                const uint32_t* __restrict__ mask,
-                                                               const int32_t* __restrict__ perm, int64_t n_out, int cin,
+                                                               const int32_t* __restrict__ perm,
+                                                               const float* __restrict__ bias, int64_t n_out, int cin,
                                                                int K, int kp) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   typedef typename G::frag_t frag_t;
@@ -240,6 +241,15 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       frag_t lo, hi;
+      if (bias) {  // fused epilogue: + bias[co] in fp32 before the rounding to the storage dtype
+        const float4* bp = reinterpret_cast<const float4*>(bias + h * (CO / 2) + 16 * b);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float4 bv = bp[v];
+          acc[b][rb][4 * v + 0] += bv.x; acc[b][rb][4 * v + 1] += bv.y;
+          acc[b][rb][4 * v + 2] += bv.z; acc[b][rb][4 * v + 3] += bv.w;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         lo[q] = (T)acc[b][rb][q];
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 
 template <typename T, int CIC, int CO, int RB>
 static int launch_gather_gemm(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                              const int32_t* perm, int64_t n_out, int cin, int K, hipStream_t s) {
+                              const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, hipStream_t s) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   const int kp = wcn_kmap_row_pitch(K);
   auto kern = gather_gemm_mfma_kernel<T, CIC, CO, RB>;
@@ -266,19 +276,19 @@ static int launch_gather_gemm(const void* in, const void* wp, void* out, const i
   }
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm,
-                     n_out, cin, K, kp);
+                     bias, n_out, cin, K, kp);
   return launch_status();
 }
 
 template <typename T, int CIC>
 static int dispatch_co(int cout, const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                       const int32_t* perm, int64_t n_out, int cin, int K, hipStream_t s) {
+                       const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, hipStream_t s) {
   switch (cout) {
-    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
-    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
-    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
-    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
-    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
@@ -299,20 +309,21 @@ bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
 
 template <typename T>
 static int dispatch_cic(int cin, int cout, const void* in, const void* wp, void* out, const int32_t* nbr,
-                        const uint32_t* mask, const int32_t* perm, int64_t n_out, int K, hipStream_t s) {
+                        const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_out, int K, hipStream_t s) {
   switch (mfma_chunk_for(cin)) {
-    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, n_out, cin, K, s);
-    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, n_out, cin, K, s);
-    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, n_out, cin, K, s);
+    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
 
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                          const int32_t* perm, int64_t n_out, int cin, int cout, int K, int dtype, hipStream_t s) {
+                          const int32_t* perm, const float* bias, int64_t n_out, int cin, int cout, int K, int dtype,
+                          hipStream_t s) {
   if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
-  if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, n_out, K, s);
-  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, n_out, K, s);
+  if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, s);
+  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, s);
 }
 
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,

@@ -89,6 +89,7 @@ class BatchedTensor:
     def _new(self, tensor: Tensor) -> "BatchedTensor":
         out = object.__new__(self.__class__)
         out.__dict__.update(self.__dict__)
+        out.__dict__.pop("_bcoords", None)
         out.batched_tensor = tensor
         return out
 

@@ -13,11 +13,15 @@ from torch import Tensor
 
 @torch.no_grad()
 def batch_index_from_offset(offsets: Tensor, device=None) -> Tensor:
-    """offsets [B+1] -> int32 batch index per row [N]."""
+    """offsets [B+1] -> int32 batch index per row [N], produced ON ``device`` (only the B counts cross the bus;
+    ``output_size`` is known from the host offsets, so there is no device->host sync)."""
     off = offsets.detach().cpu().to(torch.int64)
     counts = off[1:] - off[:-1]
-    idx = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), counts)
-    return idx if device is None else idx.to(device)
+    n = int(off[-1] - off[0])
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if len(counts) == 1:
+        return torch.zeros(n, dtype=torch.int32, device=dev)
+    return torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32, device=dev), counts.to(dev), output_size=n)
 
 
 @torch.no_grad()

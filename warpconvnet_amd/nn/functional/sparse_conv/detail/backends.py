@@ -30,6 +30,7 @@ class FwdCtx:
     fwd_block_size: Optional[int] = None
     groups: int = 1
     use_fp16_accum: bool = False
+    bias: Optional[Tensor] = None  # fused epilogue (build extension; the reference adds the bias outside)
 
 
 @dataclass
@@ -54,7 +55,8 @@ BwdFn = Callable[[BwdCtx], Tuple[Any, Any]]
 
 
 def _fwd_explicit(ctx: FwdCtx):
-    return _explicit_gemm_forward_logic(ctx.in_features, ctx.weight, ctx.kernel_map, ctx.num_out_coords, ctx.compute_dtype)
+    out = _explicit_gemm_forward_logic(ctx.in_features, ctx.weight, ctx.kernel_map, ctx.num_out_coords, ctx.compute_dtype)
+    return out if ctx.bias is None else out + ctx.bias.to(out.dtype)
 
 
 def _bwd_explicit(ctx: BwdCtx):
@@ -67,7 +69,8 @@ def _make_hip_fwd(algo: str) -> FwdFn:
         if ctx.groups != 1:
             return -1  # WCN_ERROR_PROBLEM_NOT_SUPPORTED: grouped conv is not covered by the HIP kernels yet
         dt = ctx.compute_dtype or ctx.in_features.dtype
-        out = hip_gemm.hip_forward(ctx.in_features.to(dt), ctx.weight.to(dt), ctx.kernel_map, ctx.num_out_coords, algo)
+        out = hip_gemm.hip_forward(ctx.in_features.to(dt), ctx.weight.to(dt), ctx.kernel_map, ctx.num_out_coords, algo,
+                                   bias=ctx.bias)
         return out.to(ctx.in_features.dtype) if ctx.compute_dtype is not None else out
 
     return fn

@@ -62,7 +62,8 @@ def pack_weight(weight: Tensor, transpose: bool, flip: bool) -> Tensor:
 
 
 def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: Optional[Tensor], n_out: int,
-                 cin: int, cout: int, K: int, algo_code: int, transposed: bool, flip: bool) -> Tensor:
+                 cin: int, cout: int, K: int, algo_code: int, transposed: bool, flip: bool,
+                 bias: Optional[Tensor] = None) -> Tensor:
     out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
     if n_out == 0:
         return out
@@ -72,7 +73,7 @@ def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: O
         w_arg = weight
     _lib.check(
         _lib.lib().wcn_conv_gather_gemm(
-            _lib.ptr(inp), _lib.ptr(w_arg), _lib.ptr(out), _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(perm),
+            _lib.ptr(inp), _lib.ptr(w_arg), _lib.ptr(out), _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(perm), _lib.ptr(bias),
             inp.shape[0], n_out, cin, cout, K, _lib.dtype_code(inp.dtype), algo_code, int(transposed), int(flip),
             _lib.stream_handle(inp.device)),
         "wcn_conv_gather_gemm",
@@ -81,8 +82,13 @@ def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: O
 
 
 def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_out_coords: int,
-                algo: str = "auto") -> Tensor:
-    """y[m] = sum_k x[nbr[m][k]] @ w[k]."""
+                algo: str = "auto", bias: Optional[Tensor] = None) -> Tensor:
+    """y[m] = sum_k x[nbr[m][k]] @ w[k] (+ bias, fused into the epilogue in fp32)."""
+    if bias is not None:
+        bias = bias.detach()
+        if bias.dtype != torch.float32:
+            bias = bias.float()
+        bias = _prep(bias, "bias")
     x, w = _prep(in_features, "in_features"), _prep(weight, "weight")
     if x.dtype != w.dtype:
         raise RuntimeError(f"hip forward error: {_lib.status_string(-6)} ({x.dtype} vs {w.dtype})")
@@ -91,7 +97,23 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
     attach_tables_from_csr(kernel_map, x.shape[0], num_out_coords)
     code = resolve_gather_algo(algo, cin, cout, K, x.dtype)
     return _gather_gemm(x, w, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K, code,
-                        transposed=False, flip=False)
+                        transposed=False, flip=False, bias=bias)
+
+
+def hip_colsum(t: Tensor) -> Tensor:
+    """fp32 column sums of a [N, C] tensor (bias gradient), deterministic."""
+    t = _prep(t, "grad_output")
+    n, c = t.shape
+    out = torch.empty(c, dtype=torch.float32, device=t.device)
+    L = _lib.lib()
+    ws_bytes = L.wcn_colsum_workspace(c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
+    _lib.check(
+        L.wcn_colsum(_lib.ptr(t), n, c, _lib.dtype_code(t.dtype), _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                     _lib.stream_handle(t.device)),
+        "wcn_colsum",
+    )
+    return out
 
 
 def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_in_coords: int,

@@ -64,7 +64,10 @@ class UnifiedSpatiallySparseConvFunction(Function):
         conv_cache_metadata: Optional[dict] = None,
         groups: int = 1,
         use_fp16_accum: bool = False,
+        bias: Optional[Tensor] = None,
     ) -> Tensor:
+        """``bias`` (15th argument, optional) is a build extension: the bias add is fused into the GEMM epilogue and
+        its gradient is a HIP column-sum; the 14-argument reference call signature is unchanged."""
         on_gpu = in_features.is_cuda
         ctx.kernel_map = kernel_map
         ctx.num_out_coords = num_out_coords
@@ -73,18 +76,28 @@ class UnifiedSpatiallySparseConvFunction(Function):
         ctx.dgrad_algo = _algo_name(dgrad_algo, on_gpu)
         ctx.wgrad_algo = _algo_name(wgrad_algo, on_gpu)
         ctx.save_for_backward(in_features, weight)
+        ctx.has_bias = bias is not None
         cout = weight.shape[-1] * (groups if weight.ndim == 4 else 1)
         if num_out_coords == 0 or in_features.shape[0] == 0 or in_features.shape[1] == 0 or cout == 0:
-            return torch.zeros((num_out_coords, cout), dtype=in_features.dtype, device=in_features.device)
+            out = torch.zeros((num_out_coords, cout), dtype=in_features.dtype, device=in_features.device)
+            return out if bias is None else out + bias.to(out.dtype)
         fctx = FwdCtx(in_features, weight, kernel_map, num_out_coords, compute_dtype, {}, fwd_block_size, groups,
-                      bool(use_fp16_accum))
+                      bool(use_fp16_accum), bias)
         return run_forward(_algo_name(fwd_algo, on_gpu), fctx)
 
     @staticmethod
     def backward(ctx, grad_output: Tensor):
         in_features, weight = ctx.saved_tensors  # read exactly once (activation-checkpointing contract)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        grad_in = grad_w = None
+        need_db = ctx.has_bias and len(ctx.needs_input_grad) > 14 and ctx.needs_input_grad[14]
+        grad_in = grad_w = grad_b = None
+        if need_db:
+            if grad_output.is_cuda and grad_output.shape[0] > 0:
+                from .hip_gemm import hip_colsum
+
+                grad_b = hip_colsum(grad_output.contiguous())
+            else:
+                grad_b = grad_output.float().sum(0)
         empty = ctx.num_out_coords == 0 or in_features.shape[0] == 0 or grad_output.shape[1] == 0
         if empty or not (need_dx or need_dw):
             if need_dx:
@@ -106,4 +119,6 @@ class UnifiedSpatiallySparseConvFunction(Function):
                 if need_dw:
                     _, grad_w = run_backward(ctx.wgrad_algo, _ctx((False, True)))
         ctx.kernel_map = None  # release eagerly (reference unified.py:779-783)
-        return _pad_values(14, grad_in, grad_w)
+        out = list(_pad_values(15, grad_in, grad_w))
+        out[14] = grad_b
+        return tuple(out)

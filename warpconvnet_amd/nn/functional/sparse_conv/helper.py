@@ -185,10 +185,8 @@ def spatially_sparse_conv(
         implicit_matmul_fwd_block_size, implicit_matmul_bwd_block_size, in_tensor_stride,
         {"conv_stride": _stride, "transposed": transposed, "generative": generative,
          "stride_mode": getattr(stride_mode, "value", str(stride_mode))},
-        groups, use_fp16_accum,
+        groups, use_fp16_accum, bias,  # bias: fused epilogue + HIP column-sum gradient (reference: helper.py:339-342)
     )
-    if bias is not None:
-        out_feats = out_feats + bias.to(out_feats.dtype)
 
     out_offsets_cpu = out_offsets.cpu().int() if out_offsets.dtype != torch.int32 or out_offsets.device.type != "cpu" else out_offsets
     return input_sparse_tensor.replace(
