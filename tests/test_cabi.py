@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library loads and exports every symbol include/wcn.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from tests.conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "wcn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wcn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(hip_lib):
+    from warpconvnet_amd import _lib
+
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared if not hasattr(raw, s)]
+    assert not missing, f"declared in wcn.h but not exported: {missing}"
+    # the ctypes table binds exactly the declared entry points
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_pure_host_entry_points(hip_lib):
+    """Entry points that do not touch the device."""
+    from warpconvnet_amd import _lib
+
+    L = hip_lib
+    assert L.wcn_abi_version() >= 1
+    assert _lib.status_string(0) == "Success" and _lib.status_string(-4) == "Unsupported precision/configuration"
+    assert _lib.status_string(-5) == "Invalid parameters" and _lib.status_string(-99) == "Unknown error"
+    assert L.wcn_kmap_row_pitch(27) == 32 and L.wcn_kmap_row_pitch(8) == 8 and L.wcn_kmap_row_pitch(125) == 128
+    assert L.wcn_kmap_mask_words(27) == 1 and L.wcn_kmap_mask_words(33) == 2
+    assert L.wcn_kmap_num_blocks(1000) == 16
+    assert L.wcn_mfma_gather_supported(64, 128, 27, _lib.WCN_BF16) == 1
+    assert L.wcn_mfma_gather_supported(64, 128, 27, _lib.WCN_F32) == 0
+    assert L.wcn_mfma_gather_supported(7, 13, 27, _lib.WCN_BF16) == 0
+    assert L.wcn_mfma_gather_supported(64, 128, 125, _lib.WCN_BF16) == 0
+    assert L.wcn_mfma_wgrad_supported(64, 128, _lib.WCN_F16) == 1 and L.wcn_mfma_wgrad_supported(32, 32, _lib.WCN_F16) == 0
+    assert L.wcn_kmap_binned_supported(_lib.i3((3, 3, 3)), _lib.i3((1, 1, 1))) == 1
+    assert L.wcn_kmap_binned_supported(_lib.i3((3, 3, 3)), _lib.i3((8, 8, 8))) == 0
+    assert L.wcn_packed_weight_bytes(27, 64, 128, _lib.WCN_BF16, 0) == 27 * 64 * 128 * 2
+    assert L.wcn_conv_wgrad_workspace(27, 64, 128, _lib.WCN_ALGO_MFMA) > 27 * 64 * 128 * 4
+    assert L.wcn_mask_argsort_workspace(1000) > 3 * 4000 and L.wcn_kmap_binned_workspace(1000) > 36 * 1000
+    # parameter validation happens before any launch: bad arguments come back as status codes
+    assert L.wcn_hash_prepare(None, 16, None) == -5
+    assert L.wcn_hash_prepare(None, 17, None) == -5
+    assert L.wcn_conv_gather_gemm(None, None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 1, 0, 0, None) == -5
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    from warpconvnet_amd import _lib
+
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.lib()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("lib() must raise when the HIP extension is missing")

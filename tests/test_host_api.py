@@ -1,0 +1,176 @@
+"""CPU: host-side mirror of the reference API (geometry types, containers, module init, explicit backend)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kmap as okmap
+from tests.util import scene_u
+from warpconvnet_amd.geometry.coords.search.cache import IntSearchCache, IntSearchCacheKey
+from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult, RealSearchResult
+from warpconvnet_amd.geometry.coords.search.torch_discrete import kernel_offsets_from_size
+from warpconvnet_amd.geometry.types.points import Points
+from warpconvnet_amd.geometry.types.voxels import Voxels
+from warpconvnet_amd.nn.modules.sparse_conv import SparseConv2d, SparseConv3d
+
+
+def test_kernel_offsets_match_reference_tables(golden_dir):
+    g = np.load(os.path.join(golden_dir, "offset_tables.npz"))
+    for name in g.files:
+        ks, dl = tuple(int(c) for c in name[1:4]), tuple(int(c) for c in name[6:9])
+        np.testing.assert_array_equal(kernel_offsets_from_size(ks, dl).numpy(), g[name])
+
+
+def test_int_search_result_container_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "search_result_api.npz"))
+    r = IntSearchResult(torch.from_numpy(g["in_maps"]), torch.from_numpy(g["out_maps"]), torch.from_numpy(g["offsets"]))
+    assert len(r) == int(g["length"]) and [r.numel(i) for i in range(3)] == g["numel"].tolist()
+    assert r.offsets.device.type == "cpu"
+    np.testing.assert_array_equal(r[1][0].numpy(), g["item1_in"])
+    np.testing.assert_array_equal(r[2][0].numpy(), g["item2_in"])
+    np.testing.assert_array_equal(r[2][1].numpy(), g["item2_out"])
+    ci, co, coff = r.to_csr()
+    np.testing.assert_array_equal(co.numpy(), g["csr_out"])
+    np.testing.assert_array_equal(coff.numpy(), g["csr_off"])
+    # the reference's torch.sort is not stable: compare in-rows as sets per output row
+    for j in range(len(g["csr_out"])):
+        s, e = int(g["csr_off"][j]), int(g["csr_off"][j + 1])
+        assert sorted(ci[s:e].tolist()) == sorted(g["csr_in"][s:e].tolist())
+    np.testing.assert_array_equal(r.neighbor_count_per_output(5).numpy(), g["counts"])
+    assert [len(a) for a, _ in r] == g["numel"].tolist()
+    with pytest.raises(AssertionError):
+        IntSearchResult(torch.zeros(3, dtype=torch.int32), torch.zeros(3, dtype=torch.int32), torch.tensor([0, 2]))
+    knn = RealSearchResult(torch.arange(12).reshape(4, 3))
+    assert knn.neighbor_row_splits.tolist() == [0, 3, 6, 9, 12]
+
+
+def test_cache_key_truth_table(golden_dir):
+    g = np.load(os.path.join(golden_dir, "cache_key.npz"))
+    o1, o2 = torch.tensor([0, 5, 9]), torch.tensor([0, 5, 10])
+    base = dict(kernel_size=(3, 3, 3), kernel_dilation=(1, 1, 1), transposed=False, generative=False,
+                stride_mode="stride_only", skip_symmetric_kernel_map=False, in_offsets=o1, out_offsets=o1)
+    variants = [dict(), dict(kernel_size=(2, 2, 2)), dict(kernel_dilation=(2, 2, 2)), dict(transposed=True),
+                dict(in_offsets=o2), dict(out_offsets=o2)]
+    k0 = IntSearchCacheKey(**base)
+    assert [bool(k0 == IntSearchCacheKey(**{**base, **v})) for v in variants] == g["equal"].tolist()
+    assert hash(k0) == hash(IntSearchCacheKey(**base))
+    c = IntSearchCache()
+    assert c.get(k0) is None
+    c.put(k0, "x")
+    assert c.get(IntSearchCacheKey(**base)) == "x"
+
+
+def test_module_init_matches_reference_state_dict(golden_dir):
+    """Same torch version + same RNG stream => the seeded initial weights equal the reference's bit for bit."""
+    g = np.load(os.path.join(golden_dir, "module_init.npz"))
+    for name, kwargs in [("c16x32_k3", dict(in_channels=16, out_channels=32, kernel_size=3)),
+                         ("c64x128_k3_g4", dict(in_channels=64, out_channels=128, kernel_size=3, groups=4)),
+                         ("c32x16_k2_s2_tr", dict(in_channels=32, out_channels=16, kernel_size=2, stride=2, transposed=True))]:
+        torch.manual_seed(0)
+        m = SparseConv3d(**kwargs)
+        np.testing.assert_array_equal(m.weight.detach().numpy(), g[name + "_weight"])
+        np.testing.assert_array_equal(m.bias.detach().numpy(), g[name + "_bias"])
+    m = SparseConv3d(16, 32, 3)
+    bound = (3 ** 0.5) * (2.0 / (1 + 5)) ** 0.5 / (16 * 27) ** 0.5
+    assert m.weight.shape == (27, 16, 32) and float(m.weight.detach().abs().max()) <= bound + 1e-7
+    assert SparseConv2d(8, 8, 3).weight.shape == (9, 8, 8)
+    assert SparseConv3d(8, 8, 3, bias=False).bias is None
+    with pytest.raises(ValueError):
+        SparseConv3d(10, 8, 3, groups=4)
+    with pytest.raises(ValueError):
+        SparseConv3d(8, 8, 3, fwd_algo="not_an_algo")
+
+
+def test_voxels_behaviour():
+    """Behaviours pinned by the reference's type tests (tests/types/test_voxels.py:27-255)."""
+    c = [torch.randint(0, 10, (5, 3), dtype=torch.int32), torch.randint(0, 10, (7, 3), dtype=torch.int32)]
+    f = [torch.randn(5, 4), torch.randn(7, 4)]
+    v = Voxels(c, f, voxel_size=0.02, tag="x")
+    assert v.offsets.tolist() == [0, 5, 12] and v.offsets.dtype == torch.int32 and v.batch_size == 2
+    assert v.batch_indexed_coordinates.shape == (12, 4) and v.batch_indexed_coordinates[:, 0].tolist() == [0] * 5 + [1] * 7
+    v2 = v.replace(batched_features=torch.zeros(12, 8))
+    assert v2.extra_attributes == {"voxel_size": 0.02, "tag": "x"} and v2.num_channels == 8 and v.num_channels == 4
+    assert torch.equal((v + 1.0).feature_tensor, v.feature_tensor + 1.0) and torch.equal((2 * v).feature_tensor, 2 * v.feature_tensor)
+    h = v.to(dtype=torch.float16)
+    assert h.dtype == torch.float16 and v.dtype == torch.float32
+    assert v.feature_tensor.dtype == torch.float32  # (autocast behaviour is covered by the GPU module test)
+    dup = Voxels([torch.tensor([[1, 1, 1], [2, 2, 2], [1, 1, 1]], dtype=torch.int32)], [torch.arange(6.0).reshape(3, 2)])
+    u = dup.unique()
+    assert len(u) == 2 and u.feature_tensor.tolist() == [[0.0, 1.0], [2.0, 3.0]]  # first occurrence is kept
+    d = v.to_dense()
+    back = Voxels.from_dense(d, target_spatial_sparse_tensor=v)
+    assert back.feature_tensor.shape == (12, 4)
+    assert v[1].feature_tensor.shape == (7, 4) and v.tensor_stride is None
+    v.set_tensor_stride(2)
+    assert v.tensor_stride == (2, 2, 2)
+    with pytest.raises(AssertionError):
+        Voxels(torch.zeros(3, 3, dtype=torch.int32), torch.zeros(3, 2))  # tensor input needs offsets
+    p = Points([torch.rand(10, 3), torch.rand(12, 3)], [torch.rand(10, 2), torch.rand(12, 2)])
+    assert p.to_voxels(0.3).num_channels == 2 and p.voxel_downsample(0.5).batch_size == 2
+
+
+def _attach_oracle_map(vox, ksize=(3, 3, 3)):
+    """CPU plumbing (BASELINE config 0): the kernel map comes from the oracle and is put in the cache, the product's
+    explicit_gemm backend does the arithmetic."""
+    from warpconvnet_amd.nn.functional.sparse_conv import STRIDED_CONV_MODE
+
+    bc = vox.batch_indexed_coordinates.numpy().astype(np.int32)
+    r = okmap.kernel_map(bc, bc, ksize)
+    km = IntSearchResult(torch.from_numpy(r["in_maps"]), torch.from_numpy(r["out_maps"]), torch.from_numpy(r["offsets"]), 13)
+    key = IntSearchCacheKey(ksize, (1, 1, 1), False, False, str(STRIDED_CONV_MODE.STRIDE_ONLY), False, vox.offsets, vox.offsets)
+    vox._extra_attributes["_cache"] = IntSearchCache()
+    vox.cache.put(key, km)
+    return r
+
+
+def test_config0_cpu_explicit_module_vs_oracle():
+    """8k synthetic voxels, SparseConv3d 16 -> 32 k=3, explicit gather-matmul-scatter on PyTorch CPU."""
+    from oracle import conv as oconv
+
+    s = scene_u(8000, 0)
+    feats = torch.randn(len(s), 16)
+    vox = Voxels([torch.from_numpy(s[:, 1:])], [feats])
+    r = _attach_oracle_map(vox)
+    torch.manual_seed(0)
+    conv = SparseConv3d(16, 32, 3)
+    x = vox.replace(batched_features=feats.clone().requires_grad_(True))
+    y = conv(x)
+    assert y.feature_tensor.shape == (len(s), 32) and y.cache is x.cache
+    y.feature_tensor.square().sum().backward()
+    Yr = oconv.forward(feats, conv.weight.detach(), r["in_maps"], r["out_maps"], r["offsets"], len(s), 13) + conv.bias.detach()
+    torch.testing.assert_close(y.feature_tensor.detach(), Yr, rtol=1e-5, atol=1e-5)
+    dXr, dWr = oconv.backward(2 * Yr, feats, conv.weight.detach(), r["in_maps"], r["out_maps"], r["offsets"], 13)
+    torch.testing.assert_close(conv.weight.grad, dWr, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x.batched_features.batched_tensor.grad, dXr, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(conv.bias.grad, (2 * Yr).sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_explicit_backend_matches_golden(golden_dir):
+    from warpconvnet_amd.nn.functional.sparse_conv.detail.explicit import (
+        _explicit_gemm_backward_logic,
+        _explicit_gemm_forward_logic,
+    )
+
+    for name in ("explicit_u2048_16x32_f32.npz", "explicit_stride2_k2_16x32_f32.npz", "explicit_b2_7x13_f32_noiden.npz"):
+        g = np.load(os.path.join(golden_dir, name))
+        iden = None if int(g["identity"]) < 0 else int(g["identity"])
+        km = IntSearchResult(torch.from_numpy(g["in_maps"]), torch.from_numpy(g["out_maps"]), torch.from_numpy(g["offsets"]), iden)
+        X, W, dY = (torch.from_numpy(g[k]) for k in ("X", "W", "dY"))
+        Y = _explicit_gemm_forward_logic(X, W, km, g["out_coords"].shape[0])
+        dX, dW = _explicit_gemm_backward_logic(dY, X, W, km)
+        torch.testing.assert_close(Y, torch.from_numpy(g["Y"]), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dX, torch.from_numpy(g["dX"]), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dW, torch.from_numpy(g["dW"]), rtol=1e-5, atol=1e-4)
+
+
+def test_one_by_one_conv_and_errors():
+    v = Voxels([torch.randint(0, 5, (6, 3), dtype=torch.int32)], [torch.randn(6, 4)])
+    conv = SparseConv3d(4, 8, 1)
+    torch.testing.assert_close(conv(v).feature_tensor, v.feature_tensor @ conv.weight[0] + conv.bias)
+    with pytest.raises(TypeError):
+        conv(torch.zeros(3, 4))
+    with pytest.raises(RuntimeError):  # CPU voxels without a cached map: kernel-map construction is GPU-only
+        SparseConv3d(4, 8, 3)(v)
+    with pytest.raises(NotImplementedError):
+        SparseConv3d(4, 8, 3, generative=True)(v)

@@ -34,5 +34,28 @@ def main(path):
         print(f"| `{short(name)}` | {n} | {t / 1e6:.3f} | {t / n / 1e3:.1f} | {lo / 1e3:.1f} | {hi / 1e3:.1f} | {100 * t / total:.1f} |")
 
 
+
+
+def pmc(path):
+    """Per-kernel average of every collected counter (``--pmc`` runs)."""
+    db = sqlite3.connect(path)
+    rows = db.execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+    agg = {}
+    for k, c, v in rows:
+        a = agg.setdefault((k, c), [0, 0.0])
+        a[0] += 1
+        a[1] += v
+    print(f"# rocprofv3 PMC summary ({path})\n")
+    print("| kernel | counter | dispatches | avg value (KB) | avg MB |")
+    print("|---|---|---:|---:|---:|")
+    for (k, c), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        if t / n < 64:
+            continue
+        print(f"| `{short(k)}` | {c} | {n} | {t / n:.1f} | {t / n / 1024:.2f} |")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "pmc":
+        pmc(sys.argv[1])
+    else:
+        main(sys.argv[1])

@@ -101,12 +101,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int c, float* __restrict__ out) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+// one wavefront per channel: lane l adds partials l, l+64, ... then a fixed butterfly => deterministic
+__global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int c,
+                                                          float* __restrict__ out) {
+  const int ch = blockIdx.x, lane = threadIdx.x;
   float t = 0.f;
-  for (int b = 0; b < nblocks; ++b) t += partial[(int64_t)b * c + ch];
-  out[ch] = t;
+  for (int b = lane; b < nblocks; b += 64) t += partial[(int64_t)b * c + ch];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+  if (lane == 0) out[ch] = t;
 }
 
 // dw[k][ci][co] = sum over pairs of bucket k (ascending) of x[in][ci] * dy[out][co]; one thread per element.
@@ -148,7 +151,7 @@ int conv_gather_gemm_ref(const void* in, const void* w, void* out, const int32_t
   }
 }
 
-constexpr int kColsumBlocks = 1024;
+constexpr int kColsumBlocks = 512;
 
 size_t colsum_workspace(int c) { return (size_t)kColsumBlocks * c * sizeof(float); }
 
@@ -160,8 +163,7 @@ static int launch_colsum(const void* in, int64_t n, int c, float* out, float* pa
                        (const T*)in, n, c, partial);
   else
     hipLaunchKernelGGL((colsum_partial_kernel<T, 1>), dim3(kColsumBlocks), dim3(256), 0, s, (const T*)in, n, c, partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(c, 256)), dim3(256), 0, s, (const float*)partial,
-                     kColsumBlocks, c, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)c), dim3(64), 0, s, (const float*)partial, kColsumBlocks, c, out);
   return launch_status();
 }
 
