@@ -117,8 +117,8 @@ int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int3
 /* deterministic compaction (pairs of one offset ordered by output row).
  * reference: _C.cuhash.postprocess_scatter (cuhash_kernel_map.cu:546-599, order there is racy).
  * pair_capacity = length of in_maps/out_maps; sets WCN_FLAG_PAIR_OVERFLOW in *status if too small. */
-int wcn_kmap_scatter(const int32_t* nbr, int64_t m, int32_t num_offsets, const int32_t* counts,
-                     const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
+int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets,
+                     const int32_t* counts, const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
                      int32_t* status, wcn_stream_t stream);
 /* nbr [m,kp] -> pair_table [K,m]   (the reference layout, cuhash_kernel_map.cu:133) */
 int wcn_kmap_transpose(const int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* pair_table,
@@ -137,10 +137,11 @@ int wcn_kmap_from_csr(const int32_t* in_maps, const int32_t* out_maps, const int
                       wcn_stream_t stream);
 /* permutation of rows sorted by descending mask word 0 (rows with equal neighbourhood pattern become
  * adjacent so a wavefront can skip absent offsets).  reference: _C.gemm.mask_argsort_cuda
- * (mask_data_kernels.cu:187-220, CUB radix sort).  Stable (ties keep ascending row order).
+ * (mask_data_kernels.cu:187-220, CUB radix sort).  Hand-written stable LSD radix sort (ties keep ascending
+ * row order); `num_bits` = number of significant low bits of word 0 (min(K, 32)) bounds the passes.
  * workspace: wcn_mask_argsort_workspace(n) bytes. */
 size_t wcn_mask_argsort_workspace(int64_t n);
-int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int64_t n, int32_t* perm,
+int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int32_t num_bits, int64_t n, int32_t* perm,
                      void* workspace, size_t workspace_bytes, wcn_stream_t stream);
 
 /* ---- sparse convolution GEMMs ------------------------------------------------------------------

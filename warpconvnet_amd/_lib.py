@@ -47,7 +47,7 @@ SIGNATURES = {
     "wcn_kmap_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scatter": (
         c_int,
-        [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "wcn_kmap_transpose": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_reverse": (
@@ -59,7 +59,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
     ),
     "wcn_mask_argsort_workspace": (c_size_t, [c_int64]),
-    "wcn_mask_argsort": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_mask_argsort": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wcn_mfma_gather_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
     "wcn_mfma_wgrad_supported": (c_int, [c_int32, c_int32, c_int32]),
     "wcn_packed_weight_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),

@@ -10,9 +10,6 @@
 // Reference behaviour being replaced (semantics only, nothing copied):
 //   warpconvnet/csrc/cuhash_hash_table.cu:19-262, cuhash_kernel_map.cu:68-134, 508-599,
 //   mask_data_kernels.cu:23-124, 187-220.
-#include <cstring>
-#include <rocprim/rocprim.hpp>
-
 #include "wcn_common.h"
 
 namespace wcn {
@@ -181,54 +178,42 @@ __global__ void kmap_offsets_kernel(const int32_t* __restrict__ totals, int K, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// scatter: deterministic compaction.  One wavefront per 64-row block, one LANE per (row, offset) like the
-// probe kernel, so the neighbour rows are read as contiguous 128-B lines; the rank of a pair inside its
-// bucket is  offsets[k] + scanned count of the block + running count of the wave + ballot popcount.
+// scatter: deterministic compaction.  One thread per output row, one wavefront per 64-row count block; the row's
+// mask says which offsets exist, so only present pairs touch the neighbour table.  Rank of a pair inside its
+// bucket = offsets[k] + scanned count of the block + popcount(ballot & lower lanes): no atomics, order = output row.
 // ------------------------------------------------------------------------------------------------
-template <int LPR>
-__global__ __launch_bounds__(kThreads) void kmap_scatter_kernel(const int32_t* __restrict__ nbr, int64_t m, int K,
-                                                                int kp, int64_t nwb,
+__global__ __launch_bounds__(kThreads) void kmap_scatter_kernel(const int32_t* __restrict__ nbr,
+                                                                const uint32_t* __restrict__ mask, int64_t m, int K,
+                                                                int kp, int mw, int64_t nwb,
                                                                 const int32_t* __restrict__ counts,
                                                                 const int32_t* __restrict__ offsets,
                                                                 int32_t* __restrict__ in_maps,
                                                                 int32_t* __restrict__ out_maps, int64_t pair_capacity,
                                                                 int32_t* __restrict__ status) {
-  constexpr int kRowsPerIter = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int64_t wb = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (wb >= nwb) return;
-  const int sub = lane % LPR, rsel = lane / LPR;
-  // lanes that hold the same offset: bit (r*LPR + sub) for r = 0..kRowsPerIter-1
-  unsigned long long same_k = 0ull, lower_k = 0ull;
-#pragma unroll
-  for (int r = 0; r < kRowsPerIter; ++r) {
-    const unsigned long long bit = 1ull << (r * LPR + sub);
-    same_k |= bit;
-    if (r < rsel) lower_k |= bit;
-  }
-  const int num_chunks = (K + LPR - 1) / LPR;
+  const int64_t row = wb * kCountRows + lane;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int32_t* my = nbr + row * kp;
   bool overflow = false;
-  for (int kc = 0; kc < num_chunks; ++kc) {
-    const int k = kc * LPR + sub;
-    const bool k_real = k < K;
-    int64_t run = 0;
-    if (k_real) run = (int64_t)offsets[k] + counts[(int64_t)k * nwb + wb];
-#pragma unroll 4
-    for (int it = 0; it < 64 / kRowsPerIter; ++it) {
-      const int64_t row = wb * kCountRows + it * kRowsPerIter + rsel;
-      int v = -1;
-      if (row < m && k_real) v = nbr[row * kp + k];
-      const unsigned long long ball = __ballot(v >= 0);
-      if (v >= 0) {
-        const int64_t pos = run + __popcll(ball & lower_k);
+  for (int w = 0; w < mw; ++w) {
+    const uint32_t bits = row < m ? mask[row * mw + w] : 0u;
+    const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;
+    for (int b = 0; b < kend; ++b) {
+      const bool v = (bits >> b) & 1u;
+      const unsigned long long ball = __ballot(v);
+      if (ball == 0ull) continue;  // wave-uniform
+      const int k = w * 32 + b;
+      if (v) {
+        const int64_t pos = (int64_t)offsets[k] + counts[(int64_t)k * nwb + wb] + __popcll(ball & lt);
         if (pos < pair_capacity) {
-          in_maps[pos] = v;
+          in_maps[pos] = my[k];
           out_maps[pos] = (int32_t)row;
         } else {
           overflow = true;
         }
       }
-      run += __popcll(ball & same_k);
     }
   }
   if (overflow) atomicOr(status, (int)WCN_FLAG_PAIR_OVERFLOW);
@@ -277,15 +262,6 @@ __global__ void kmap_pairs_to_table_kernel(const int32_t* __restrict__ in_maps, 
   const int64_t row = by_in ? i : o;
   tbl[row * kp + k] = by_in ? o : i;
   atomicOr(&mask[row * mw + (k >> 5)], 1u << (k & 31));
-}
-
-__global__ void argsort_prepare_kernel(const uint32_t* __restrict__ mask, int mw, int64_t n,
-                                       uint32_t* __restrict__ keys, int32_t* __restrict__ iota) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    keys[i] = mask[i * mw];
-    iota[i] = (int32_t)i;
-  }
 }
 
 static inline int lanes_per_row(int kp) {
@@ -410,25 +386,18 @@ int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int3
   return launch_status();
 }
 
-int wcn_kmap_scatter(const int32_t* nbr, int64_t m, int32_t num_offsets, const int32_t* counts, const int32_t* offsets,
-                     int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status, wcn_stream_t stream) {
+int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets, const int32_t* counts,
+                     const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status,
+                     wcn_stream_t stream) {
   if (m < 0 || num_offsets < 1 || num_offsets > 4096 || pair_capacity < 0 || !status) return WCN_ERROR_INVALID_PARAMETERS;
   if (m == 0) return WCN_SUCCESS;
-  if (!nbr || !counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps))) return WCN_ERROR_INVALID_PARAMETERS;
-  const int K = num_offsets, kp = wcn_kmap_row_pitch(K);
+  if (!nbr || !mask || !counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps)))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  const int K = num_offsets, kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
   const int64_t nwb = wcn_kmap_num_blocks(m);
-  const dim3 grid((unsigned)ceil_div(nwb, kThreads / 64)), block(kThreads);
-  hipStream_t s = (hipStream_t)stream;
-#define WCN_SCATTER(L)                                                                                              \
-  hipLaunchKernelGGL(kmap_scatter_kernel<L>, grid, block, 0, s, nbr, m, K, kp, nwb, counts, offsets, in_maps, out_maps, \
-                     pair_capacity, status)
-  switch (lanes_per_row(kp)) {
-    case 8: WCN_SCATTER(8); break;
-    case 16: WCN_SCATTER(16); break;
-    case 32: WCN_SCATTER(32); break;
-    default: WCN_SCATTER(64); break;
-  }
-#undef WCN_SCATTER
+  hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(nwb, kThreads / 64)), dim3(kThreads), 0,
+                     (hipStream_t)stream, nbr, mask, m, K, kp, mw, nwb, counts, offsets, in_maps, out_maps, pair_capacity,
+                     status);
   return launch_status();
 }
 
@@ -468,43 +437,6 @@ int wcn_kmap_reverse(const int32_t* in_maps, const int32_t* out_maps, const int3
 int wcn_kmap_from_csr(const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets, int32_t num_offsets,
                       int64_t max_pairs, int64_t n_out, int32_t* nbr, uint32_t* mask, wcn_stream_t stream) {
   return pairs_to_table(in_maps, out_maps, offsets, num_offsets, max_pairs, n_out, 0, nbr, mask, (hipStream_t)stream);
-}
-
-static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-static size_t rocprim_sort_bytes(int64_t n) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs_desc((void*)nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                       (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 32u, (hipStream_t)0,
-                                       false);
-  return bytes;
-}
-
-size_t wcn_mask_argsort_workspace(int64_t n) {
-  if (n <= 0) return 256;
-  // keys_in, keys_out, iota + rocPRIM temporary storage
-  return 3 * align256((size_t)n * 4) + align256(rocprim_sort_bytes(n)) + 256;
-}
-
-int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int64_t n, int32_t* perm, void* workspace,
-                     size_t workspace_bytes, wcn_stream_t stream) {
-  if (n < 0 || mask_words < 1) return WCN_ERROR_INVALID_PARAMETERS;
-  if (n == 0) return WCN_SUCCESS;
-  if (!mask || !perm || !workspace || workspace_bytes < wcn_mask_argsort_workspace(n)) return WCN_ERROR_INVALID_PARAMETERS;
-  hipStream_t s = (hipStream_t)stream;
-  char* ws = (char*)workspace;
-  const size_t seg = align256((size_t)n * 4);
-  uint32_t* keys_in = (uint32_t*)ws;
-  uint32_t* keys_out = (uint32_t*)(ws + seg);
-  int32_t* iota = (int32_t*)(ws + 2 * seg);
-  void* tmp = ws + 3 * seg;
-  size_t tmp_bytes = rocprim_sort_bytes(n);
-  hipLaunchKernelGGL(argsort_prepare_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, mask, (int)mask_words, n,
-                     keys_in, iota);
-  hipError_t e = rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, (const uint32_t*)keys_in, keys_out, (const int32_t*)iota,
-                                                perm, (size_t)n, 0u, 32u, s, false);
-  if (e != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
-  return launch_status();
 }
 
 }  // extern "C"

@@ -6,7 +6,8 @@
 // one-cell... H-cell halo (taken from the 26 neighbouring bins) into a dense LDS grid and answers all
 // K probes of its voxels from LDS.  Global traffic becomes streaming bin reads + full-line row writes.
 //
-//   pass 1  bin_insert   voxel -> block slot (CAS on block key), position inside the bin (atomic counter)
+//   pass 1  bin_insert   voxel -> block slot (CAS on block key), position inside the bin (atomic counters; voxels
+//                        within H cells of a block face - the only ones a NEIGHBOUR block can need - go first)
 //   pass 2  bin_assign   dense block id -> slot, bin size
 //   pass 3  bin_scan     exclusive scan of bin sizes
 //   pass 4  bin_scatter  voxels -> binned array {x, y, z, row}
@@ -53,8 +54,15 @@ __device__ __forceinline__ int block_find(const Slot* __restrict__ slots, uint32
   return -1;
 }
 
+// Slot use on this path: key = block key, value = number of BOUNDARY voxels, pad = number of INTERIOR voxels
+// (both zeroed by bin_prepare_kernel).  vox_pos >= 0: boundary position; < 0: ~interior position.
+__global__ void bin_prepare_kernel(uint4* __restrict__ slots, int64_t capacity) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < capacity) slots[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, const int4* __restrict__ coords, int64_t n,
-                                  int32_t* __restrict__ vox_slot, int32_t* __restrict__ vox_pos,
+                                  int hx, int hy, int hz, int32_t* __restrict__ vox_slot, int32_t* __restrict__ vox_pos,
                                   int32_t* __restrict__ blk_slot, int32_t* __restrict__ nblk,
                                   int32_t* __restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,16 +97,19 @@ __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, cons
     return;
   }
   vox_slot[i] = found;
-  vox_pos[i] = atomicAdd(&slots[found].pad, 1);  // pad doubles as the bin counter (zeroed by wcn_hash_prepare)
+  const int lx = c.y & (kBlk - 1), ly = c.z & (kBlk - 1), lz = c.w & (kBlk - 1);
+  const bool boundary = lx < hx || lx >= kBlk - hx || ly < hy || ly >= kBlk - hy || lz < hz || lz >= kBlk - hz;
+  vox_pos[i] = boundary ? atomicAdd(&slots[found].value, 1) : ~atomicAdd(&slots[found].pad, 1);
 }
 
-__global__ void bin_assign_kernel(Slot* __restrict__ slots, const int32_t* __restrict__ blk_slot,
-                                  const int32_t* __restrict__ nblk, int64_t max_blocks, int32_t* __restrict__ blk_cnt) {
+__global__ void bin_assign_kernel(const Slot* __restrict__ slots, const int32_t* __restrict__ blk_slot,
+                                  const int32_t* __restrict__ nblk, int64_t max_blocks, int32_t* __restrict__ blk_cnt,
+                                  int32_t* __restrict__ slot_id) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= max_blocks || id >= *nblk) return;
   const int s = blk_slot[id];
-  blk_cnt[id] = slots[s].pad;
-  slots[s].value = (int32_t)id;
+  blk_cnt[id] = slots[s].value + slots[s].pad;
+  slot_id[s] = (int32_t)id;  // written (and later read) only for occupied slots: no initialisation needed
 }
 
 // single workgroup: exclusive scan of blk_cnt[0..nblk) -> blk_off[0..nblk]
@@ -131,20 +142,24 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const int32_t* __restric
   if (tid == 1023) blk_off[n] = base + incl;
 }
 
-__global__ void bin_scatter_kernel(const Slot* __restrict__ slots, const int4* __restrict__ coords, int64_t n,
-                                   const int32_t* __restrict__ vox_slot, const int32_t* __restrict__ vox_pos,
-                                   const int32_t* __restrict__ blk_off, int4* __restrict__ binned) {
+__global__ void bin_scatter_kernel(const Slot* __restrict__ slots, const int32_t* __restrict__ slot_id,
+                                   const int4* __restrict__ coords, int64_t n, const int32_t* __restrict__ vox_slot,
+                                   const int32_t* __restrict__ vox_pos, const int32_t* __restrict__ blk_off,
+                                   int4* __restrict__ binned) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int s = vox_slot[i];
   if (s < 0) return;
-  const int id = slots[s].value;
+  const int id = slot_id[s];
   const int4 c = coords[i];
-  binned[blk_off[id] + vox_pos[i]] = make_int4(c.y, c.z, c.w, (int)i);
+  const int p = vox_pos[i];
+  const int local = p >= 0 ? p : slots[s].value + ~p;  // boundary voxels first, then the interior ones
+  binned[blk_off[id] + local] = make_int4(c.y, c.z, c.w, (int)i);
 }
 
 template <int LPR>
 __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* __restrict__ slots, uint32_t cmask,
+                                                                    const int32_t* __restrict__ slot_id,
                                                                     const int32_t* __restrict__ blk_slot,
                                                                     const int32_t* __restrict__ nblk,
                                                                     const int32_t* __restrict__ blk_off,
@@ -174,9 +189,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
       if (needed) {
         const int s = block_find(slots, cmask, block_key(b, wrap_blk(bx + ddx), wrap_blk(by + ddy), wrap_blk(bz + ddz)));
         if (s >= 0) {
-          const int nid = slots[s].value;
+          const int nid = slot_id[s];
           beg = blk_off[nid];
-          cnt = blk_off[nid + 1] - beg;
+          // a neighbour block can only contribute its boundary voxels (stored first); the own block is read whole
+          cnt = (tid == 13) ? (blk_off[nid + 1] - beg) : slots[s].value;
         }
       }
       s_nb_beg[tid] = beg;
@@ -243,12 +259,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
 static inline size_t align256b(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct BinWorkspace {
-  int32_t *vox_slot, *vox_pos, *blk_slot, *blk_cnt, *blk_off, *nblk;
+  int32_t *vox_slot, *vox_pos, *blk_slot, *blk_cnt, *blk_off, *nblk, *slot_id;
   int4* binned;
   size_t bytes;
 };
 
-static BinWorkspace carve(void* ws, int64_t n) {
+static BinWorkspace carve(void* ws, int64_t n, int64_t capacity) {
   BinWorkspace w;
   char* p = (char*)ws;
   size_t off = 0;
@@ -260,6 +276,7 @@ static BinWorkspace carve(void* ws, int64_t n) {
   w.blk_cnt = (int32_t*)take((size_t)n * 4);
   w.blk_off = (int32_t*)take((size_t)(n + 1) * 4);
   w.binned = (int4*)take((size_t)n * 16);
+  w.slot_id = (int32_t*)take((size_t)capacity * 4);
   w.bytes = off;
   return w;
 }
@@ -276,7 +293,16 @@ using namespace wcn;
 
 extern "C" {
 
-size_t wcn_kmap_binned_workspace(int64_t n) { return carve(nullptr, n < 0 ? 0 : n).bytes; }
+static int64_t binned_capacity(int64_t n) {
+  int64_t c = 16;
+  while (c < 2 * n) c <<= 1;
+  return c;
+}
+
+size_t wcn_kmap_binned_workspace(int64_t n) {
+  if (n < 0) n = 0;
+  return carve(nullptr, n, binned_capacity(n)).bytes;
+}
 
 int wcn_kmap_binned_supported(const int32_t ksize[3], const int32_t dilation[3]) {
   if (!ksize || !dilation) return 0;
@@ -296,11 +322,11 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
     return WCN_ERROR_INVALID_PARAMETERS;
   if (!wcn_kmap_binned_supported(ksize, dilation)) return WCN_ERROR_PROBLEM_NOT_SUPPORTED;
   if (n == 0) return WCN_SUCCESS;
-  if (capacity < 2 * n && capacity < (1ll << 31)) return WCN_ERROR_INVALID_PARAMETERS;
   if (!coords || !nbr || !mask || !workspace || workspace_bytes < wcn_kmap_binned_workspace(n))
     return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
-  const BinWorkspace w = carve(workspace, n);
+  if (capacity != binned_capacity(n)) return WCN_ERROR_INVALID_PARAMETERS;
+  const BinWorkspace w = carve(workspace, n, capacity);
   const int K = ksize[0] * ksize[1] * ksize[2];
   const int kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
   BinGeom g;
@@ -312,23 +338,24 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   g.gx = kBlk + 2 * g.hx; g.gy = kBlk + 2 * g.hy; g.gz = kBlk + 2 * g.hz;
 
   if (hipMemsetAsync(w.nblk, 0, 256, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
-  int rc = wcn_hash_prepare(slots, capacity, stream);
-  if (rc != WCN_SUCCESS) return rc;
+  hipLaunchKernelGGL(bin_prepare_kernel, dim3((unsigned)ceil_div(capacity, 256)), dim3(256), 0, s, (uint4*)slots, capacity);
   const uint32_t cmask = (uint32_t)(capacity - 1);
   const unsigned gn = (unsigned)ceil_div(n, 256);
-  hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n,
-                     w.vox_slot, w.vox_pos, w.blk_slot, w.nblk, status);
-  hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, (const int32_t*)w.blk_slot,
-                     (const int32_t*)w.nblk, n, w.blk_cnt);
+  hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n, g.hx, g.hy,
+                     g.hz, w.vox_slot, w.vox_pos, w.blk_slot, w.nblk, status);
+  hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, (const Slot*)slots, (const int32_t*)w.blk_slot,
+                     (const int32_t*)w.nblk, n, w.blk_cnt, w.slot_id);
   hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)w.blk_cnt, (const int32_t*)w.nblk,
                      w.blk_off);
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(gn), dim3(256), 0, s, (const Slot*)slots, (const int4*)coords, n,
-                     (const int32_t*)w.vox_slot, (const int32_t*)w.vox_pos, (const int32_t*)w.blk_off, w.binned);
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(gn), dim3(256), 0, s, (const Slot*)slots, (const int32_t*)w.slot_id,
+                     (const int4*)coords, n, (const int32_t*)w.vox_slot, (const int32_t*)w.vox_pos,
+                     (const int32_t*)w.blk_off, w.binned);
   const size_t shm = (size_t)g.gx * g.gy * g.gz * 4 + 64 * 4;
   const int64_t want = n / 64 + 1;  // never more workgroups than could have work
   const dim3 grid((unsigned)(want < 4096 ? want : 4096)), block(kBinThreads);
 #define WCN_BIN_NB(L)                                                                                                  \
-  hipLaunchKernelGGL(bin_neighbors_kernel<L>, grid, block, shm, s, (const Slot*)slots, cmask, (const int32_t*)w.blk_slot, \
+  hipLaunchKernelGGL(bin_neighbors_kernel<L>, grid, block, shm, s, (const Slot*)slots, cmask,                            \
+                     (const int32_t*)w.slot_id, (const int32_t*)w.blk_slot,                                               \
                      (const int32_t*)w.nblk, (const int32_t*)w.blk_off, (const int4*)w.binned, g, K, kp, mw, nbr, mask)
   switch (lanes_per_row_b(kp)) {
     case 8: WCN_BIN_NB(8); break;

@@ -51,7 +51,7 @@ def nbr_to_pair_table(nbr: Tensor, num_offsets: int) -> Tensor:
 
 
 @torch.no_grad()
-def mask_argsort(mask: Tensor) -> Tensor:
+def mask_argsort(mask: Tensor, num_offsets: int = 32) -> Tensor:
     """Rows sorted by descending neighbour mask (word 0), stable."""
     n, mw = mask.shape
     perm = torch.empty(n, dtype=torch.int32, device=mask.device)
@@ -61,7 +61,8 @@ def mask_argsort(mask: Tensor) -> Tensor:
     ws_bytes = L.wcn_mask_argsort_workspace(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mask.device)
     _lib.check(
-        L.wcn_mask_argsort(_lib.ptr(mask), mw, n, _lib.ptr(perm), _lib.ptr(ws), ws_bytes, _lib.stream_handle(mask.device)),
+        L.wcn_mask_argsort(_lib.ptr(mask), mw, min(int(num_offsets), 32), n, _lib.ptr(perm), _lib.ptr(ws), ws_bytes,
+                           _lib.stream_handle(mask.device)),
         "wcn_mask_argsort",
     )
     return perm
@@ -89,7 +90,7 @@ def attach_tables_from_csr(kmap: IntSearchResult, num_in: int, num_out: int) -> 
         "wcn_kmap_from_csr",
     )
     kmap._nbr, kmap._mask, kmap._offsets_dev = nbr, mask, offsets_dev
-    kmap._perm = mask_argsort(mask)
+    kmap._perm = mask_argsort(mask, K)
     kmap._num_in, kmap._num_out = num_in, num_out
     return kmap
 
@@ -115,7 +116,7 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
                                _lib.stream_handle(dev)),
             "wcn_kmap_reverse",
         )
-        kmap._rev = (rev_nbr, rev_mask, mask_argsort(rev_mask))
+        kmap._rev = (rev_nbr, rev_mask, mask_argsort(rev_mask, K))
     return kmap._rev
 
 
@@ -216,11 +217,11 @@ def generate_kernel_map(
     in_maps = torch.empty(num_pairs, dtype=torch.int32, device=dev)
     out_maps = torch.empty(num_pairs, dtype=torch.int32, device=dev)
     _lib.check(
-        L.wcn_kmap_scatter(_lib.ptr(nbr), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
+        L.wcn_kmap_scatter(_lib.ptr(nbr), _lib.ptr(mask), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
                            _lib.ptr(out_maps), num_pairs, _lib.ptr(meta[K + 1 :]), stream),
         "wcn_kmap_scatter",
     )
-    perm = mask_argsort(mask)
+    perm = mask_argsort(mask, K)
 
     odd = all(k % 2 == 1 for k in ksize)
     identity = K // 2 if (odd and unit_stride and N == M) else None
