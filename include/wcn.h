@@ -152,7 +152,7 @@ int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int32_t num_bits,
  * _C.mask_gemm.fwd/.dgrad/.wgrad (bindings/mask_gemm_bindings.cu:2071-2123).
  *
  * `algo`: 1 = hip_ref (any channel count / dtype), 2 = hip_mfma (bf16/f16; forward/dgrad: Cin%16==0,
- * Cout in {32,64,96,128,256}, K<=32; wgrad: Cin%64==0, Cout%64==0; WCN_ERROR_UNSUPPORTED_CONFIG
+ * Cout in {32,64,96,128,192,256}, K<=32; wgrad: Cin%32==0, Cout%32==0; WCN_ERROR_UNSUPPORTED_CONFIG
  * otherwise).  0 (auto) is resolved by the caller with wcn_mfma_*_supported because the two algorithms
  * take different weight images.  Accumulation is always fp32.
  */

@@ -288,6 +288,7 @@ static int dispatch_co(int cout, const void* in, const void* wp, void* out, cons
     case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
     case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
     case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
     case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
@@ -304,7 +305,7 @@ bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
   if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
   if (K < 1 || K > kMaxKp) return false;
   if (mfma_chunk_for(cin) == 0) return false;
-  return cout == 32 || cout == 64 || cout == 96 || cout == 128 || cout == 256;
+  return cout == 32 || cout == 64 || cout == 96 || cout == 128 || cout == 192 || cout == 256;
 }
 
 template <typename T>

@@ -79,11 +79,12 @@ struct Wgrad {
   static constexpr int STAGE_BYTES = XT_BYTES + YT_BYTES;
   static constexpr int X_UNITS = XT_BYTES / 1024, Y_UNITS = YT_BYTES / 1024;  // 1 KiB per wave-instruction
   static constexpr int DATA_OPS = (X_UNITS + Y_UNITS) / 4;                    // DMA instructions per wave per stage
-  static constexpr int MB = CIT / 64;   // 32x32 blocks per wave along ci (wave owns CIT/2 rows)
-  static constexpr int NBK = COT / 64;  // ... along co
+  static constexpr int MBLK = CIT / 32, NBLK = COT / 32;  // 32x32 MFMA blocks of the tile
+  static constexpr int BLOCKS = MBLK * NBLK;
+  static constexpr int PER_WAVE = (BLOCKS + 3) / 4;       // block j of wave w is w + 4*j (round robin)
   static constexpr int IDX_BYTES = kIdxSlots * 2 * kPairs * 4;
   static constexpr size_t LDS_BYTES = (size_t)kStages * STAGE_BYTES + IDX_BYTES;
-  static_assert(CIT % 64 == 0 && COT % 64 == 0, "tile must be a multiple of 64 channels");
+  static_assert(CIT % 32 == 0 && COT % 32 == 0, "tile must be a multiple of 32 channels");
   static_assert(X_UNITS % 4 == 0 && Y_UNITS % 4 == 0, "every wave must issue the same number of DMA instructions");
 };
 
@@ -131,7 +132,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_idx = smem + (size_t)kStages * W::STAGE_BYTES;  // [kIdxSlots][2][64] int32
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   const int G = gridDim.x, g = blockIdx.x;
   const int tiles_co = cout / COT;
   const int ci0 = (blockIdx.y / tiles_co) * CIT, co0 = (blockIdx.y % tiles_co) * COT;
@@ -153,28 +153,29 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
     k = lo;
   }
 
-  f32x16 acc[W::MB][W::NBK];
+  f32x16 acc[W::PER_WAVE];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int a = 0; a < W::MB; ++a)
+    for (int j = 0; j < W::PER_WAVE; ++j)
 #pragma unroll
-      for (int b = 0; b < W::NBK; ++b)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
   };
   auto flush = [&](int kk) {
     float* slab = slabs + (int64_t)(g + kk) * cin * cout;
     const int h = lane >> 5, n = lane & 31;
 #pragma unroll
-    for (int a = 0; a < W::MB; ++a)
-#pragma unroll
-      for (int b = 0; b < W::NBK; ++b)
+    for (int j = 0; j < W::PER_WAVE; ++j) {
+      const int blk = wave + 4 * j;
+      if (blk < W::BLOCKS) {
+        const int a = blk / W::NBLK, b = blk % W::NBLK;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int ci = ci0 + wm * (CIT / 2) + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-          const int co = co0 + wn * (COT / 2) + b * 32 + n;
-          slab[(int64_t)ci * cout + co] = acc[a][b][q];
+          const int ci = ci0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          const int co = co0 + b * 32 + n;
+          slab[(int64_t)ci * cout + co] = acc[j][q];
         }
+      }
+    }
   };
 
   // A: indices of step `st` -> index ring.  Wave w moves rows [16w, 16w+16) of in_maps and of out_maps.
@@ -222,15 +223,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
     const char* yt = xt + W::XT_BYTES;
 #pragma unroll
     for (int ks = 0; ks < kPairs / 16; ++ks) {
-      s16x8 af[W::MB], bf[W::NBK];
 #pragma unroll
-      for (int a = 0; a < W::MB; ++a) af[a] = read_frag_tr<W::CHX>(xt, ks * 16, wm * (CIT / 2) + a * 32, lane);
-#pragma unroll
-      for (int b = 0; b < W::NBK; ++b) bf[b] = read_frag_tr<W::CHY>(yt, ks * 16, wn * (COT / 2) + b * 32, lane);
-#pragma unroll
-      for (int a = 0; a < W::MB; ++a)
-#pragma unroll
-        for (int b = 0; b < W::NBK; ++b) acc[a][b] = WFrag<T>::mfma(af[a], bf[b], acc[a][b]);
+      for (int j = 0; j < W::PER_WAVE; ++j) {
+        const int blk = wave + 4 * j;
+        if (blk < W::BLOCKS) {  // wave-uniform
+          const s16x8 af = read_frag_tr<W::CHX>(xt, ks * 16, (blk / W::NBLK) * 32, lane);
+          const s16x8 bf = read_frag_tr<W::CHY>(yt, ks * 16, (blk % W::NBLK) * 32, lane);
+          acc[j] = WFrag<T>::mfma(af, bf, acc[j]);
+        }
+      }
     }
   };
   auto barrier = [&]() {
@@ -299,9 +300,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (part == 0 && e < ce) dw[(int64_t)k * ce + e] = (s_part[0][el] + s_part[1][el]) + (s_part[2][el] + s_part[3][el]);
 }
 
+static int wgrad_tile(int c) {  // largest supported tile dividing the channel count
+  if (c % 128 == 0) return 128;
+  if (c % 96 == 0) return 96;
+  if (c % 64 == 0) return 64;
+  if (c % 32 == 0) return 32;
+  return 0;
+}
+
 bool mfma_wgrad_supported(int cin, int cout, int dtype) {
   if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
-  return cin % 64 == 0 && cout % 64 == 0;
+  return wgrad_tile(cin) != 0 && wgrad_tile(cout) != 0;
 }
 
 size_t wgrad_mfma_workspace(int K, int cin, int cout) {
@@ -332,16 +341,28 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
   return launch_status();
 }
 
+template <typename T, int CIT>
+static int dispatch_wgrad_co(int cot, const void* x, const void* dy, float* dw, const int32_t* in_maps,
+                             const int32_t* out_maps, const int32_t* offsets, int cin, int cout, int K, void* workspace,
+                             hipStream_t s) {
+  switch (cot) {
+    case 32: return launch_wgrad<T, CIT, 32>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    case 64: return launch_wgrad<T, CIT, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    case 96: return launch_wgrad<T, CIT, 96>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    default: return launch_wgrad<T, CIT, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+  }
+}
+
 template <typename T>
 static int dispatch_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                           const int32_t* offsets, int cin, int cout, int K, void* workspace, hipStream_t s) {
-  // tile = largest of {128, 64} dividing each dimension
-  const int cit = (cin % 128 == 0) ? 128 : 64;
-  const int cot = (cout % 128 == 0) ? 128 : 64;
-  if (cit == 64 && cot == 64) return launch_wgrad<T, 64, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-  if (cit == 64 && cot == 128) return launch_wgrad<T, 64, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-  if (cit == 128 && cot == 64) return launch_wgrad<T, 128, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-  return launch_wgrad<T, 128, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+  const int cot = wgrad_tile(cout);
+  switch (wgrad_tile(cin)) {
+    case 32: return dispatch_wgrad_co<T, 32>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    case 64: return dispatch_wgrad_co<T, 64>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    case 96: return dispatch_wgrad_co<T, 96>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    default: return dispatch_wgrad_co<T, 128>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+  }
 }
 
 int conv_wgrad_mfma(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
