@@ -6,9 +6,10 @@
 // one-cell... H-cell halo (taken from the 26 neighbouring bins) into a dense LDS grid and answers all
 // K probes of its voxels from LDS.  Global traffic becomes streaming bin reads + full-line row writes.
 //
-//   pass 1  bin_insert   voxel -> block slot (CAS on block key), position inside the bin (atomic counters; voxels
-//                        within H cells of a block face - the only ones a NEIGHBOUR block can need - go first)
-//   pass 2  bin_assign   dense block id -> slot, bin size
+//   pass 1a bin_insert   voxel -> block slot (CAS on the block key only on first touch), dense block ids
+//   pass 1b bin_count    position inside the bin: 4 sub-counters per class (same-address atomics serialise); voxels
+//                        within H cells of a block face - the only ones a NEIGHBOUR block can need - go first
+//   pass 2  bin_assign   bin size / boundary count per block
 //   pass 3  bin_scan     exclusive scan of bin sizes
 //   pass 4  bin_scatter  voxels -> binned array {x, y, z, row}
 //   pass 5  bin_neighbors  per block: LDS grid of (16+2H)^3 row ids (atomicMin => duplicates keep the smallest
@@ -54,16 +55,21 @@ __device__ __forceinline__ int block_find(const Slot* __restrict__ slots, uint32
   return -1;
 }
 
-// Slot use on this path: key = block key, value = number of BOUNDARY voxels, pad = number of INTERIOR voxels
-// (both zeroed by bin_prepare_kernel).  vox_pos >= 0: boundary position; < 0: ~interior position.
+// Slot use on this path: key = block key, value / pad unused (zeroed).  Bin sizes live in cnt[id][8]:
+// 4 sub-counters for BOUNDARY voxels then 4 for INTERIOR voxels.  Same-address atomics serialise (~280 ns each,
+// ~455 voxels per 16^3 block on the uniform scene), so spreading a block's voxels over 4 counters per class cuts the
+// critical path 4x; the sub-counter is chosen by the voxel's row index.
+constexpr int kSub = 4;
+
 __global__ void bin_prepare_kernel(uint4* __restrict__ slots, int64_t capacity) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < capacity) slots[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// pass 1a: create the block entries (CAS only on first touch; everybody else just reads) and remember the slot
 __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, const int4* __restrict__ coords, int64_t n,
-                                  int hx, int hy, int hz, int32_t* __restrict__ vox_slot, int32_t* __restrict__ vox_pos,
-                                  int32_t* __restrict__ blk_slot, int32_t* __restrict__ nblk,
+                                  int32_t* __restrict__ vox_slot, int32_t* __restrict__ blk_slot,
+                                  int32_t* __restrict__ slot_id, int32_t* __restrict__ nblk,
                                   int32_t* __restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -84,6 +90,7 @@ __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, cons
       if (cur == 0ull) {  // this thread created the block: give it a dense id
         const int id = atomicAdd(nblk, 1);
         blk_slot[id] = (int)s;
+        slot_id[s] = id;  // read by the NEXT kernels only
         found = (int)s;
         break;
       }
@@ -91,25 +98,44 @@ __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, cons
     if (cur == key) { found = (int)s; break; }
     s = (s + 1) & cmask;
   }
-  if (found < 0) {
-    atomicOr(status, (int)WCN_FLAG_TABLE_FULL);
-    vox_slot[i] = -1;
-    return;
-  }
+  if (found < 0) atomicOr(status, (int)WCN_FLAG_TABLE_FULL);
   vox_slot[i] = found;
-  const int lx = c.y & (kBlk - 1), ly = c.z & (kBlk - 1), lz = c.w & (kBlk - 1);
-  const bool boundary = lx < hx || lx >= kBlk - hx || ly < hy || ly >= kBlk - hy || lz < hz || lz >= kBlk - hz;
-  vox_pos[i] = boundary ? atomicAdd(&slots[found].value, 1) : ~atomicAdd(&slots[found].pad, 1);
 }
 
-__global__ void bin_assign_kernel(const Slot* __restrict__ slots, const int32_t* __restrict__ blk_slot,
-                                  const int32_t* __restrict__ nblk, int64_t max_blocks, int32_t* __restrict__ blk_cnt,
-                                  int32_t* __restrict__ slot_id) {
+// pass 1b: position of every voxel inside its (block, class, sub-counter) group.
+// vox_pos = (class * kSub + sub) << 24 | position  (a 16^3 block holds at most 4096 distinct voxels, duplicates are
+// bounded by n < 2^24 per sub-counter in practice; larger counts set the overflow flag)
+__global__ void bin_count_kernel(const int4* __restrict__ coords, int64_t n, int hx, int hy, int hz,
+                                 const int32_t* __restrict__ vox_slot, const int32_t* __restrict__ slot_id,
+                                 int32_t* __restrict__ cnt, int32_t* __restrict__ vox_pos,
+                                 int32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = vox_slot[i];
+  if (s < 0) return;
+  const int4 c = coords[i];
+  const int lx = c.y & (kBlk - 1), ly = c.z & (kBlk - 1), lz = c.w & (kBlk - 1);
+  const bool boundary = lx < hx || lx >= kBlk - hx || ly < hy || ly >= kBlk - hy || lz < hz || lz >= kBlk - hz;
+  const int group = (boundary ? 0 : kSub) + (int)(i & (kSub - 1));
+  const int pos = atomicAdd(&cnt[(int64_t)slot_id[s] * (2 * kSub) + group], 1);
+  if (pos >= (1 << 24)) atomicOr(status, (int)WCN_FLAG_TABLE_FULL);
+  vox_pos[i] = (group << 24) | (pos & 0xFFFFFF);
+}
+
+// pass 2: bin size and boundary count per block
+__global__ void bin_assign_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ nblk, int64_t max_blocks,
+                                  int32_t* __restrict__ blk_cnt, int32_t* __restrict__ blk_bnd) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= max_blocks || id >= *nblk) return;
-  const int s = blk_slot[id];
-  blk_cnt[id] = slots[s].value + slots[s].pad;
-  slot_id[s] = (int32_t)id;  // written (and later read) only for occupied slots: no initialisation needed
+  const int32_t* c = cnt + id * (2 * kSub);
+  int bnd = 0, tot = 0;
+#pragma unroll
+  for (int g = 0; g < 2 * kSub; ++g) {
+    tot += c[g];
+    if (g < kSub) bnd += c[g];
+  }
+  blk_cnt[id] = tot;
+  blk_bnd[id] = bnd;
 }
 
 // single workgroup: exclusive scan of blk_cnt[0..nblk) -> blk_off[0..nblk]
@@ -142,7 +168,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const int32_t* __restric
   if (tid == 1023) blk_off[n] = base + incl;
 }
 
-__global__ void bin_scatter_kernel(const Slot* __restrict__ slots, const int32_t* __restrict__ slot_id,
+__global__ void bin_scatter_kernel(const int32_t* __restrict__ slot_id, const int32_t* __restrict__ cnt,
                                    const int4* __restrict__ coords, int64_t n, const int32_t* __restrict__ vox_slot,
                                    const int32_t* __restrict__ vox_pos, const int32_t* __restrict__ blk_off,
                                    int4* __restrict__ binned) {
@@ -153,13 +179,19 @@ __global__ void bin_scatter_kernel(const Slot* __restrict__ slots, const int32_t
   const int id = slot_id[s];
   const int4 c = coords[i];
   const int p = vox_pos[i];
-  const int local = p >= 0 ? p : slots[s].value + ~p;  // boundary voxels first, then the interior ones
+  const int group = p >> 24;
+  int local = p & 0xFFFFFF;  // groups are laid out in order: boundary sub-bins 0..3, then interior sub-bins 0..3
+  const int32_t* cc = cnt + (int64_t)id * (2 * kSub);
+#pragma unroll
+  for (int g = 0; g < 2 * kSub; ++g)
+    if (g < group) local += cc[g];
   binned[blk_off[id] + local] = make_int4(c.y, c.z, c.w, (int)i);
 }
 
 template <int LPR>
 __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* __restrict__ slots, uint32_t cmask,
                                                                     const int32_t* __restrict__ slot_id,
+                                                                    const int32_t* __restrict__ blk_bnd,
                                                                     const int32_t* __restrict__ blk_slot,
                                                                     const int32_t* __restrict__ nblk,
                                                                     const int32_t* __restrict__ blk_off,
@@ -192,7 +224,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
           const int nid = slot_id[s];
           beg = blk_off[nid];
           // a neighbour block can only contribute its boundary voxels (stored first); the own block is read whole
-          cnt = (tid == 13) ? (blk_off[nid + 1] - beg) : slots[s].value;
+          cnt = (tid == 13) ? (blk_off[nid + 1] - beg) : blk_bnd[nid];
         }
       }
       s_nb_beg[tid] = beg;
@@ -259,7 +291,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
 static inline size_t align256b(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct BinWorkspace {
-  int32_t *vox_slot, *vox_pos, *blk_slot, *blk_cnt, *blk_off, *nblk, *slot_id;
+  int32_t *vox_slot, *vox_pos, *blk_slot, *blk_cnt, *blk_bnd, *blk_off, *nblk, *slot_id, *cnt;
   int4* binned;
   size_t bytes;
 };
@@ -274,6 +306,8 @@ static BinWorkspace carve(void* ws, int64_t n, int64_t capacity) {
   w.vox_pos = (int32_t*)take((size_t)n * 4);
   w.blk_slot = (int32_t*)take((size_t)n * 4);
   w.blk_cnt = (int32_t*)take((size_t)n * 4);
+  w.blk_bnd = (int32_t*)take((size_t)n * 4);
+  w.cnt = (int32_t*)take((size_t)n * 2 * kSub * 4);
   w.blk_off = (int32_t*)take((size_t)(n + 1) * 4);
   w.binned = (int4*)take((size_t)n * 16);
   w.slot_id = (int32_t*)take((size_t)capacity * 4);
@@ -341,13 +375,18 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   hipLaunchKernelGGL(bin_prepare_kernel, dim3((unsigned)ceil_div(capacity, 256)), dim3(256), 0, s, (uint4*)slots, capacity);
   const uint32_t cmask = (uint32_t)(capacity - 1);
   const unsigned gn = (unsigned)ceil_div(n, 256);
-  hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n, g.hx, g.hy,
-                     g.hz, w.vox_slot, w.vox_pos, w.blk_slot, w.nblk, status);
-  hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, (const Slot*)slots, (const int32_t*)w.blk_slot,
-                     (const int32_t*)w.nblk, n, w.blk_cnt, w.slot_id);
+  hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n, w.vox_slot,
+                     w.blk_slot, w.slot_id, w.nblk, status);
+  // counters of the blocks that exist: cnt[nblk][8]; nblk is only known on the device, so clear the worst case lazily:
+  // a block has at least one voxel, hence nblk <= n and the first n*8 ints cover every id
+  if (hipMemsetAsync(w.cnt, 0, (size_t)n * 2 * kSub * 4, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
+  hipLaunchKernelGGL(bin_count_kernel, dim3(gn), dim3(256), 0, s, (const int4*)coords, n, g.hx, g.hy, g.hz,
+                     (const int32_t*)w.vox_slot, (const int32_t*)w.slot_id, w.cnt, w.vox_pos, status);
+  hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, (const int32_t*)w.cnt, (const int32_t*)w.nblk, n,
+                     w.blk_cnt, w.blk_bnd);
   hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)w.blk_cnt, (const int32_t*)w.nblk,
                      w.blk_off);
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(gn), dim3(256), 0, s, (const Slot*)slots, (const int32_t*)w.slot_id,
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(gn), dim3(256), 0, s, (const int32_t*)w.slot_id, (const int32_t*)w.cnt,
                      (const int4*)coords, n, (const int32_t*)w.vox_slot, (const int32_t*)w.vox_pos,
                      (const int32_t*)w.blk_off, w.binned);
   const size_t shm = (size_t)g.gx * g.gy * g.gz * 4 + 64 * 4;
@@ -355,7 +394,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   const dim3 grid((unsigned)(want < 4096 ? want : 4096)), block(kBinThreads);
 #define WCN_BIN_NB(L)                                                                                                  \
   hipLaunchKernelGGL(bin_neighbors_kernel<L>, grid, block, shm, s, (const Slot*)slots, cmask,                            \
-                     (const int32_t*)w.slot_id, (const int32_t*)w.blk_slot,                                               \
+                     (const int32_t*)w.slot_id, (const int32_t*)w.blk_bnd, (const int32_t*)w.blk_slot,                   \
                      (const int32_t*)w.nblk, (const int32_t*)w.blk_off, (const int4*)w.binned, g, K, kp, mw, nbr, mask)
   switch (lanes_per_row_b(kp)) {
     case 8: WCN_BIN_NB(8); break;

@@ -81,7 +81,11 @@ struct Wgrad {
   static constexpr int DATA_OPS = (X_UNITS + Y_UNITS) / 4;                    // DMA instructions per wave per stage
   static constexpr int MBLK = CIT / 32, NBLK = COT / 32;  // 32x32 MFMA blocks of the tile
   static constexpr int BLOCKS = MBLK * NBLK;
-  static constexpr int PER_WAVE = (BLOCKS + 3) / 4;       // block j of wave w is w + 4*j (round robin)
+  // wave layout: 2 x 2 grid of sub-tiles when both block counts are even (operand fragments are shared across the
+  // wave's blocks: MB + NB transpose-reads feed MB * NB MFMAs); otherwise blocks go round robin (w, w+4, ...)
+  static constexpr bool GRID = (MBLK % 2 == 0) && (NBLK % 2 == 0);
+  static constexpr int MB = GRID ? MBLK / 2 : 1, NB = GRID ? NBLK / 2 : 1;
+  static constexpr int PER_WAVE = GRID ? MB * NB : (BLOCKS + 3) / 4;
   static constexpr int IDX_BYTES = kIdxSlots * 2 * kPairs * 4;
   static constexpr size_t LDS_BYTES = (size_t)kStages * STAGE_BYTES + IDX_BYTES;
   static_assert(CIT % 32 == 0 && COT % 32 == 0, "tile must be a multiple of 32 channels");
@@ -165,7 +169,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
     const int h = lane >> 5, n = lane & 31;
 #pragma unroll
     for (int j = 0; j < W::PER_WAVE; ++j) {
-      const int blk = wave + 4 * j;
+      const int blk = W::GRID ? ((wave >> 1) * W::MB + j / W::NB) * W::NBLK + (wave & 1) * W::NB + j % W::NB
+                              : wave + 4 * j;
       if (blk < W::BLOCKS) {
         const int a = blk / W::NBLK, b = blk % W::NBLK;
 #pragma unroll
@@ -223,13 +228,25 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
     const char* yt = xt + W::XT_BYTES;
 #pragma unroll
     for (int ks = 0; ks < kPairs / 16; ++ks) {
+      if constexpr (W::GRID) {
+        s16x8 af[W::MB], bf[W::NB];
 #pragma unroll
-      for (int j = 0; j < W::PER_WAVE; ++j) {
-        const int blk = wave + 4 * j;
-        if (blk < W::BLOCKS) {  // wave-uniform
-          const s16x8 af = read_frag_tr<W::CHX>(xt, ks * 16, (blk / W::NBLK) * 32, lane);
-          const s16x8 bf = read_frag_tr<W::CHY>(yt, ks * 16, (blk % W::NBLK) * 32, lane);
-          acc[j] = WFrag<T>::mfma(af, bf, acc[j]);
+        for (int a = 0; a < W::MB; ++a) af[a] = read_frag_tr<W::CHX>(xt, ks * 16, ((wave >> 1) * W::MB + a) * 32, lane);
+#pragma unroll
+        for (int b = 0; b < W::NB; ++b) bf[b] = read_frag_tr<W::CHY>(yt, ks * 16, ((wave & 1) * W::NB + b) * 32, lane);
+#pragma unroll
+        for (int a = 0; a < W::MB; ++a)
+#pragma unroll
+          for (int b = 0; b < W::NB; ++b) acc[a * W::NB + b] = WFrag<T>::mfma(af[a], bf[b], acc[a * W::NB + b]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < W::PER_WAVE; ++j) {
+          const int blk = wave + 4 * j;
+          if (blk < W::BLOCKS) {  // wave-uniform
+            const s16x8 af = read_frag_tr<W::CHX>(xt, ks * 16, (blk / W::NBLK) * 32, lane);
+            const s16x8 bf = read_frag_tr<W::CHY>(yt, ks * 16, (blk % W::NBLK) * 32, lane);
+            acc[j] = WFrag<T>::mfma(af, bf, acc[j]);
+          }
         }
       }
     }
