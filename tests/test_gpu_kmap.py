@@ -107,7 +107,7 @@ def test_binned_edge_cases(kmap_method):
     assert r["found"][22, i_hi] == i_lo  # k = 22 is offset (+1, 0, 0)
     bad = s.copy(); bad[3, 2] = 131072
     with pytest.raises(ValueError):
-        _gen(bad, bad, (3, 3, 3), same=True)
+        _gen(bad, bad, (3, 3, 3), same=True).offsets  # (.offsets: also covers the lazy WARPCONVNET_AMD_ASYNC_KMAP=1 mode)
 
 
 def test_dilation_and_2d(kmap_method):

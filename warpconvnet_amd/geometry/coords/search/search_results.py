@@ -49,6 +49,13 @@ class RealSearchResult:
 
 
 class IntSearchResult:
+    """CSR-by-offset kernel map.  ``in_maps`` / ``out_maps`` / ``offsets`` may be *pending*: the builder launches every
+    kernel asynchronously, scatters the pairs into worst-case sized buffers and copies ``offsets`` + status flags to
+    pinned host memory behind an event; the first access of one of those attributes (or of ``len(in_maps)``) waits for
+    the event, validates the flags and narrows the buffers.  The HIP GEMMs never need the host copy (they read the
+    device offsets), so the hot path has no host synchronisation at all; ``poll()`` raises a pending error as soon
+    as the event has completed without ever blocking."""
+
     def __init__(
         self,
         in_maps: Tensor,
@@ -60,10 +67,15 @@ class IntSearchResult:
         assert len(in_maps) == len(out_maps) == int(offsets_cpu[-1]), (
             f"in_maps ({len(in_maps)}), out_maps ({len(out_maps)}) and offsets[-1] ({int(offsets_cpu[-1])}) disagree"
         )
-        self.in_maps = in_maps
-        self.out_maps = out_maps
-        self.offsets = offsets_cpu
+        self._in_maps = in_maps
+        self._out_maps = out_maps
+        self._offsets = offsets_cpu
+        self._pending = None
+        self._num_offsets = len(offsets_cpu) - 1
         self.identity_map_index = identity_map_index
+        self._init_tables()
+
+    def _init_tables(self):
         # build-specific device tables (see module docstring)
         self._nbr: Optional[Tensor] = None
         self._mask: Optional[Tensor] = None
@@ -75,6 +87,60 @@ class IntSearchResult:
         self._num_out: Optional[int] = None
         self._pair_table_cache: Optional[Tensor] = None
 
+    @classmethod
+    def _from_pending(cls, in_full: Tensor, out_full: Tensor, meta_host: Tensor, event, num_offsets: int,
+                      identity_map_index: Optional[int], on_flags) -> "IntSearchResult":
+        """Builder hook: buffers of worst-case length + pinned ``meta_host`` = offsets[K+1] ++ [flags], ready at ``event``."""
+        self = object.__new__(cls)
+        self._in_maps, self._out_maps, self._offsets = in_full, out_full, None
+        self._pending = (meta_host, event, on_flags)
+        self._num_offsets = num_offsets
+        self.identity_map_index = identity_map_index
+        self._init_tables()
+        return self
+
+    def _materialize(self):
+        if self._pending is None:
+            return
+        meta_host, event, on_flags = self._pending
+        event.synchronize()
+        self._pending = None
+        K = self._num_offsets
+        on_flags(int(meta_host[K + 1]))
+        self._offsets = meta_host[: K + 1].clone()
+        n = int(self._offsets[-1])
+        self._in_maps = self._in_maps[:n]
+        self._out_maps = self._out_maps[:n]
+
+    def poll(self):
+        """Non-blocking: if the pending host copy has arrived, validate its status flags (raises on error)."""
+        if self._pending is not None and self._pending[1].query():
+            self._materialize()
+
+    @property
+    def in_maps(self) -> Tensor:
+        self._materialize()
+        return self._in_maps
+
+    @property
+    def out_maps(self) -> Tensor:
+        self._materialize()
+        return self._out_maps
+
+    @property
+    def offsets(self) -> Tensor:
+        self._materialize()
+        return self._offsets
+
+    @property
+    def in_maps_device(self) -> Tensor:
+        """Pair buffer without forcing the host copy (may be longer than the number of pairs)."""
+        return self._in_maps
+
+    @property
+    def out_maps_device(self) -> Tensor:
+        return self._out_maps
+
     # ---- reference container API --------------------------------------------------------
     @torch.no_grad()
     def __getitem__(self, idx: int) -> Tuple[Tensor, Tensor]:
@@ -82,7 +148,7 @@ class IntSearchResult:
         return self.in_maps[start:end], self.out_maps[start:end]
 
     def __len__(self) -> int:
-        return len(self.offsets) - 1
+        return self._num_offsets
 
     def __iter__(self):
         for i in range(len(self)):
@@ -96,7 +162,7 @@ class IntSearchResult:
 
     @property
     def device(self):
-        return self.in_maps.device
+        return self._in_maps.device
 
     @torch.no_grad()
     def get_batch(self, start_idx: int, end_idx: int, out_format: Literal["list", "tensor"] = "list"):

@@ -77,16 +77,16 @@ def attach_tables_from_csr(kmap: IntSearchResult, num_in: int, num_out: int) -> 
     """
     if kmap._nbr is not None:
         return kmap
-    dev = kmap.in_maps.device
+    dev = kmap.in_maps_device.device
     K = len(kmap)
     L = _lib.lib()
     kp, mw = L.wcn_kmap_row_pitch(K), L.wcn_kmap_mask_words(K)
     nbr = torch.empty((num_out, kp), dtype=torch.int32, device=dev)
     mask = torch.empty((num_out, mw), dtype=torch.int32, device=dev)
-    offsets_dev = kmap.offsets.to(device=dev, dtype=torch.int32)
+    offsets_dev = kmap._offsets_dev if kmap._offsets_dev is not None else kmap.offsets.to(device=dev, dtype=torch.int32)
     _lib.check(
-        L.wcn_kmap_from_csr(_lib.ptr(kmap.in_maps), _lib.ptr(kmap.out_maps), _lib.ptr(offsets_dev), K,
-                            kmap.in_maps.shape[0], num_out, _lib.ptr(nbr), _lib.ptr(mask), _lib.stream_handle(dev)),
+        L.wcn_kmap_from_csr(_lib.ptr(kmap.in_maps_device), _lib.ptr(kmap.out_maps_device), _lib.ptr(offsets_dev), K,
+                            kmap.in_maps_device.shape[0], num_out, _lib.ptr(nbr), _lib.ptr(mask), _lib.stream_handle(dev)),
         "wcn_kmap_from_csr",
     )
     kmap._nbr, kmap._mask, kmap._offsets_dev = nbr, mask, offsets_dev
@@ -102,7 +102,7 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
     Role of `_build_reverse_mask_data` (`mask_gemm.py:279-350`).
     """
     if kmap._rev is None:
-        dev = kmap.in_maps.device
+        dev = kmap.in_maps_device.device
         K = len(kmap)
         L = _lib.lib()
         kp, mw = L.wcn_kmap_row_pitch(K), L.wcn_kmap_mask_words(K)
@@ -111,8 +111,8 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
         if kmap._offsets_dev is None:
             kmap._offsets_dev = kmap.offsets.to(device=dev, dtype=torch.int32)
         _lib.check(
-            L.wcn_kmap_reverse(_lib.ptr(kmap.in_maps), _lib.ptr(kmap.out_maps), _lib.ptr(kmap._offsets_dev), K,
-                               kmap.in_maps.shape[0], num_in, _lib.ptr(rev_nbr), _lib.ptr(rev_mask),
+            L.wcn_kmap_reverse(_lib.ptr(kmap.in_maps_device), _lib.ptr(kmap.out_maps_device), _lib.ptr(kmap._offsets_dev), K,
+                               kmap.in_maps_device.shape[0], num_in, _lib.ptr(rev_nbr), _lib.ptr(rev_mask),
                                _lib.stream_handle(dev)),
             "wcn_kmap_reverse",
         )
@@ -210,22 +210,42 @@ def generate_kernel_map(
         )
     _lib.check(L.wcn_kmap_count(_lib.ptr(mask), M, K, _lib.ptr(block_counts), stream), "wcn_kmap_count")
     _lib.check(L.wcn_kmap_scan(_lib.ptr(block_counts), nblk, K, _lib.ptr(meta), stream), "wcn_kmap_scan")
-    meta_host = meta.cpu()  # the single host sync of the build
-    PackedHashTable.raise_for_flags(int(meta_host[K + 1]), N, _next_power_of_2(max(16, 2 * N)))
-    offsets_host = meta_host[: K + 1].clone()
-    num_pairs = int(offsets_host[-1])
-    in_maps = torch.empty(num_pairs, dtype=torch.int32, device=dev)
-    out_maps = torch.empty(num_pairs, dtype=torch.int32, device=dev)
-    _lib.check(
-        L.wcn_kmap_scatter(_lib.ptr(nbr), _lib.ptr(mask), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
-                           _lib.ptr(out_maps), num_pairs, _lib.ptr(meta[K + 1 :]), stream),
-        "wcn_kmap_scatter",
-    )
+    table_capacity = _next_power_of_2(max(16, 2 * N))
+    # offsets + status flags start travelling to pinned host memory now; the mask argsort does not depend on the pair
+    # count and keeps the GPU busy during the host round trip
+    meta_host = torch.empty(K + 2, dtype=torch.int32, pin_memory=True)
+    meta_host.copy_(meta, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record(torch.cuda.current_stream(dev))
     perm = mask_argsort(mask, K)
 
     odd = all(k % 2 == 1 for k in ksize)
     identity = K // 2 if (odd and unit_stride and N == M) else None
-    result = IntSearchResult(in_maps, out_maps, offsets_host, identity_map_index=identity)
+    # WARPCONVNET_AMD_ASYNC_KMAP=1 (opt-in): never wait - pairs go to worst-case sized buffers and offsets / flags are
+    # validated lazily (IntSearchResult.poll / first host access).  Default: wait for the copy here, raise range /
+    # capacity errors at build time like the reference, allocate exact-size pair buffers.
+    async_ok = os.environ.get("WARPCONVNET_AMD_ASYNC_KMAP", "0") in ("1", "true") and K * M * 8 <= (1 << 29)
+    if async_ok:
+        pair_capacity = K * M
+        offsets_host = None
+    else:
+        event.synchronize()
+        PackedHashTable.raise_for_flags(int(meta_host[K + 1]), N, table_capacity)
+        offsets_host = meta_host[: K + 1].clone()
+        pair_capacity = int(offsets_host[-1])
+    in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
+    out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
+    _lib.check(
+        L.wcn_kmap_scatter(_lib.ptr(nbr), _lib.ptr(mask), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
+                           _lib.ptr(out_maps), pair_capacity, _lib.ptr(meta[K + 1 :]), stream),
+        "wcn_kmap_scatter",
+    )
+    if async_ok:
+        result = IntSearchResult._from_pending(
+            in_maps, out_maps, meta_host, event, K, identity,
+            lambda flags, n=N, c=table_capacity: PackedHashTable.raise_for_flags(flags, n, c))
+    else:
+        result = IntSearchResult(in_maps, out_maps, offsets_host, identity_map_index=identity)
     result._nbr, result._mask, result._perm = nbr, mask, perm
     result._offsets_dev = meta[: K + 1]
     result._symmetric = bool(same_tensor and odd and unit_stride)

@@ -94,6 +94,7 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
         raise RuntimeError(f"hip forward error: {_lib.status_string(-6)} ({x.dtype} vs {w.dtype})")
     K, cin, cout = w.shape
     assert K == len(kernel_map) and cin == x.shape[1]
+    kernel_map.poll()
     attach_tables_from_csr(kernel_map, x.shape[0], num_out_coords)
     code = resolve_gather_algo(algo, cin, cout, K, x.dtype)
     return _gather_gemm(x, w, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K, code,
@@ -123,6 +124,7 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
     if dy.dtype != w.dtype:
         raise RuntimeError(f"hip dgrad error: {_lib.status_string(-6)} ({dy.dtype} vs {w.dtype})")
     K, cin, cout = w.shape
+    kernel_map.poll()
     attach_tables_from_csr(kernel_map, num_in_coords, dy.shape[0])
     if kernel_map._symmetric:
         tbl, mask, perm, flip = kernel_map._nbr, kernel_map._mask, kernel_map._perm, True
@@ -140,6 +142,7 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
         raise RuntimeError(f"hip wgrad error: {_lib.status_string(-6)} ({x.dtype} vs {dy.dtype})")
     K, cin, cout = weight_shape
     dev = x.device
+    kernel_map.poll()
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
     if kernel_map._offsets_dev is None:
         kernel_map._offsets_dev = kernel_map.offsets.to(device=dev, dtype=torch.int32)
@@ -148,8 +151,8 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
     ws_bytes = L.wcn_conv_wgrad_workspace(K, cin, cout, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _lib.check(
-        L.wcn_conv_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(kernel_map.in_maps),
-                         _lib.ptr(kernel_map.out_maps), _lib.ptr(kernel_map._offsets_dev), x.shape[0], dy.shape[0], cin,
+        L.wcn_conv_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(kernel_map.in_maps_device),
+                         _lib.ptr(kernel_map.out_maps_device), _lib.ptr(kernel_map._offsets_dev), x.shape[0], dy.shape[0], cin,
                          cout, K, _lib.dtype_code(x.dtype), code, _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)),
         "wcn_conv_wgrad",
     )

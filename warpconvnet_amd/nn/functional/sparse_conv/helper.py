@@ -36,7 +36,9 @@ class STRIDED_CONV_MODE(Enum):
 
 def _swap(kernel_map: IntSearchResult) -> IntSearchResult:
     """Transposed convolution uses the forward map with in/out exchanged (reference helper.py:487-497)."""
-    return IntSearchResult(in_maps=kernel_map.out_maps, out_maps=kernel_map.in_maps, offsets=kernel_map.offsets)
+    swapped = IntSearchResult(in_maps=kernel_map.out_maps, out_maps=kernel_map.in_maps, offsets=kernel_map.offsets)
+    swapped._offsets_dev = kernel_map._offsets_dev
+    return swapped
 
 
 def _cpu_kernel_map(in_coords: Tensor, out_coords: Tensor, stride, kernel_size, kernel_dilation) -> IntSearchResult:
