@@ -27,6 +27,7 @@ constexpr int kBlkShift = 4;
 constexpr int kBlk = 1 << kBlkShift;  // 16 cells per axis
 constexpr int kMaxHalo = 4;
 constexpr int kBinThreads = 256;
+constexpr int kOwnChunk = 512;  // own-bin entries staged in LDS per pass
 constexpr int kBlkCoordBits = kCoordBits - kBlkShift;  // 14-bit signed block coordinates
 
 struct BinGeom {
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
   const int cells = g.gx * g.gy * g.gz;
   int* s_nb_beg = reinterpret_cast<int*>(s_grid + cells);  // [27] first entry of neighbour bin
   int* s_nb_pre = s_nb_beg + 27;                            // [28] prefix of neighbour bin sizes
+  int4* s_own = reinterpret_cast<int4*>(s_grid + ((cells + 64 + 3) & ~3));  // [kOwnChunk] staged own entries (16-B aligned)
   const int tid = threadIdx.x, lane = tid & 63;
   const int nblocks = *nblk;
   constexpr int kVoxPerIter = kBinThreads / LPR;
@@ -237,52 +239,74 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
       for (int q = 0; q < 27; ++q) s_nb_pre[q + 1] += s_nb_pre[q];
     }
     __syncthreads();
-    // ---- fill the grid from the 27 bins ----
+    // ---- fill the grid from the 27 bins (4 independent loads in flight per thread) ----
     const int total = s_nb_pre[27];
-    for (int e = tid; e < total; e += kBinThreads) {
-      int q = 0;
+    for (int e0 = tid; e0 < total; e0 += 4 * kBinThreads) {
+      int4 v[4];
+      int qq[4];
 #pragma unroll
-      for (int t = 1; t < 27; ++t) q += (e >= s_nb_pre[t]);
-      const int4 v = binned[s_nb_beg[q] + (e - s_nb_pre[q])];
-      const int ddx = q / 9 - 1, ddy = (q / 3) % 3 - 1, ddz = q % 3 - 1;
-      const int lx = (v.x & (kBlk - 1)) + kBlk * ddx + g.hx;
-      const int ly = (v.y & (kBlk - 1)) + kBlk * ddy + g.hy;
-      const int lz = (v.z & (kBlk - 1)) + kBlk * ddz + g.hz;
-      if (lx >= 0 && lx < g.gx && ly >= 0 && ly < g.gy && lz >= 0 && lz < g.gz)
-        atomicMin(&s_grid[(lx * g.gy + ly) * g.gz + lz], (unsigned int)v.w);
-    }
-    __syncthreads();
-    // ---- answer the K probes of the block's own voxels: one lane per (voxel, offset) ----
-    const int own_beg = s_nb_beg[13], own_cnt = s_nb_pre[14] - s_nb_pre[13];
-    const int num_chunks = (kp + LPR - 1) / LPR;
-    for (int kc = 0; kc < num_chunks; ++kc) {
-      const int k = kc * LPR + sub;
-      const bool k_real = k < K, k_store = k < kp;
-      const int l = k % g.kz, j = (k / g.kz) % g.ky, i = k / (g.kz * g.ky);
-      const int ox = (i - g.cx) * g.dx, oy = (j - g.cy) * g.dy, oz = (l - g.cz) * g.dz;
-      for (int e0 = 0; e0 < own_cnt; e0 += kVoxPerIter) {
-        const int e = e0 + vsel;
-        int found = -1;
-        int row = -1;
-        if (e < own_cnt) {
-          const int4 v = binned[own_beg + e];
-          row = v.w;
-          if (k_real) {
-            const int lx = (v.x & (kBlk - 1)) + g.hx + ox, ly = (v.y & (kBlk - 1)) + g.hy + oy,
-                      lz = (v.z & (kBlk - 1)) + g.hz + oz;
-            found = (int)s_grid[(lx * g.gy + ly) * g.gz + lz];  // 0xFFFFFFFF -> -1
-          }
-          if (k_store) nbr[(int64_t)row * kp + k] = found;
-        }
-        const unsigned long long ball = __ballot(found >= 0);
-        if (row >= 0 && sub == 0) {
-          const int lsel = lane / LPR;  // voxel slot inside this wavefront
-          const unsigned long long bits = (LPR == 64) ? ball : ((ball >> (lsel * LPR)) & ((1ull << (LPR & 63)) - 1ull));
-          const int w0 = (kc * LPR) >> 5;
-          if (w0 < mw) mask[(int64_t)row * mw + w0] = (uint32_t)bits;
-          if (LPR == 64 && w0 + 1 < mw) mask[(int64_t)row * mw + w0 + 1] = (uint32_t)(bits >> 32);
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * kBinThreads;
+        qq[u] = -1;
+        if (e < total) {
+          int q = 0;
+#pragma unroll
+          for (int t = 1; t < 27; ++t) q += (e >= s_nb_pre[t]);
+          qq[u] = q;
+          v[u] = binned[s_nb_beg[q] + (e - s_nb_pre[q])];
         }
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = qq[u];
+        if (q < 0) continue;
+        const int ddx = q / 9 - 1, ddy = (q / 3) % 3 - 1, ddz = q % 3 - 1;
+        const int lx = (v[u].x & (kBlk - 1)) + kBlk * ddx + g.hx;
+        const int ly = (v[u].y & (kBlk - 1)) + kBlk * ddy + g.hy;
+        const int lz = (v[u].z & (kBlk - 1)) + kBlk * ddz + g.hz;
+        if (lx >= 0 && lx < g.gx && ly >= 0 && ly < g.gy && lz >= 0 && lz < g.gz)
+          atomicMin(&s_grid[(lx * g.gy + ly) * g.gz + lz], (unsigned int)v[u].w);
+      }
+    }
+    __syncthreads();
+    // ---- answer the K probes of the block's own voxels: one lane per (voxel, offset).  The block's own entries are
+    //      staged through LDS in chunks (coalesced, upfront) so the probe loop itself has no global loads. ----
+    const int own_beg = s_nb_beg[13], own_cnt = s_nb_pre[14] - s_nb_pre[13];
+    const int num_chunks = (kp + LPR - 1) / LPR;
+    for (int c0 = 0; c0 < own_cnt; c0 += kOwnChunk) {
+      const int cn = (own_cnt - c0) < kOwnChunk ? (own_cnt - c0) : kOwnChunk;
+      for (int e = tid; e < cn; e += kBinThreads) s_own[e] = binned[own_beg + c0 + e];
+      __syncthreads();
+      for (int kc = 0; kc < num_chunks; ++kc) {
+        const int k = kc * LPR + sub;
+        const bool k_real = k < K, k_store = k < kp;
+        const int l = k % g.kz, j = (k / g.kz) % g.ky, i = k / (g.kz * g.ky);
+        const int ox = (i - g.cx) * g.dx, oy = (j - g.cy) * g.dy, oz = (l - g.cz) * g.dz;
+        for (int e0 = 0; e0 < cn; e0 += kVoxPerIter) {
+          const int e = e0 + vsel;
+          int found = -1;
+          int row = -1;
+          if (e < cn) {
+            const int4 v = s_own[e];
+            row = v.w;
+            if (k_real) {
+              const int lx = (v.x & (kBlk - 1)) + g.hx + ox, ly = (v.y & (kBlk - 1)) + g.hy + oy,
+                        lz = (v.z & (kBlk - 1)) + g.hz + oz;
+              found = (int)s_grid[(lx * g.gy + ly) * g.gz + lz];  // 0xFFFFFFFF -> -1
+            }
+            if (k_store) nbr[(int64_t)row * kp + k] = found;
+          }
+          const unsigned long long ball = __ballot(found >= 0);
+          if (row >= 0 && sub == 0) {
+            const int lsel = lane / LPR;  // voxel slot inside this wavefront
+            const unsigned long long bits = (LPR == 64) ? ball : ((ball >> (lsel * LPR)) & ((1ull << (LPR & 63)) - 1ull));
+            const int w0 = (kc * LPR) >> 5;
+            if (w0 < mw) mask[(int64_t)row * mw + w0] = (uint32_t)bits;
+            if (LPR == 64 && w0 + 1 < mw) mask[(int64_t)row * mw + w0 + 1] = (uint32_t)(bits >> 32);
+          }
+        }
+      }
+      __syncthreads();  // s_own is refilled by the next chunk
     }
     __syncthreads();  // grid is reused by the next block
   }
@@ -389,7 +413,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(gn), dim3(256), 0, s, (const int32_t*)w.slot_id, (const int32_t*)w.cnt,
                      (const int4*)coords, n, (const int32_t*)w.vox_slot, (const int32_t*)w.vox_pos,
                      (const int32_t*)w.blk_off, w.binned);
-  const size_t shm = (size_t)g.gx * g.gy * g.gz * 4 + 64 * 4;
+  const size_t shm = (((size_t)g.gx * g.gy * g.gz + 64 + 3) & ~(size_t)3) * 4 + (size_t)kOwnChunk * 16;
   const int64_t want = n / 64 + 1;  // never more workgroups than could have work
   const dim3 grid((unsigned)(want < 4096 ? want : 4096)), block(kBinThreads);
 #define WCN_BIN_NB(L)                                                                                                  \
