@@ -10,10 +10,16 @@
 //     holding CO/2 contiguous output channels of one output row, stored with 16-B writes.
 //   * weights: the [CIC x CO] slab of the current (offset, channel-chunk) step is streamed into LDS by
 //     LDS-DMA (global_load_lds, 16 B/lane) in exactly the order the A fragments are read back
-//     (lane-linear => conflict-free ds_read_b128), double buffered, one barrier per step.
+//     (lane-linear => conflict-free ds_read_b128), double buffered, one barrier per step.  The DMA goes through
+//     inline asm and the per-step drain through the s_waitcnt BUILTIN: with the DMA builtin hipcc drains vmcnt(0)
+//     in front of the first LDS read of every step (i.e. in front of the MFMAs), and with an asm s_waitcnt its own
+//     scoreboard still believes the gathered registers are in flight and waits again - either way gather latency
+//     and math serialise.
 //   * the tile's neighbour rows (TILE x 32 int32) are staged in LDS once ("index slab").
 //   * offsets absent from every row of the workgroup are skipped (bitmask OR), and a wave skips the
 //     gather + MFMA of an offset none of its own rows has.
+//   * epilogue: + bias in fp32, round, transpose 32 rows at a time through a wave-private LDS stage and write whole
+//     rows with adjacent lanes (full-line writes instead of 8 partial-line write requests per 128 B).
 //
 // Math: out[r] = sum_k in[nbr[r][k]] . Wp[k]  (fp32 accumulate), Wp = packed image of w (forward),
 // or of w^T with k reversed (dgrad of a submanifold map), or of w^T (dgrad with a reverse table).
@@ -43,6 +49,18 @@ template <> struct Frag<_Float16> {
 
 constexpr int kWaves = 4;
 constexpr int kMaxKp = 32;  // fast path covers kernel volumes up to 32 (one mask word)
+
+#ifdef WCN_PROF
+// dev-only phase stamps (wall clock, 10 ns ticks): [wg][8] = {entry, after perm, after slab, loop end, end, steps}
+__device__ unsigned long long g_prof[8192 * 8];
+__device__ unsigned long long g_prof2[8192 * 4];  // per-WG sums (wave 0): issue, compute, vmcnt wait, barrier (clocks)
+#define WCN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_prof[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define WCN_STAMPV(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_prof[blockIdx.x * 8 + (i)] = (v); } while (0)
+#else
+#define WCN_STAMP(i)
+#define WCN_STAMPV(i, v)
+#endif
+
 
 // ---- weight packing --------------------------------------------------------------------------------
 // packed[k][chunk][b][s][lane][j], lane = (h<<5)|m:
@@ -109,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
   const int nchunk = cin / CIC;
   const int64_t row0 = (int64_t)blockIdx.x * TILE;
 
+  WCN_STAMP(0);
   // ---- stage output row ids, neighbour slab and masks ----
   uint32_t my_mask = 0;
   if (tid < TILE) {
@@ -120,14 +139,35 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
     if (r >= 0) my_mask = mask[r];
   }
   __syncthreads();
+  WCN_STAMP(1);
   {
+    // all row ids first, then all table loads, then all LDS writes: written as one loop, every s_rows read is ordered
+    // behind the previous s_nbr write (same LDS array) and the global round trips serialise
     const int vec_per_row = kp >> 2;
-    for (int e = tid; e < TILE * vec_per_row; e += 256) {
+    constexpr int kIter = TILE * (kMaxKp / 4) / 256;
+    int32_t rr[kIter];
+    int4 vv[kIter];
+#pragma unroll
+    for (int t = 0; t < kIter; ++t) {
+      const int e = tid + t * 256;
+      rr[t] = (e < TILE * vec_per_row) ? s_rows[e / vec_per_row] : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < kIter; ++t) {
+      const int e = tid + t * 256;
       const int i = e / vec_per_row, c = e - i * vec_per_row;
-      const int32_t r = s_rows[i];
-      int4 v = make_int4(-1, -1, -1, -1);
-      if (r >= 0) v = reinterpret_cast<const int4*>(nbr + (int64_t)r * kp)[c];
-      reinterpret_cast<int4*>(s_nbr + i * kp)[c] = v;
+      vv[t] = make_int4(-1, -1, -1, -1);
+      if (rr[t] >= 0) {  // read once: non-temporal
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * kp) + c);
+        vv[t] = make_int4(q.x, q.y, q.z, q.w);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kIter; ++t) {
+      const int e = tid + t * 256;
+      const int i = e / vec_per_row, c = e - i * vec_per_row;
+      if (e < TILE * vec_per_row) reinterpret_cast<int4*>(s_nbr + i * kp)[c] = vv[t];
     }
   }
   // OR-reduce masks: rows of wave w are [w*RPW, (w+1)*RPW)
@@ -137,6 +177,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
   __syncthreads();
   const uint32_t wave_mask = s_wmask[wave];
   const uint32_t block_mask = s_wmask[0] | s_wmask[1] | s_wmask[2] | s_wmask[3];
+  WCN_STAMP(2);
+  WCN_STAMPV(5, (unsigned long long)__builtin_popcount(block_mask));
 
   f32x16 acc[NB][RB];
 #pragma unroll
@@ -155,14 +197,13 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
       for (int it = 0; it < (G::DMA_UNITS + kWaves - 1) / kWaves; ++it) {
         const int u = it * kWaves + wave;  // wave-uniform 1-KiB unit
         if (u < G::DMA_UNITS)
-          __builtin_amdgcn_global_load_lds(
-              (const void __attribute__((address_space(1)))*)(reinterpret_cast<const char*>(src) + u * 1024 + lane * 16),
-              (void __attribute__((address_space(3)))*)(dst + u * 1024), 16, 0, 0);
+          glds16(reinterpret_cast<const char*>(src) + u * 1024 + lane * 16,
+                 __builtin_amdgcn_readfirstlane(lds_addr_of(dst + u * 1024)));
       }
     };
     // LDS-DMA completion is tracked by vmcnt; drain it explicitly before every barrier.
     auto sync_step = [&]() {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), gfx9 encoding; also resets hipcc's own load scoreboard
       __syncthreads();
     };
     auto gather = [&](frag_t (&bf)[RB][NS], int k, int chunk) {
@@ -185,14 +226,23 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
     auto compute = [&](const frag_t (&bf)[RB][NS], int buf, int k) {
       if (!((wave_mask >> k) & 1u)) return;
       const frag_t* wl = reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(s_w) + (size_t)buf * G::SLAB_BYTES);
+      // the NB weight fragments of channel slice s+1 are read from LDS while the NB*RB MFMAs of slice s run
+      frag_t a_cur[NB], a_nxt[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) a_cur[b] = wl[(b * NS) * 64 + lane];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) a_nxt[b] = wl[(b * NS + s + 1) * 64 + lane];
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const frag_t a = wl[(b * NS + s) * 64 + lane];
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) acc[b][rb] = Frag<T>::mfma(a, bf[rb][s], acc[b][rb]);
+          for (int rb = 0; rb < RB; ++rb) acc[b][rb] = Frag<T>::mfma(a_cur[b], bf[rb][s], acc[b][rb]);
         }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) a_cur[b] = a_nxt[b];
       }
     };
     // step iterator over (set bits of block_mask ascending) x (channel chunks)
@@ -231,12 +281,21 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
     }
   }
 
-  // ---- epilogue: lane (h, n) holds out channels h*CO/2 + 16*b + q of row (rb, n) ----
+  WCN_STAMP(3);
+  // ---- epilogue: lane (h, n) holds out channels h*CO/2 + 16*b + q of row (rb, n).  Storing that straight to HBM
+  // makes every lane write 16-B pieces of its own row (8 partial-line write requests per 128-B line); instead each
+  // wave transposes 32 rows at a time through its own LDS stage and writes whole rows with adjacent lanes. ----
+  constexpr int kPitch = CO * 2 + 16;               // bytes; +16 keeps the b128 stage writes conflict-free
+  constexpr int kStage = 32 * kPitch;               // one 32-row block per wave
+  constexpr bool kStaged = (size_t)kWaves * kStage <= 2 * (size_t)G::SLAB_BYTES + (size_t)TILE * kMaxKp * 4;
+  if (kStaged) __syncthreads();  // the weight / index slabs are dead from here on: reuse them as the stage
+  char* stage = smem + wave * kStage;
+  constexpr int kLanesPerRow = CO / 8;              // 16-B pieces per output row
+  constexpr int kRowsPerInstr = 64 / kLanesPerRow;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int i = wave * RPW + rb * 32 + n;
     const int32_t r = s_rows[i];
-    if (r < 0) continue;
     T* dst = out + (int64_t)r * CO + h * (CO / 2);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -255,10 +314,35 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
         lo[q] = (T)acc[b][rb][q];
         hi[q] = (T)acc[b][rb][8 + q];
       }
-      *reinterpret_cast<frag_t*>(dst + 16 * b) = lo;
-      *reinterpret_cast<frag_t*>(dst + 16 * b + 8) = hi;
+      if (kStaged) {
+        frag_t* sp = reinterpret_cast<frag_t*>(stage + n * kPitch + (h * (CO / 2) + 16 * b) * 2);
+        sp[0] = lo;
+        sp[1] = hi;
+      } else if (r >= 0) {
+        *reinterpret_cast<frag_t*>(dst + 16 * b) = lo;
+        *reinterpret_cast<frag_t*>(dst + 16 * b + 8) = hi;
+      }
+    }
+    if (kStaged) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // stage is wave-private: LDS ops of one wave execute in order
+      const int piece = lane % kLanesPerRow, rsub = lane / kLanesPerRow;
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += kRowsPerInstr) {
+        const int row = r0 + rsub;
+        if (rsub < kRowsPerInstr && row < 32) {
+          const int32_t rr = s_rows[wave * RPW + rb * 32 + row];
+          if (rr >= 0)  // streamed once: non-temporal, so the output does not push the gathered input out of the caches
+            __builtin_nontemporal_store(*reinterpret_cast<const frag_t*>(stage + row * kPitch + piece * 16),
+                                        reinterpret_cast<frag_t*>(out + (int64_t)rr * CO + piece * 8));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // next block overwrites the stage
     }
   }
+#ifdef WCN_PROF
+  wait_vmcnt<0>();
+  WCN_STAMP(4);
+#endif
 }
 
 template <typename T, int CIC, int CO, int RB>
@@ -338,4 +422,15 @@ int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int tra
   return launch_status();
 }
 
+#ifdef WCN_PROF
 }  // namespace wcn
+extern "C" int wcn_debug_read_prof2(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wcn::g_prof2), bytes);
+}
+extern "C" int wcn_debug_read_prof(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wcn::g_prof), bytes);
+}
+namespace wcn {
+#endif
+}  // namespace wcn
+

@@ -60,6 +60,33 @@ __device__ __forceinline__ int slot_lookup(const Slot* __restrict__ slots, uint3
   return -1;
 }
 
+// LDS-DMA issued through inline asm: hipcc neither counts these in its own s_waitcnt bookkeeping nor orders
+// later LDS reads behind them (with the builtin it drains vmcnt(0) before the first ds_read of every step, which
+// serialises the ring).  Completion is tracked by the counted s_waitcnt vmcnt(N) below.  M0 (LDS destination base)
+// is written and restored inside the statement; `lds_addr` must be wave-uniform.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? WCN_SUCCESS : WCN_ERROR_KERNEL_EXECUTION;
