@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const int i = wave * RPW + rb * 32 + n;
-        const int32_t idx = s_nbr[i * kp + k];
+        int32_t idx = s_nbr[i * kp + k];
+#ifdef WCN_ABL_LOCAL
+        if (idx >= 0) idx &= 1023;  // dev ablation: all gathers hit a 128 KB window
+#endif
         const T* p = in + (int64_t)idx * cin + chunk * CIC + h * (CIC / 2);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -256,6 +259,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
       return true;
     };
 
+#ifdef WCN_PROF
+    unsigned long long pq[4] = {0, 0, 0, 0};
+#endif
     frag_t B0[RB][NS], B1[RB][NS];
     int k0 = -1, c0 = 0, k1 = -1, c1 = 0;
     next_step(k0, c0);
@@ -267,9 +273,26 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
       // even half-iteration: compute (k0,c0) from buffer 0 while fetching (k1,c1) into buffer 1
       k1 = k0; c1 = c0;
       const bool has1 = next_step(k1, c1);
+#ifdef WCN_PROF
+      const unsigned long long q0 = clock64();
+#endif
       if (has1) { dma_weights(1, k1, c1); gather(B1, k1, c1); }
+#ifdef WCN_PROF
+      const unsigned long long q1 = clock64();
+#endif
       compute(B0, 0, k0);
-      sync_step();
+#ifdef WCN_PROF
+      const unsigned long long q2 = clock64();
+#endif
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef WCN_PROF
+      const unsigned long long q3 = clock64();
+#endif
+      __syncthreads();
+#ifdef WCN_PROF
+      const unsigned long long q4 = clock64();
+      pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += q4 - q3;
+#endif
       if (!has1) break;
       // odd half-iteration
       k0 = k1; c0 = c1;
@@ -279,6 +302,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
       sync_step();
       more = has0;
     }
+#ifdef WCN_PROF
+    if (tid == 0 && blockIdx.x < 8192)
+      for (int q = 0; q < 4; ++q) g_prof2[blockIdx.x * 4 + q] = 2 * pq[q];  // only even half-steps are timed
+#endif
   }
 
   WCN_STAMP(3);

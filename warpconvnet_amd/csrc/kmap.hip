@@ -190,31 +190,50 @@ __global__ __launch_bounds__(kThreads) void kmap_scatter_kernel(const int32_t* _
                                                                 int32_t* __restrict__ in_maps,
                                                                 int32_t* __restrict__ out_maps, int64_t pair_capacity,
                                                                 int32_t* __restrict__ status) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wb = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  // Per wave: 64 rows.  The rows' neighbour entries are copied into LDS with whole-row (coalesced) 16-B loads first:
+  // reading nbr[row][k] per lane inside the offset loop costs one L1 lookup per lane and offset (~1 lane per clock
+  // per CU), which made this kernel 2x slower than its HBM traffic.  [4 waves][64 rows][32 ints], 16-B chunks
+  // XOR-swizzled by row so the per-lane column reads spread over the banks.
+  __shared__ __attribute__((aligned(16))) int32_t s_tile[(kThreads / 64) * 64 * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wb = (int64_t)blockIdx.x * (kThreads / 64) + wave;
   if (wb >= nwb) return;
-  const int64_t row = wb * kCountRows + lane;
+  const int64_t row0 = wb * kCountRows;
+  const int64_t row = row0 + lane;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const int32_t* my = nbr + row * kp;
+  int32_t* tile = s_tile + wave * 64 * 32;
   bool overflow = false;
   for (int w = 0; w < mw; ++w) {
+    const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;      // offsets in this mask word
+    const int cols4 = ((kp - w * 32) < 32 ? (kp - w * 32) : 32) >> 2;  // 16-B chunks per row in this word
+    for (int e = lane; e < 64 * cols4; e += 64) {
+      const int r = e / cols4, c = e - r * cols4;
+      int4 v = make_int4(-1, -1, -1, -1);
+      if (row0 + r < m) v = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kp + w * 32 + c * 4);
+      *reinterpret_cast<int4*>(tile + r * 32 + ((c ^ (r & 7)) << 2)) = v;
+    }
+    // bucket write positions of this wave for the word's offsets: lane b holds the base of offset w*32+b
+    int64_t base = 0;
+    if (lane < kend) base = (int64_t)offsets[w * 32 + lane] + counts[(int64_t)(w * 32 + lane) * nwb + wb];
     const uint32_t bits = row < m ? mask[row * mw + w] : 0u;
-    const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile is wave-private; LDS ops of a wave execute in order
     for (int b = 0; b < kend; ++b) {
       const bool v = (bits >> b) & 1u;
       const unsigned long long ball = __ballot(v);
       if (ball == 0ull) continue;  // wave-uniform
-      const int k = w * 32 + b;
+      const int32_t lo = __builtin_amdgcn_readlane((int32_t)base, b);
+      const int32_t hi = __builtin_amdgcn_readlane((int32_t)(base >> 32), b);
       if (v) {
-        const int64_t pos = (int64_t)offsets[k] + counts[(int64_t)k * nwb + wb] + __popcll(ball & lt);
+        const int64_t pos = (((int64_t)hi << 32) | (uint32_t)lo) + __popcll(ball & lt);
         if (pos < pair_capacity) {
-          in_maps[pos] = my[k];
+          in_maps[pos] = tile[lane * 32 + (((b >> 2) ^ (lane & 7)) << 2) + (b & 3)];
           out_maps[pos] = (int32_t)row;
         } else {
           overflow = true;
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // next word overwrites the tile
   }
   if (overflow) atomicOr(status, (int)WCN_FLAG_PAIR_OVERFLOW);
 }
