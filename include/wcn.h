@@ -47,7 +47,9 @@ enum wcn_kmap_flag {
   WCN_FLAG_TABLE_FULL = 1,      /* hash insert ran out of slots   (reference hash_table.cuh:60-62)   */
   WCN_FLAG_COORD_RANGE = 2,     /* batch not in [0,511] or coord not in [-131072,131071]
                                    (reference packed_hashmap.py:66-82 raises ValueError)            */
-  WCN_FLAG_PAIR_OVERFLOW = 4    /* in_maps/out_maps capacity smaller than the number of pairs       */
+  WCN_FLAG_PAIR_OVERFLOW = 4,   /* in_maps/out_maps capacity smaller than the number of pairs       */
+  WCN_FLAG_DUPLICATE_COORD = 8  /* informational: the inserted coordinates are not all distinct (the smallest row wins,
+                                   so the centre neighbour of a later duplicate is not the row itself)          */
 };
 
 /* ---- misc ------------------------------------------------------------------------------------ */
@@ -179,6 +181,19 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
                          const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_in,
                          int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
                          int32_t algo, int32_t w_transposed, int32_t k_flip, wcn_stream_t stream);
+
+/* Dgrad + bias gradient in one pass over grad_out.  As wcn_conv_gather_gemm with algo = WCN_ALGO_MFMA, and additionally
+ * colsum_out[c] = sum over rows r of in[r][c] (fp32), taken from the rows the kernel gathers anyway for offset
+ * `self_offset` - the offset whose neighbour of row r is r itself (the centre of an odd submanifold kernel; the caller
+ * guarantees nbr[r][self_offset] == r for every row).  Deterministic (fixed-order partial sums).  Replaces the
+ * autograd reduce of `out + bias` (warpconvnet/nn/functional/sparse_conv/helper.py:339-342) without a second read of
+ * grad_out.  WCN_ERROR_UNSUPPORTED_CONFIG when wcn_mfma_gather_supported is false (use wcn_colsum then). */
+size_t wcn_gather_gemm_colsum_workspace(int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype);
+int wcn_conv_gather_gemm_colsum(const void* in, const void* w_packed, void* out, const int32_t* nbr,
+                                const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_in,
+                                int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
+                                int32_t self_offset, float* colsum_out, void* workspace, size_t workspace_bytes,
+                                wcn_stream_t stream);
 
 /* out[c] = sum_r in[r][c] in fp32 (bias gradient; reference: autograd of `out + bias`, helper.py:339-342).
  * Deterministic two-pass reduction; workspace: wcn_colsum_workspace(channels) bytes. */

@@ -83,6 +83,41 @@ def test_mfma_vs_oracle_submanifold(dtype, cin, cout):
     Y2, dX2, dW2 = _run_all(km, X, W, dY, "hip_ref", len(s), len(s))
     assert rel_max_err(Y2, Yr) < TOL[dtype] and rel_max_err(dX2, dXr) < TOL[dtype] and rel_max_err(dW2, dWr) < 1e-3
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (32, 32), (16, 32), (96, 96), (256, 64)])
+def test_dgrad_fused_bias_grad(dtype, cin, cout):
+    """wcn_conv_gather_gemm_colsum: dgrad unchanged, bias gradient = column sums of grad_output (fp64 oracle sum of the
+    values the GPU saw; fp32 accumulation => 1e-4 relative), deterministic, and NOT offered when coordinates repeat."""
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    s = np.concatenate([scene_u(3000, 31, 0), scene_u(1234, 32, 1)], 0)  # 4234 rows: ragged last tile
+    km = _kmap(s, s, (3, 3, 3), same=True)
+    assert km._symmetric and km._self_exact
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin * 7 + cout)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev, dtype)
+    dY = torch.randn(len(s), cout, generator=g).to(dev, dtype)
+    dX0 = hip_gemm.hip_dgrad(dY, W, km, len(s), "auto")
+    dX1, db = hip_gemm.hip_dgrad(dY, W, km, len(s), "auto", want_colsum=True)
+    from warpconvnet_amd import _lib
+
+    if not _lib.lib().wcn_mfma_gather_supported(cout, cin, 27, _lib.dtype_code(dtype)):
+        assert db is None and torch.equal(dX0, dX1)  # hip_ref dgrad: the caller falls back to wcn_colsum
+        return
+    assert db is not None and db.dtype == torch.float32 and db.shape == (cout,)
+    assert torch.equal(dX0, dX1)
+    want = dY.double().sum(0)
+    assert ((db.double() - want).abs().max() / want.abs().max()).item() < 1e-4
+    _, db2 = hip_gemm.hip_dgrad(dY, W, km, len(s), "auto", want_colsum=True)
+    assert torch.equal(db, db2)
+    assert rel_max_err(db, hip_gemm.hip_colsum(dY)) < 1e-5
+    # duplicate coordinates: the centre neighbour of the later copy is the earlier row -> no fused column sum
+    sd = np.concatenate([s[:2000], s[:17]], 0)
+    kmd = _kmap(sd, sd, (3, 3, 3), same=True)
+    assert kmd._symmetric and not kmd._self_exact
+    _, dbd = hip_gemm.hip_dgrad(dY[: len(sd)].contiguous(), W, kmd, len(sd), "auto", want_colsum=True)
+    assert dbd is None
+
 
 @pytest.mark.parametrize("ksize,stride", [((2, 2, 2), (2, 2, 2)), ((3, 3, 3), (2, 2, 2))])
 def test_mfma_strided_and_transposed(ksize, stride):

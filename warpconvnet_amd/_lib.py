@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_CSRC, "libwcn_hip.so")
 
 WCN_F32, WCN_F16, WCN_BF16 = 0, 1, 2
 WCN_ALGO_AUTO, WCN_ALGO_REF, WCN_ALGO_MFMA = 0, 1, 2
-WCN_FLAG_TABLE_FULL, WCN_FLAG_COORD_RANGE, WCN_FLAG_PAIR_OVERFLOW = 1, 2, 4
+WCN_FLAG_TABLE_FULL, WCN_FLAG_COORD_RANGE, WCN_FLAG_PAIR_OVERFLOW, WCN_FLAG_DUPLICATE_COORD = 1, 2, 4, 8
 
 _I32P = c_void_p  # all pointers travel as void*
 _3I = c_int32 * 3
@@ -71,6 +71,12 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
          c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    ),
+    "wcn_gather_gemm_colsum_workspace": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),
+    "wcn_conv_gather_gemm_colsum": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
+         c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "wcn_colsum_workspace": (c_size_t, [c_int32]),
     "wcn_colsum": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),

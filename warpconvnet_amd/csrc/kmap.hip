@@ -43,6 +43,7 @@ __global__ void hash_insert_kernel(Slot* __restrict__ slots, uint32_t capacity_m
     if (prev == 0ull || prev == key) {
       // unsigned min: the empty marker 0xFFFFFFFF loses against every row index
       atomicMin(reinterpret_cast<unsigned int*>(&slots[s].value), (unsigned int)i);
+      if (prev == key) atomicOr(status, (int)WCN_FLAG_DUPLICATE_COORD);
       return;
     }
     s = (s + 1) & capacity_mask;

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
                                                                     const int32_t* __restrict__ blk_off,
                                                                     const int4* __restrict__ binned, BinGeom g, int K,
                                                                     int kp, int mw, int32_t* __restrict__ nbr,
-                                                                    uint32_t* __restrict__ mask) {
+                                                                    uint32_t* __restrict__ mask,
+                                                                    int32_t* __restrict__ status) {
   extern __shared__ unsigned int s_grid[];  // [gx*gy*gz] row ids, 0xFFFFFFFF = empty; then 27*3 ints of bin info
   const int cells = g.gx * g.gy * g.gz;
   int* s_nb_beg = reinterpret_cast<int*>(s_grid + cells);  // [27] first entry of neighbour bin
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
               const int lx = (v.x & (kBlk - 1)) + g.hx + ox, ly = (v.y & (kBlk - 1)) + g.hy + oy,
                         lz = (v.z & (kBlk - 1)) + g.hz + oz;
               found = (int)s_grid[(lx * g.gy + ly) * g.gz + lz];  // 0xFFFFFFFF -> -1
+              if ((ox | oy | oz) == 0 && found != row) atomicOr(status, (int)WCN_FLAG_DUPLICATE_COORD);
             }
             if (k_store) nbr[(int64_t)row * kp + k] = found;
           }
@@ -419,7 +421,8 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
 #define WCN_BIN_NB(L)                                                                                                  \
   hipLaunchKernelGGL(bin_neighbors_kernel<L>, grid, block, shm, s, (const Slot*)slots, cmask,                            \
                      (const int32_t*)w.slot_id, (const int32_t*)w.blk_bnd, (const int32_t*)w.blk_slot,                   \
-                     (const int32_t*)w.nblk, (const int32_t*)w.blk_off, (const int4*)w.binned, g, K, kp, mw, nbr, mask)
+                     (const int32_t*)w.nblk, (const int32_t*)w.blk_off, (const int4*)w.binned, g, K, kp, mw, nbr, mask,  \
+                     status)
   switch (lanes_per_row_b(kp)) {
     case 8: WCN_BIN_NB(8); break;
     case 16: WCN_BIN_NB(16); break;

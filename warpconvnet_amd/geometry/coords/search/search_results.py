@@ -82,6 +82,7 @@ class IntSearchResult:
         self._perm: Optional[Tensor] = None
         self._offsets_dev: Optional[Tensor] = None
         self._symmetric: bool = False
+        self._self_exact: bool = False  # symmetric AND no duplicate coordinates: nbr[r][K//2] == r for every row
         self._rev: Optional[Tuple[Tensor, Tensor, Tensor]] = None
         self._num_in: Optional[int] = None
         self._num_out: Optional[int] = None

@@ -225,6 +225,7 @@ def generate_kernel_map(
     # validated lazily (IntSearchResult.poll / first host access).  Default: wait for the copy here, raise range /
     # capacity errors at build time like the reference, allocate exact-size pair buffers.
     async_ok = os.environ.get("WARPCONVNET_AMD_ASYNC_KMAP", "0") in ("1", "true") and K * M * 8 <= (1 << 29)
+    has_duplicates = True  # unknown until the flags arrive (async mode): assume the worst
     if async_ok:
         pair_capacity = K * M
         offsets_host = None
@@ -233,6 +234,7 @@ def generate_kernel_map(
         PackedHashTable.raise_for_flags(int(meta_host[K + 1]), N, table_capacity)
         offsets_host = meta_host[: K + 1].clone()
         pair_capacity = int(offsets_host[-1])
+        has_duplicates = bool(int(meta_host[K + 1]) & _lib.WCN_FLAG_DUPLICATE_COORD)
     in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
     out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
     _lib.check(
@@ -249,6 +251,7 @@ def generate_kernel_map(
     result._nbr, result._mask, result._perm = nbr, mask, perm
     result._offsets_dev = meta[: K + 1]
     result._symmetric = bool(same_tensor and odd and unit_stride)
+    result._self_exact = result._symmetric and not has_duplicates
     result._num_in, result._num_out = N, M
     result._hashtable = table
     result._kernel_size = ksize

@@ -48,6 +48,8 @@ class BwdCtx:
     groups: int = 1
     use_fp16_accum: bool = False
     scratch: Optional[Dict[int, Any]] = None
+    want_bias_grad: bool = False        # build extension: the caller would like sum_rows(grad_output) as well
+    bias_grad: Optional[Tensor] = None  # set by a backend that produced it in the same pass (fp32 [Cout])
 
 
 FwdFn = Callable[[FwdCtx], Any]
@@ -85,7 +87,11 @@ def _make_hip_bwd(algo: str) -> BwdFn:
         dy = ctx.grad_output.to(dt)
         dx = dw = None
         if need_dx:
-            dx = hip_gemm.hip_dgrad(dy, ctx.weight.to(dt), ctx.kernel_map, ctx.in_features.shape[0], algo)
+            fuse_db = ctx.want_bias_grad and dy.dtype == ctx.grad_output.dtype  # same values as an unfused column sum
+            dx, db = hip_gemm.hip_dgrad(dy, ctx.weight.to(dt), ctx.kernel_map, ctx.in_features.shape[0], algo,
+                                        want_colsum=True) if fuse_db else (
+                hip_gemm.hip_dgrad(dy, ctx.weight.to(dt), ctx.kernel_map, ctx.in_features.shape[0], algo), None)
+            ctx.bias_grad = db
             dx = dx.to(ctx.in_features.dtype)
         if need_dw:
             dw = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape), algo)

@@ -118,8 +118,13 @@ def hip_colsum(t: Tensor) -> Tensor:
 
 
 def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_in_coords: int,
-              algo: str = "auto") -> Tensor:
-    """dx[n] = sum_k dy[rev[n][k]] @ w[k]^T; a submanifold map reuses the forward table with k reversed."""
+              algo: str = "auto", want_colsum: bool = False):
+    """dx[n] = sum_k dy[rev[n][k]] @ w[k]^T; a submanifold map reuses the forward table with k reversed.
+
+    ``want_colsum``: also return the fp32 column sums of ``grad_output`` (the bias gradient) when the fused kernel can
+    provide them in the same pass (submanifold map without duplicate coordinates, MFMA path); returns
+    ``(dx, colsum_or_None)`` in that mode.
+    """
     dy, w = _prep(grad_output, "grad_output"), _prep(weight, "weight")
     if dy.dtype != w.dtype:
         raise RuntimeError(f"hip dgrad error: {_lib.status_string(-6)} ({dy.dtype} vs {w.dtype})")
@@ -132,7 +137,24 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
         tbl, mask, perm = reverse_tables(kernel_map, num_in_coords)
         flip = False
     code = resolve_gather_algo(algo, cout, cin, K, dy.dtype)
-    return _gather_gemm(dy, w, tbl, mask, perm, num_in_coords, cout, cin, K, code, transposed=True, flip=flip)
+    fuse = (want_colsum and code == _lib.WCN_ALGO_MFMA and getattr(kernel_map, "_self_exact", False)
+            and num_in_coords == dy.shape[0] and num_in_coords > 0)
+    if not fuse:
+        dx = _gather_gemm(dy, w, tbl, mask, perm, num_in_coords, cout, cin, K, code, transposed=True, flip=flip)
+        return (dx, None) if want_colsum else dx
+    L = _lib.lib()
+    dx = torch.empty((num_in_coords, cin), dtype=dy.dtype, device=dy.device)
+    colsum = torch.empty(cout, dtype=torch.float32, device=dy.device)
+    ws_bytes = L.wcn_gather_gemm_colsum_workspace(num_in_coords, cout, cin, K, _lib.dtype_code(dy.dtype))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+    _lib.check(
+        L.wcn_conv_gather_gemm_colsum(
+            _lib.ptr(dy), _lib.ptr(pack_weight(w, True, flip)), _lib.ptr(dx), _lib.ptr(tbl), _lib.ptr(mask), _lib.ptr(perm),
+            None, dy.shape[0], num_in_coords, cout, cin, K, _lib.dtype_code(dy.dtype), K // 2, _lib.ptr(colsum),
+            _lib.ptr(ws), ws_bytes, _lib.stream_handle(dy.device)),
+        "wcn_conv_gather_gemm_colsum",
+    )
+    return dx, colsum
 
 
 def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchResult, weight_shape, algo: str = "auto") -> Tensor:

@@ -91,13 +91,6 @@ class UnifiedSpatiallySparseConvFunction(Function):
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_db = ctx.has_bias and len(ctx.needs_input_grad) > 14 and ctx.needs_input_grad[14]
         grad_in = grad_w = grad_b = None
-        if need_db:
-            if grad_output.is_cuda and grad_output.shape[0] > 0:
-                from .hip_gemm import hip_colsum
-
-                grad_b = hip_colsum(grad_output.contiguous())
-            else:
-                grad_b = grad_output.float().sum(0)
         empty = ctx.num_out_coords == 0 or in_features.shape[0] == 0 or grad_output.shape[1] == 0
         if empty or not (need_dx or need_dw):
             if need_dx:
@@ -107,17 +100,28 @@ class UnifiedSpatiallySparseConvFunction(Function):
         else:
             grad_output = grad_output.contiguous()
 
-            def _ctx(needs):
+            def _ctx(needs, want_db=False):
                 return BwdCtx(grad_output, in_features, weight, ctx.kernel_map, ctx.num_out_coords, ctx.compute_dtype,
-                              grad_output.device, needs, {}, None, ctx.groups, False, {})
+                              grad_output.device, needs, {}, None, ctx.groups, False, {}, want_db)
 
             if ctx.dgrad_algo == ctx.wgrad_algo:
-                grad_in, grad_w = run_backward(ctx.dgrad_algo, _ctx((need_dx, need_dw)))
+                bctx = _ctx((need_dx, need_dw), need_db)
+                grad_in, grad_w = run_backward(ctx.dgrad_algo, bctx)
+                grad_b = bctx.bias_grad
             else:
                 if need_dx:
-                    grad_in, _ = run_backward(ctx.dgrad_algo, _ctx((True, False)))
+                    bctx = _ctx((True, False), need_db)
+                    grad_in, _ = run_backward(ctx.dgrad_algo, bctx)
+                    grad_b = bctx.bias_grad
                 if need_dw:
                     _, grad_w = run_backward(ctx.wgrad_algo, _ctx((False, True)))
+        if need_db and grad_b is None:  # the dgrad kernel did not produce it in the same pass
+            if grad_output.is_cuda and grad_output.shape[0] > 0:
+                from .hip_gemm import hip_colsum
+
+                grad_b = hip_colsum(grad_output.contiguous())
+            else:
+                grad_b = grad_output.float().sum(0)
         ctx.kernel_map = None  # release eagerly (reference unified.py:779-783)
         out = list(_pad_values(15, grad_in, grad_w))
         out[14] = grad_b
