@@ -120,7 +120,8 @@ def main():
     coords = torch.from_numpy(scene_u(args.voxels, seed=1000 + rank)).to(dev)
     N = coords.shape[0]
     g = torch.Generator().manual_seed(rank)
-    feats = torch.randn(N, CIN, generator=g).to(dev, torch.bfloat16)  # bf16 features resident in HBM
+    # bf16 features resident in HBM; a leaf that requires grad, so the backward pass runs ABt (dgrad) as well as AtB
+    feats = torch.randn(N, CIN, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
     grad_out = torch.randn(N, COUT, generator=g).to(dev, torch.bfloat16)
     offsets = torch.tensor([0, N], dtype=torch.int32)
     torch.manual_seed(0)
@@ -130,6 +131,7 @@ def main():
     def step():
         for p in params:
             p.grad = None
+        feats.grad = None
         x = Voxels(coords, feats, offsets=offsets)  # fresh geometry -> kernel map rebuilt every step
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = conv(x)
@@ -166,7 +168,7 @@ def main():
         bcoords = torch.cat([torch.zeros(N, 1, dtype=torch.int32, device=dev), coords], 1).contiguous()
         km = generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3))
         L = int(km.offsets[-1])
-        X = feats
+        X = feats.detach()
         W = conv.weight.detach().to(torch.bfloat16)
         it = max(5, args.steps)
         t_kmap = time_events(lambda: generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3)), it)

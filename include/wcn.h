@@ -182,19 +182,6 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
                          int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
                          int32_t algo, int32_t w_transposed, int32_t k_flip, wcn_stream_t stream);
 
-/* Dgrad + bias gradient in one pass over grad_out.  As wcn_conv_gather_gemm with algo = WCN_ALGO_MFMA, and additionally
- * colsum_out[c] = sum over rows r of in[r][c] (fp32), taken from the rows the kernel gathers anyway for offset
- * `self_offset` - the offset whose neighbour of row r is r itself (the centre of an odd submanifold kernel; the caller
- * guarantees nbr[r][self_offset] == r for every row).  Deterministic (fixed-order partial sums).  Replaces the
- * autograd reduce of `out + bias` (warpconvnet/nn/functional/sparse_conv/helper.py:339-342) without a second read of
- * grad_out.  WCN_ERROR_UNSUPPORTED_CONFIG when wcn_mfma_gather_supported is false (use wcn_colsum then). */
-size_t wcn_gather_gemm_colsum_workspace(int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype);
-int wcn_conv_gather_gemm_colsum(const void* in, const void* w_packed, void* out, const int32_t* nbr,
-                                const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_in,
-                                int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
-                                int32_t self_offset, float* colsum_out, void* workspace, size_t workspace_bytes,
-                                wcn_stream_t stream);
-
 /* out[c] = sum_r in[r][c] in fp32 (bias gradient; reference: autograd of `out + bias`, helper.py:339-342).
  * Deterministic two-pass reduction; workspace: wcn_colsum_workspace(channels) bytes. */
 size_t wcn_colsum_workspace(int32_t channels);
@@ -208,6 +195,20 @@ int wcn_conv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_m
                    const int32_t* out_maps, const int32_t* offsets, int64_t n_in, int64_t n_out,
                    int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype, int32_t algo,
                    void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+
+/* Weight gradient + bias gradient in one pass.  As wcn_conv_wgrad with algo = WCN_ALGO_MFMA, and additionally
+ * bias_grad[co] = sum over rows r of dy[r][co] (fp32 [cout], overwritten): while the kernel streams bucket
+ * `self_offset` - the offset whose pairs are (r, r) for every row r, i.e. the centre of an odd submanifold kernel
+ * built from distinct coordinates (WCN_FLAG_DUPLICATE_COORD clear) - it also multiplies a ones-row fragment with the
+ * dy fragments it holds, so the column sums come out of the matrix cores with no extra read of dy.  Deterministic.
+ * Replaces the autograd reduce of `out + bias` (warpconvnet/nn/functional/sparse_conv/helper.py:339-342).
+ * WCN_ERROR_UNSUPPORTED_CONFIG unless wcn_mfma_wgrad_bias_supported (then use wcn_conv_wgrad + wcn_colsum).
+ * workspace: wcn_conv_wgrad_workspace(num_offsets, cin, cout, WCN_ALGO_MFMA) bytes. */
+int wcn_mfma_wgrad_bias_supported(int32_t cin, int32_t cout, int32_t dtype);
+int wcn_conv_wgrad_bias(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                        const int32_t* offsets, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout,
+                        int32_t num_offsets, int32_t dtype, int32_t self_offset, float* bias_grad, void* workspace,
+                        size_t workspace_bytes, wcn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -84,38 +84,38 @@ def test_mfma_vs_oracle_submanifold(dtype, cin, cout):
     assert rel_max_err(Y2, Yr) < TOL[dtype] and rel_max_err(dX2, dXr) < TOL[dtype] and rel_max_err(dW2, dWr) < 1e-3
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (32, 32), (16, 32), (96, 96), (256, 64)])
-def test_dgrad_fused_bias_grad(dtype, cin, cout):
-    """wcn_conv_gather_gemm_colsum: dgrad unchanged, bias gradient = column sums of grad_output (fp64 oracle sum of the
-    values the GPU saw; fp32 accumulation => 1e-4 relative), deterministic, and NOT offered when coordinates repeat."""
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (32, 32), (64, 64), (96, 96), (256, 64), (128, 256)])
+def test_wgrad_fused_bias_grad(dtype, cin, cout):
+    """wcn_conv_wgrad_bias: dw bit-identical to wcn_conv_wgrad, bias gradient = column sums of grad_output (fp64 sum of
+    the values the GPU saw; fp32 accumulation => 1e-4 relative), deterministic, and NOT offered when coordinates repeat."""
+    from warpconvnet_amd import _lib
     from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
 
-    s = np.concatenate([scene_u(3000, 31, 0), scene_u(1234, 32, 1)], 0)  # 4234 rows: ragged last tile
+    s = np.concatenate([scene_u(3000, 31, 0), scene_u(1234, 32, 1)], 0)  # 4234 rows: ragged last chunk
     km = _kmap(s, s, (3, 3, 3), same=True)
     assert km._symmetric and km._self_exact
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(cin * 7 + cout)
-    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev, dtype)
+    X = torch.randn(len(s), cin, generator=g).to(dev, dtype)
     dY = torch.randn(len(s), cout, generator=g).to(dev, dtype)
-    dX0 = hip_gemm.hip_dgrad(dY, W, km, len(s), "auto")
-    dX1, db = hip_gemm.hip_dgrad(dY, W, km, len(s), "auto", want_colsum=True)
-    from warpconvnet_amd import _lib
-
-    if not _lib.lib().wcn_mfma_gather_supported(cout, cin, 27, _lib.dtype_code(dtype)):
-        assert db is None and torch.equal(dX0, dX1)  # hip_ref dgrad: the caller falls back to wcn_colsum
+    dW0 = hip_gemm.hip_wgrad(X, dY, km, (27, cin, cout), "auto")
+    dW1, db = hip_gemm.hip_wgrad(X, dY, km, (27, cin, cout), "auto", want_bias_grad=True)
+    assert torch.equal(dW0, dW1)
+    if not _lib.lib().wcn_mfma_wgrad_bias_supported(cin, cout, _lib.dtype_code(dtype)):
+        assert db is None  # odd number of 32-channel blocks: the caller falls back to wcn_colsum
         return
     assert db is not None and db.dtype == torch.float32 and db.shape == (cout,)
-    assert torch.equal(dX0, dX1)
     want = dY.double().sum(0)
     assert ((db.double() - want).abs().max() / want.abs().max()).item() < 1e-4
-    _, db2 = hip_gemm.hip_dgrad(dY, W, km, len(s), "auto", want_colsum=True)
+    _, db2 = hip_gemm.hip_wgrad(X, dY, km, (27, cin, cout), "auto", want_bias_grad=True)
     assert torch.equal(db, db2)
     assert rel_max_err(db, hip_gemm.hip_colsum(dY)) < 1e-5
-    # duplicate coordinates: the centre neighbour of the later copy is the earlier row -> no fused column sum
+    # duplicate coordinates: bucket K//2 is no longer "every row once" -> no fused bias gradient
     sd = np.concatenate([s[:2000], s[:17]], 0)
     kmd = _kmap(sd, sd, (3, 3, 3), same=True)
     assert kmd._symmetric and not kmd._self_exact
-    _, dbd = hip_gemm.hip_dgrad(dY[: len(sd)].contiguous(), W, kmd, len(sd), "auto", want_colsum=True)
+    _, dbd = hip_gemm.hip_wgrad(X[: len(sd)].contiguous(), dY[: len(sd)].contiguous(), kmd, (27, cin, cout), "auto",
+                                want_bias_grad=True)
     assert dbd is None
 
 

@@ -72,12 +72,6 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
          c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     ),
-    "wcn_gather_gemm_colsum_workspace": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),
-    "wcn_conv_gather_gemm_colsum": (
-        c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
-         c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p],
-    ),
     "wcn_colsum_workspace": (c_size_t, [c_int32]),
     "wcn_colsum": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wcn_conv_wgrad_workspace": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
@@ -85,6 +79,12 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
          c_int32, c_int32, c_void_p, c_size_t, c_void_p],
+    ),
+    "wcn_mfma_wgrad_bias_supported": (c_int, [c_int32, c_int32, c_int32]),
+    "wcn_conv_wgrad_bias": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+         c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
 }
 

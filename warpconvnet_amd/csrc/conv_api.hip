@@ -11,18 +11,18 @@ int conv_wgrad_ref(const void* x, const void* dy, float* dw, const int32_t* in_m
                    const int32_t* offsets, int cin, int cout, int K, int dtype, hipStream_t s);
 // conv_mfma.hip
 bool mfma_gather_supported(int cin, int cout, int K, int dtype);
-int64_t gather_gemm_colsum_rows(int64_t n_out, int cout);
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                           const int32_t* perm, const float* bias, int64_t n_out, int cin, int cout, int K, int dtype,
-                          float* cs_partial, int cs_k, hipStream_t s);
+                          hipStream_t s);
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s);
 // wgrad_mfma.hip
 bool mfma_wgrad_supported(int cin, int cout, int dtype);
 size_t wgrad_mfma_workspace(int K, int cin, int cout);
+bool mfma_wgrad_bias_supported(int cin, int cout, int dtype);
 int conv_wgrad_mfma(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                     const int32_t* offsets, int cin, int cout, int K, int dtype, void* workspace, size_t workspace_bytes,
-                    hipStream_t s);
+                    int cs_k, float* bias_grad, hipStream_t s);
 }  // namespace wcn
 
 using namespace wcn;
@@ -66,39 +66,11 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
     case WCN_ALGO_MFMA:
       // `w` must be the packed image (wcn_pack_weight already applied transpose / flip)
       if (!mask) return WCN_ERROR_INVALID_PARAMETERS;
-      return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, nullptr, -1, s);
+      return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, s);
     default:
       // AUTO cannot be resolved here because the two algorithms take different weight images.
       return WCN_ERROR_INVALID_PARAMETERS;
   }
-}
-
-size_t wcn_gather_gemm_colsum_workspace(int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype) {
-  if (n_out <= 0 || !mfma_gather_supported(cin, cout, num_offsets, dtype)) return 0;
-  return (size_t)gather_gemm_colsum_rows(n_out, cout) * cin * sizeof(float) + colsum_workspace(cin);
-}
-
-int wcn_conv_gather_gemm_colsum(const void* in, const void* w, void* out, const int32_t* nbr, const uint32_t* mask,
-                                const int32_t* perm, const float* bias, int64_t n_in, int64_t n_out, int32_t cin,
-                                int32_t cout, int32_t num_offsets, int32_t dtype, int32_t self_offset, float* colsum_out,
-                                void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
-  if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || !dtype_ok(dtype) || !colsum_out)
-    return WCN_ERROR_INVALID_PARAMETERS;
-  if (self_offset < 0 || self_offset >= num_offsets) return WCN_ERROR_INVALID_PARAMETERS;
-  if (!mfma_gather_supported(cin, cout, num_offsets, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
-  hipStream_t s = (hipStream_t)stream;
-  if (n_out == 0) return hipMemsetAsync(colsum_out, 0, (size_t)cin * sizeof(float), s) == hipSuccess
-                             ? WCN_SUCCESS : WCN_ERROR_KERNEL_EXECUTION;
-  if (!w || !out || !nbr || !mask || !in) return WCN_ERROR_INVALID_PARAMETERS;
-  const size_t need = wcn_gather_gemm_colsum_workspace(n_out, cin, cout, num_offsets, dtype);
-  if (!workspace || workspace_bytes < need) return WCN_ERROR_INVALID_PARAMETERS;
-  const int64_t rows = gather_gemm_colsum_rows(n_out, cout);
-  float* partial = (float*)workspace;
-  const int rc = conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, partial,
-                                       self_offset, s);
-  if (rc != WCN_SUCCESS) return rc;
-  // fixed-order reduction of the per-wave partial rows (an fp32 [rows, cin] matrix)
-  return colsum(partial, rows, cin, WCN_F32, colsum_out, partial + rows * cin, colsum_workspace(cin), s);
 }
 
 size_t wcn_colsum_workspace(int32_t channels) { return channels > 0 ? colsum_workspace(channels) : 0; }
@@ -126,10 +98,25 @@ int wcn_conv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_m
       return conv_wgrad_ref(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, s);
     case WCN_ALGO_MFMA:
       return conv_wgrad_mfma(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, workspace,
-                             workspace_bytes, s);
+                             workspace_bytes, -1, nullptr, s);
     default:
       return WCN_ERROR_INVALID_PARAMETERS;
   }
+}
+
+int wcn_mfma_wgrad_bias_supported(int32_t cin, int32_t cout, int32_t dtype) {
+  return mfma_wgrad_bias_supported(cin, cout, dtype) ? 1 : 0;
+}
+
+int wcn_conv_wgrad_bias(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                        const int32_t* offsets, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout,
+                        int32_t num_offsets, int32_t dtype, int32_t self_offset, float* bias_grad, void* workspace,
+                        size_t workspace_bytes, wcn_stream_t stream) {
+  if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || !dtype_ok(dtype) || !dw || !offsets || !bias_grad)
+    return WCN_ERROR_INVALID_PARAMETERS;
+  if (self_offset < 0 || self_offset >= num_offsets) return WCN_ERROR_INVALID_PARAMETERS;
+  return conv_wgrad_mfma(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, workspace, workspace_bytes,
+                         self_offset, bias_grad, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -105,13 +105,13 @@ struct GatherGemm {
   typedef typename Frag<T>::type frag_t;
 };
 
-template <typename T, int CIC, int CO, int RB, bool CS>
+template <typename T, int CIC, int CO, int RB>
 __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __restrict__ in, const T* __restrict__ wp,
                                                                T* __restrict__ out, const int32_t* __restrict__ nbr,
                                                                const uint32_t* __restrict__ mask,
                                                                const int32_t* __restrict__ perm,
                                                                const float* __restrict__ bias, int64_t n_out, int cin,
-                                                               int K, int kp, float* __restrict__ cs_partial, int cs_k) {
+                                                               int K, int kp) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   typedef typename G::frag_t frag_t;
   constexpr int NS = G::NS, NB = G::NB, RPW = G::ROWS_PER_WAVE, TILE = G::TILE;
@@ -180,9 +180,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
   WCN_STAMP(2);
   WCN_STAMPV(5, (unsigned long long)__builtin_popcount(block_mask));
 
-  if (CS && !((wave_mask >> cs_k) & 1u)) {
-    for (int cch = lane; cch < cin; cch += 64) cs_partial[((int64_t)blockIdx.x * kWaves + wave) * cin + cch] = 0.f;
-  }
   f32x16 acc[NB][RB];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
@@ -229,50 +226,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
         }
       }
     };
-    // CS: column sums of the gathered operand, taken from offset cs_k whose neighbour of row r is r itself (every row
-    // is gathered exactly once there).  The 8*NS values a lane holds are reduce-scattered over the 32 lanes that
-    // share its channel half: after 5 exchange steps lane n owns the wave total of value n.  Written per wave to
-    // cs_partial[(block*4 + wave)][cin]; wcn_colsum's final pass adds the rows (fixed order => deterministic).
-    auto colsum_step = [&](const frag_t (&bf)[RB][NS], int chunk) {
-      constexpr int NV = NS * 8;
-      float v[NV];
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float t = 0.f;
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) t += (float)bf[rb][s][q];
-          v[s * 8 + q] = t;
-        }
-      int cnt = NV;
-#pragma unroll
-      for (int d = 16; d >= 1; d >>= 1) {
-        if (cnt >= 2 * d) {  // reduce-scatter: keep one half, hand the other to lane ^ d  (resolved at compile time)
-          const bool up = (n & d) != 0;
-          const int half = cnt / 2;
-#pragma unroll
-          for (int i = 0; i < NV / 2; ++i) {
-            if (i < half) {
-              const float keep = up ? v[i + half] : v[i];
-              const float send = up ? v[i] : v[i + half];
-              v[i] = keep + __shfl_xor(send, d);
-            }
-          }
-          cnt = half;
-        } else {  // fewer values than lanes left: plain exchange
-#pragma unroll
-          for (int i = 0; i < NV; ++i)
-            if (i < cnt) v[i] += __shfl_xor(v[i], d);
-        }
-      }
-      // lane n now holds value (n mod NV): channel chunk*CIC + h*(CIC/2) + (n mod NV); lanes n >= NV are duplicates
-      if (n < NV)
-        cs_partial[((int64_t)blockIdx.x * kWaves + wave) * cin + chunk * CIC + h * (CIC / 2) + n] = v[0];
-    };
-    auto compute = [&](const frag_t (&bf)[RB][NS], int buf, int k, int chunk) {
+    auto compute = [&](const frag_t (&bf)[RB][NS], int buf, int k) {
       if (!((wave_mask >> k) & 1u)) return;
-      if (CS && k == cs_k) colsum_step(bf, chunk);
       const frag_t* wl = reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(s_w) + (size_t)buf * G::SLAB_BYTES);
       // the NB weight fragments of channel slice s+1 are read from LDS while the NB*RB MFMAs of slice s run
       frag_t a_cur[NB], a_nxt[NB];
@@ -325,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 #ifdef WCN_PROF
       const unsigned long long q1 = clock64();
 #endif
-      compute(B0, 0, k0, c0);
+      compute(B0, 0, k0);
 #ifdef WCN_PROF
       const unsigned long long q2 = clock64();
 #endif
@@ -343,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
       k0 = k1; c0 = c1;
       const bool has0 = next_step(k0, c0);
       if (has0) { dma_weights(0, k0, c0); gather(B0, k0, c0); }
-      compute(B1, 1, k1, c1);
+      compute(B1, 1, k1);
       sync_step();
       more = has0;
     }
@@ -419,46 +374,33 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 
 template <typename T, int CIC, int CO, int RB>
 static int launch_gather_gemm(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                              const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, float* cs_partial,
-                              int cs_k, hipStream_t s) {
+                              const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, hipStream_t s) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   const int kp = wcn_kmap_row_pitch(K);
+  auto kern = gather_gemm_mfma_kernel<T, CIC, CO, RB>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_mfma_kernel<T, CIC, CO, RB, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_mfma_kernel<T, CIC, CO, RB, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)G::LDS_BYTES) != hipSuccess)
       return WCN_ERROR_KERNEL_INITIALIZATION;
     attr_set = true;
   }
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
-  if (cs_partial)
-    hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, true>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, cs_partial, cs_k);
-  else
-    hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, false>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, nullptr, -1);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm,
+                     bias, n_out, cin, K, kp);
   return launch_status();
-}
-
-// rows of the colsum partial buffer written by the fused kernel (one per wave)
-int64_t gather_gemm_colsum_rows(int64_t n_out, int cout) {
-  const int tile = kWaves * 32 * ((cout <= 128) ? 2 : 1);
-  return ceil_div(n_out, tile) * kWaves;
 }
 
 template <typename T, int CIC>
 static int dispatch_co(int cout, const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                       const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, float* cs, int cs_k,
-                       hipStream_t s) {
+                       const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, hipStream_t s) {
   switch (cout) {
-    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
-    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
-    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
-    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
-    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
-    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
+    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
@@ -479,24 +421,21 @@ bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
 
 template <typename T>
 static int dispatch_cic(int cin, int cout, const void* in, const void* wp, void* out, const int32_t* nbr,
-                        const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_out, int K, float* cs,
-                        int cs_k, hipStream_t s) {
+                        const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_out, int K, hipStream_t s) {
   switch (mfma_chunk_for(cin)) {
-    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
-    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
-    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, cs, cs_k, s);
+    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
 
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                           const int32_t* perm, const float* bias, int64_t n_out, int cin, int cout, int K, int dtype,
-                          float* cs_partial, int cs_k, hipStream_t s) {
+                          hipStream_t s) {
   if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
-  if (cs_partial && (cs_k < 0 || cs_k >= K)) return WCN_ERROR_INVALID_PARAMETERS;
-  if (dtype == WCN_BF16)
-    return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, cs_partial, cs_k, s);
-  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, cs_partial, cs_k, s);
+  if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, s);
+  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, s);
 }
 
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,

@@ -67,6 +67,17 @@ __device__ __forceinline__ s16x8 read_frag_tr(const char* tile, int p0, int c0, 
   return out;
 }
 
+// A-operand fragment of a 32-row block whose row 0 is all ones (rows 1..31 zero): MFMA(ones, dy-fragment) puts the
+// column sums over the step's pairs into row 0 of the product - the bias gradient falls out of the matrix cores.
+template <typename T> __device__ __forceinline__ s16x8 ones_row_frag(int lane) {
+  const short one = sizeof(T) == 2 && __is_same(T, __bf16) ? (short)0x3F80 : (short)0x3C00;
+  const short v = ((lane & 31) == 0) ? one : (short)0;
+  s16x8 f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) f[q] = v;
+  return f;
+}
+
 constexpr int kStages = 3;     // data ring: one stage computing, two in flight / landing
 constexpr int kIdxSlots = 4;   // index ring (64 in + 64 out rows per slot)
 
@@ -99,12 +110,16 @@ struct Wgrad {
 //   C  MFMA on step i           (transpose reads from stage i % 3)
 //   D  s_waitcnt vmcnt(DATA_OPS)  -> everything but B of this step has landed (data i+1, indices i+3)
 //      s_barrier                  -> ... and is visible to all waves; stage (i % 3) may be overwritten
-template <typename T, int CIT, int COT>
+// CS (bias gradient): while a workgroup streams bucket cs_k - the offset whose pairs are (r, r) for every row r - the
+// waves that own ci-block row 0 also multiply a ones-row fragment with the dy fragments they already hold; row 0 of
+// that product is sum_pairs dy[out][co].  Partial sums go to cs_slabs[g][cout], reduced in fixed order afterwards.
+template <typename T, int CIT, int COT, bool CS>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const int32_t* __restrict__ in_maps,
                                                          const int32_t* __restrict__ out_maps,
                                                          const int32_t* __restrict__ offsets, int K, int cin, int cout,
-                                                         const char* __restrict__ zero_page, float* __restrict__ slabs) {
+                                                         const char* __restrict__ zero_page, float* __restrict__ slabs,
+                                                         float* __restrict__ cs_slabs, int cs_k) {
   typedef Wgrad<T, CIT, COT> W;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_idx = smem + (size_t)kStages * W::STAGE_BYTES;  // [kIdxSlots][2][64] int32
@@ -130,13 +145,23 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
     k = lo;
   }
 
+  static_assert(!CS || W::GRID, "the fused bias gradient needs the 2 x 2 wave layout");
   f32x16 acc[W::PER_WAVE];
+  f32x16 acc1[CS ? W::NB : 1];  // ones-row products (CS only)
   auto zero_acc = [&]() {
 #pragma unroll
     for (int j = 0; j < W::PER_WAVE; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    if (CS) {
+#pragma unroll
+      for (int b = 0; b < W::NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc1[b][q] = 0.f;
+    }
   };
+  const bool cs_tile = CS && (blockIdx.y / tiles_co) == 0;  // one ci tile is enough: the sums do not depend on ci
+  const s16x8 ones = ones_row_frag<T>(lane);
   auto flush = [&](int kk) {
     float* slab = slabs + (int64_t)(g + kk) * cin * cout;
     const int h = lane >> 5, n = lane & 31;
@@ -196,7 +221,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
       glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(yt + u * 1024)));
     }
   };
-  auto compute = [&](int st) {
+  auto compute = [&](int st, bool do_cs) {
     const char* xt = smem + (size_t)(st % kStages) * W::STAGE_BYTES;
     const char* yt = xt + W::XT_BYTES;
 #pragma unroll
@@ -211,6 +236,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
         for (int a = 0; a < W::MB; ++a)
 #pragma unroll
           for (int b = 0; b < W::NB; ++b) acc[a * W::NB + b] = WFrag<T>::mfma(af[a], bf[b], acc[a * W::NB + b]);
+        if (CS && do_cs && (wave >> 1) == 0) {
+#pragma unroll
+          for (int b = 0; b < W::NB; ++b) acc1[b] = WFrag<T>::mfma(ones, bf[b], acc1[b]);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < W::PER_WAVE; ++j) {
@@ -234,6 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
     while ((int64_t)offsets[k + 1] <= pos) ++k;  // skip empty buckets
     const int64_t seg_end = ((int64_t)offsets[k + 1] < r_end) ? (int64_t)offsets[k + 1] : r_end;
     const int nsteps = (int)((seg_end - pos + kPairs - 1) / kPairs);
+    const bool do_cs = cs_tile && k == cs_k;
     zero_acc();
     // ---- prologue: indices of steps 0..2, data of steps 0..1 ----
     dma_idx(0, pos, seg_end);
@@ -254,7 +284,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
       if (i + 3 < nsteps) dma_idx(i + 3, pos, seg_end);
       const bool more = i + 2 < nsteps;
       if (more) dma_data(i + 2, pos, seg_end);
-      compute(i);
+      compute(i, do_cs);
       if (more) {
         wait_vmcnt<W::DATA_OPS>();
       } else {
@@ -263,6 +293,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x
       barrier();
     }
     flush(k);
+    if (CS && do_cs && (wave >> 1) == 0 && lane < 32) {  // row 0 of the ones-row product: lanes 0..31, register 0
+#pragma unroll
+      for (int b = 0; b < W::NB; ++b)
+        cs_slabs[(int64_t)g * cout + co0 + ((wave & 1) * W::NB + b) * 32 + lane] = acc1[b][0];
+    }
     pos = seg_end;
   }
 }
@@ -290,6 +325,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (part == 0 && e < ce) dw[(int64_t)k * ce + e] = (s_part[0][el] + s_part[1][el]) + (s_part[2][el] + s_part[3][el]);
 }
 
+// bias_grad[co] = sum over the ranges g that intersect bucket cs_k (ascending) of cs_slabs[g][co]; one wavefront per
+// channel, lane l adds ranges g_lo + l, + 64, ... then a fixed butterfly => deterministic.
+__global__ __launch_bounds__(64) void wgrad_colsum_reduce_kernel(const float* __restrict__ cs_slabs,
+                                                                 const int32_t* __restrict__ offsets, int K, int cs_k,
+                                                                 int cout, int G, float* __restrict__ out) {
+  const int co = blockIdx.x, lane = threadIdx.x;
+  const int64_t L = offsets[K];
+  int64_t Q = (L + G - 1) / G;
+  Q = ((Q + kPairs - 1) / kPairs) * kPairs;
+  const int64_t b = offsets[cs_k], en = offsets[cs_k + 1];
+  float s = 0.f;
+  if (en > b && Q > 0) {
+    const int g_lo = (int)(b / Q), g_hi = (int)((en - 1) / Q);
+    for (int g = g_lo + lane; g <= g_hi; g += 64) s += cs_slabs[(int64_t)g * cout + co];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (lane == 0) out[co] = s;
+}
+
 static int wgrad_tile(int c) {  // largest supported tile dividing the channel count
   if (c % 128 == 0) return 128;
   if (c % 96 == 0) return 96;
@@ -303,28 +358,52 @@ bool mfma_wgrad_supported(int cin, int cout, int dtype) {
   return wgrad_tile(cin) != 0 && wgrad_tile(cout) != 0;
 }
 
+bool mfma_wgrad_bias_supported(int cin, int cout, int dtype) {
+  if (!mfma_wgrad_supported(cin, cout, dtype)) return false;
+  return (wgrad_tile(cin) / 32) % 2 == 0 && (wgrad_tile(cout) / 32) % 2 == 0;  // 2 x 2 wave layout (Wgrad::GRID)
+}
+
 size_t wgrad_mfma_workspace(int K, int cin, int cout) {
-  return (size_t)kZeroPage + (size_t)(kWgradGrid + K) * cin * cout * sizeof(float);
+  // zero page + weight-gradient slabs + bias-gradient partials
+  return (size_t)kZeroPage + (size_t)(kWgradGrid + K) * cin * cout * sizeof(float) + (size_t)kWgradGrid * cout * sizeof(float);
 }
 
 template <typename T, int CIT, int COT>
 static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
-                        const int32_t* offsets, int cin, int cout, int K, void* workspace, hipStream_t s) {
+                        const int32_t* offsets, int cin, int cout, int K, void* workspace, int cs_k, float* bias_grad,
+                        hipStream_t s) {
   typedef Wgrad<T, CIT, COT> W;
-  auto kern = wgrad_mfma_kernel<T, CIT, COT>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)W::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<T, CIT, COT, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES) != hipSuccess)
       return WCN_ERROR_KERNEL_INITIALIZATION;
+    if constexpr (W::GRID) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<T, CIT, COT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES) != hipSuccess)
+        return WCN_ERROR_KERNEL_INITIALIZATION;
+    }
     attr_set = true;
   }
   char* zero_page = (char*)workspace;
   float* slabs = (float*)((char*)workspace + kZeroPage);
+  float* cs_slabs = slabs + (size_t)(kWgradGrid + K) * cin * cout;
   if (hipMemsetAsync(zero_page, 0, kZeroPage, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
   const dim3 grid(kWgradGrid, (cin / CIT) * (cout / COT));
-  hipLaunchKernelGGL(kern, grid, dim3(256), W::LDS_BYTES, s, (const T*)x, (const T*)dy, in_maps, out_maps, offsets, K, cin,
-                     cout, (const char*)zero_page, slabs);
+  if (bias_grad) {
+    if constexpr (W::GRID) {
+      hipLaunchKernelGGL((wgrad_mfma_kernel<T, CIT, COT, true>), grid, dim3(256), W::LDS_BYTES, s, (const T*)x,
+                         (const T*)dy, in_maps, out_maps, offsets, K, cin, cout, (const char*)zero_page, slabs, cs_slabs,
+                         cs_k);
+      hipLaunchKernelGGL(wgrad_colsum_reduce_kernel, dim3((unsigned)cout), dim3(64), 0, s, (const float*)cs_slabs, offsets,
+                         K, cs_k, cout, kWgradGrid, bias_grad);
+    } else {
+      return WCN_ERROR_UNSUPPORTED_CONFIG;
+    }
+  } else {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, CIT, COT, false>), grid, dim3(256), W::LDS_BYTES, s, (const T*)x,
+                       (const T*)dy, in_maps, out_maps, offsets, K, cin, cout, (const char*)zero_page, slabs, nullptr, -1);
+  }
   const int64_t ce = (int64_t)cin * cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ce, 64), K), dim3(256), 0, s, (const float*)slabs,
                      offsets, K, ce, kWgradGrid, dw);
@@ -334,35 +413,37 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
 template <typename T, int CIT>
 static int dispatch_wgrad_co(int cot, const void* x, const void* dy, float* dw, const int32_t* in_maps,
                              const int32_t* out_maps, const int32_t* offsets, int cin, int cout, int K, void* workspace,
-                             hipStream_t s) {
+                             int cs_k, float* bias_grad, hipStream_t s) {
   switch (cot) {
-    case 32: return launch_wgrad<T, CIT, 32>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-    case 64: return launch_wgrad<T, CIT, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-    case 96: return launch_wgrad<T, CIT, 96>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-    default: return launch_wgrad<T, CIT, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    case 32: return launch_wgrad<T, CIT, 32>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    case 64: return launch_wgrad<T, CIT, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    case 96: return launch_wgrad<T, CIT, 96>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    default: return launch_wgrad<T, CIT, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
   }
 }
 
 template <typename T>
 static int dispatch_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
-                          const int32_t* offsets, int cin, int cout, int K, void* workspace, hipStream_t s) {
+                          const int32_t* offsets, int cin, int cout, int K, void* workspace, int cs_k, float* bias_grad,
+                             hipStream_t s) {
   const int cot = wgrad_tile(cout);
   switch (wgrad_tile(cin)) {
-    case 32: return dispatch_wgrad_co<T, 32>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-    case 64: return dispatch_wgrad_co<T, 64>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-    case 96: return dispatch_wgrad_co<T, 96>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-    default: return dispatch_wgrad_co<T, 128>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    case 32: return dispatch_wgrad_co<T, 32>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    case 64: return dispatch_wgrad_co<T, 64>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    case 96: return dispatch_wgrad_co<T, 96>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    default: return dispatch_wgrad_co<T, 128>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
   }
 }
 
 int conv_wgrad_mfma(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                     const int32_t* offsets, int cin, int cout, int K, int dtype, void* workspace, size_t workspace_bytes,
-                    hipStream_t s) {
+                    int cs_k, float* bias_grad, hipStream_t s) {
   if (!mfma_wgrad_supported(cin, cout, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (bias_grad && (!mfma_wgrad_bias_supported(cin, cout, dtype) || cs_k < 0 || cs_k >= K)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   if (!workspace || workspace_bytes < wgrad_mfma_workspace(K, cin, cout)) return WCN_ERROR_INVALID_PARAMETERS;
   if (dtype == WCN_BF16)
-    return dispatch_wgrad<__bf16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
-  return dispatch_wgrad<_Float16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, s);
+    return dispatch_wgrad<__bf16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+  return dispatch_wgrad<_Float16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
 }
 
 }  // namespace wcn

@@ -87,14 +87,16 @@ def _make_hip_bwd(algo: str) -> BwdFn:
         dy = ctx.grad_output.to(dt)
         dx = dw = None
         if need_dx:
-            fuse_db = ctx.want_bias_grad and dy.dtype == ctx.grad_output.dtype  # same values as an unfused column sum
-            dx, db = hip_gemm.hip_dgrad(dy, ctx.weight.to(dt), ctx.kernel_map, ctx.in_features.shape[0], algo,
-                                        want_colsum=True) if fuse_db else (
-                hip_gemm.hip_dgrad(dy, ctx.weight.to(dt), ctx.kernel_map, ctx.in_features.shape[0], algo), None)
-            ctx.bias_grad = db
+            dx = hip_gemm.hip_dgrad(dy, ctx.weight.to(dt), ctx.kernel_map, ctx.in_features.shape[0], algo)
             dx = dx.to(ctx.in_features.dtype)
         if need_dw:
-            dw = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape), algo)
+            # the bias gradient rides along only if it is the column sum of the very tensor autograd handed us
+            fuse_db = ctx.want_bias_grad and dy.dtype == ctx.grad_output.dtype
+            if fuse_db:
+                dw, ctx.bias_grad = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape),
+                                                       algo, want_bias_grad=True)
+            else:
+                dw = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape), algo)
             dw = dw.to(ctx.weight.dtype)
         return dx, dw
 

@@ -118,13 +118,8 @@ def hip_colsum(t: Tensor) -> Tensor:
 
 
 def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_in_coords: int,
-              algo: str = "auto", want_colsum: bool = False):
-    """dx[n] = sum_k dy[rev[n][k]] @ w[k]^T; a submanifold map reuses the forward table with k reversed.
-
-    ``want_colsum``: also return the fp32 column sums of ``grad_output`` (the bias gradient) when the fused kernel can
-    provide them in the same pass (submanifold map without duplicate coordinates, MFMA path); returns
-    ``(dx, colsum_or_None)`` in that mode.
-    """
+              algo: str = "auto") -> Tensor:
+    """dx[n] = sum_k dy[rev[n][k]] @ w[k]^T; a submanifold map reuses the forward table with k reversed."""
     dy, w = _prep(grad_output, "grad_output"), _prep(weight, "weight")
     if dy.dtype != w.dtype:
         raise RuntimeError(f"hip dgrad error: {_lib.status_string(-6)} ({dy.dtype} vs {w.dtype})")
@@ -137,28 +132,17 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
         tbl, mask, perm = reverse_tables(kernel_map, num_in_coords)
         flip = False
     code = resolve_gather_algo(algo, cout, cin, K, dy.dtype)
-    fuse = (want_colsum and code == _lib.WCN_ALGO_MFMA and getattr(kernel_map, "_self_exact", False)
-            and num_in_coords == dy.shape[0] and num_in_coords > 0)
-    if not fuse:
-        dx = _gather_gemm(dy, w, tbl, mask, perm, num_in_coords, cout, cin, K, code, transposed=True, flip=flip)
-        return (dx, None) if want_colsum else dx
-    L = _lib.lib()
-    dx = torch.empty((num_in_coords, cin), dtype=dy.dtype, device=dy.device)
-    colsum = torch.empty(cout, dtype=torch.float32, device=dy.device)
-    ws_bytes = L.wcn_gather_gemm_colsum_workspace(num_in_coords, cout, cin, K, _lib.dtype_code(dy.dtype))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-    _lib.check(
-        L.wcn_conv_gather_gemm_colsum(
-            _lib.ptr(dy), _lib.ptr(pack_weight(w, True, flip)), _lib.ptr(dx), _lib.ptr(tbl), _lib.ptr(mask), _lib.ptr(perm),
-            None, dy.shape[0], num_in_coords, cout, cin, K, _lib.dtype_code(dy.dtype), K // 2, _lib.ptr(colsum),
-            _lib.ptr(ws), ws_bytes, _lib.stream_handle(dy.device)),
-        "wcn_conv_gather_gemm_colsum",
-    )
-    return dx, colsum
+    return _gather_gemm(dy, w, tbl, mask, perm, num_in_coords, cout, cin, K, code, transposed=True, flip=flip)
 
 
-def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchResult, weight_shape, algo: str = "auto") -> Tensor:
-    """dw[k] = x[in_k]^T @ dy[out_k], fp32 [K, Cin, Cout]."""
+def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchResult, weight_shape, algo: str = "auto",
+              want_bias_grad: bool = False):
+    """dw[k] = x[in_k]^T @ dy[out_k], fp32 [K, Cin, Cout].
+
+    ``want_bias_grad``: returns ``(dw, bias_grad_or_None)``; the fp32 column sums of ``grad_output`` come out of the same
+    kernel (ones-row MFMA on the centre bucket) when the map is a submanifold map over distinct coordinates and the
+    MFMA tile layout supports it, else ``None`` (the caller then uses :func:`hip_colsum`).
+    """
     x, dy = _prep(in_features, "in_features"), _prep(grad_output, "grad_output")
     if x.dtype != dy.dtype:
         raise RuntimeError(f"hip wgrad error: {_lib.status_string(-6)} ({x.dtype} vs {dy.dtype})")
@@ -172,10 +156,23 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
     code = resolve_wgrad_algo(algo, cin, cout, x.dtype)
     ws_bytes = L.wcn_conv_wgrad_workspace(K, cin, cout, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    fuse = (want_bias_grad and code == _lib.WCN_ALGO_MFMA and getattr(kernel_map, "_self_exact", False)
+            and x.shape[0] == dy.shape[0] and dy.shape[0] > 0
+            and bool(L.wcn_mfma_wgrad_bias_supported(cin, cout, _lib.dtype_code(x.dtype))))
+    if fuse:
+        db = torch.empty(cout, dtype=torch.float32, device=dev)
+        _lib.check(
+            L.wcn_conv_wgrad_bias(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(kernel_map.in_maps_device),
+                                  _lib.ptr(kernel_map.out_maps_device), _lib.ptr(kernel_map._offsets_dev), x.shape[0],
+                                  dy.shape[0], cin, cout, K, _lib.dtype_code(x.dtype), K // 2, _lib.ptr(db), _lib.ptr(ws),
+                                  ws_bytes, _lib.stream_handle(dev)),
+            "wcn_conv_wgrad_bias",
+        )
+        return dw, db
     _lib.check(
         L.wcn_conv_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(kernel_map.in_maps_device),
                          _lib.ptr(kernel_map.out_maps_device), _lib.ptr(kernel_map._offsets_dev), x.shape[0], dy.shape[0], cin,
                          cout, K, _lib.dtype_code(x.dtype), code, _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)),
         "wcn_conv_wgrad",
     )
-    return dw
+    return (dw, None) if want_bias_grad else dw

@@ -110,12 +110,12 @@ class UnifiedSpatiallySparseConvFunction(Function):
                 grad_b = bctx.bias_grad
             else:
                 if need_dx:
-                    bctx = _ctx((True, False), need_db)
-                    grad_in, _ = run_backward(ctx.dgrad_algo, bctx)
-                    grad_b = bctx.bias_grad
+                    grad_in, _ = run_backward(ctx.dgrad_algo, _ctx((True, False)))
                 if need_dw:
-                    _, grad_w = run_backward(ctx.wgrad_algo, _ctx((False, True)))
-        if need_db and grad_b is None:  # the dgrad kernel did not produce it in the same pass
+                    bctx = _ctx((False, True), need_db)
+                    _, grad_w = run_backward(ctx.wgrad_algo, bctx)
+                    grad_b = bctx.bias_grad
+        if need_db and grad_b is None:  # the wgrad kernel did not produce it in the same pass
             if grad_output.is_cuda and grad_output.shape[0] > 0:
                 from .hip_gemm import hip_colsum
 
