@@ -114,7 +114,7 @@ struct Wgrad {
 // waves that own ci-block row 0 also multiply a ones-row fragment with the dy fragments they already hold; row 0 of
 // that product is sum_pairs dy[out][co].  Partial sums go to cs_slabs[g][cout], reduced in fixed order afterwards.
 template <typename T, int CIT, int COT, bool CS>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const int32_t* __restrict__ in_maps,
                                                          const int32_t* __restrict__ out_maps,
                                                          const int32_t* __restrict__ offsets, int K, int cin, int cout,
