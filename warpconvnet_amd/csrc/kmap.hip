@@ -140,33 +140,48 @@ __global__ __launch_bounds__(kThreads) void kmap_count_kernel(const uint32_t* __
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ counts, int64_t nwb, int K,
                                                          int32_t* __restrict__ totals) {
-  __shared__ int s_part[16];
+  // one workgroup per offset; kPer consecutive counts per thread and trip (the wave still reads one contiguous span),
+  // wave scan of the thread sums by shuffles, wave totals combined through LDS, running carry in a register
+  constexpr int kPer = 8;
+  __shared__ int s_wave[16];
   int32_t* c = counts + (int64_t)blockIdx.x * nwb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t chunk = (nwb + 1023) / 1024;
-  const int64_t b0 = (int64_t)tid * chunk;
-  const int64_t b1 = (b0 + chunk < nwb) ? (b0 + chunk) : nwb;
-  int sum = 0;
-  for (int64_t b = b0; b < b1; ++b) sum += c[b];
-  int incl = sum;
+  int carry = 0;
+  for (int64_t base = 0; base < nwb; base += 1024 * kPer) {
+    const int64_t i0 = base + (int64_t)tid * kPer;
+    int v[kPer];
+    int sum = 0;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
+    for (int j = 0; j < kPer; ++j) {
+      v[j] = (i0 + j < nwb) ? c[i0 + j] : 0;
+      sum += v[j];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wave_base = 0, trip_total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int t = s_wave[w];
+      if (w < wave) wave_base += t;
+      trip_total += t;
+    }
+    int run = carry + wave_base + incl - sum;  // exclusive prefix of this thread's first element
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      if (i0 + j < nwb) c[i0 + j] = run;
+      run += v[j];
+    }
+    carry += trip_total;
+    __syncthreads();  // s_wave is rewritten by the next trip
   }
-  if (lane == 63) s_part[wave] = incl;
-  __syncthreads();
-  int wave_base = 0;
-  for (int w = 0; w < wave; ++w) wave_base += s_part[w];
-  int run = wave_base + incl - sum;
-  for (int64_t b = b0; b < b1; ++b) {
-    const int v = c[b];
-    c[b] = run;
-    run += v;
-  }
-  if (tid == 1023) totals[blockIdx.x] = wave_base + incl;
+  if (tid == 0) totals[blockIdx.x] = carry;
 }
-
 __global__ void kmap_offsets_kernel(const int32_t* __restrict__ totals, int K, int32_t* __restrict__ offsets) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int acc = 0;

@@ -189,6 +189,12 @@ __global__ void bin_scatter_kernel(const int32_t* __restrict__ slot_id, const in
   binned[blk_off[id] + local] = make_int4(c.y, c.z, c.w, (int)i);
 }
 
+#ifdef WCN_PROF
+__device__ unsigned long long g_bprof[4096 * 8];
+#define BSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_bprof[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define BSTAMP(i)
+#endif
 template <int LPR>
 __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* __restrict__ slots, uint32_t cmask,
                                                                     const int32_t* __restrict__ slot_id,
@@ -204,13 +210,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
   const int cells = g.gx * g.gy * g.gz;
   int* s_nb_beg = reinterpret_cast<int*>(s_grid + cells);  // [27] first entry of neighbour bin
   int* s_nb_pre = s_nb_beg + 27;                            // [28] prefix of neighbour bin sizes
-  int4* s_own = reinterpret_cast<int4*>(s_grid + ((cells + 64 + 3) & ~3));  // [kOwnChunk] staged own entries (16-B aligned)
+  int2* s_own = reinterpret_cast<int2*>(s_grid + ((cells + 64 + 3) & ~3));  // [kOwnChunk] staged own voxels: (grid cell, row)
   const int tid = threadIdx.x, lane = tid & 63;
   const int nblocks = *nblk;
   constexpr int kVoxPerIter = kBinThreads / LPR;
   const int sub = tid % LPR, vsel = tid / LPR;
 
   for (int id = blockIdx.x; id < nblocks; id += gridDim.x) {
+    BSTAMP(0);
     const uint64_t key = slots[blk_slot[id]].key;
     const int b = (int)((key >> 54) & kBatchMask);
     const int bx = wrap_blk((int)((key >> 36) & kCoordMask));
@@ -235,6 +242,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
     }
     for (int c = tid; c < cells; c += kBinThreads) s_grid[c] = 0xFFFFFFFFu;
     __syncthreads();
+    BSTAMP(1);
     if (tid == 0) {
       s_nb_pre[0] = 0;
       for (int q = 0; q < 27; ++q) s_nb_pre[q + 1] += s_nb_pre[q];
@@ -270,33 +278,41 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
       }
     }
     __syncthreads();
+    BSTAMP(2);
     // ---- answer the K probes of the block's own voxels: one lane per (voxel, offset).  The block's own entries are
     //      staged through LDS in chunks (coalesced, upfront) so the probe loop itself has no global loads. ----
     const int own_beg = s_nb_beg[13], own_cnt = s_nb_pre[14] - s_nb_pre[13];
     const int num_chunks = (kp + LPR - 1) / LPR;
     for (int c0 = 0; c0 < own_cnt; c0 += kOwnChunk) {
       const int cn = (own_cnt - c0) < kOwnChunk ? (own_cnt - c0) : kOwnChunk;
-      for (int e = tid; e < cn; e += kBinThreads) s_own[e] = binned[own_beg + c0 + e];
+      // staged as (grid cell of the voxel, row): the probe loop is instruction-issue bound, so everything that does
+      // not depend on the offset is computed once here
+      for (int e = tid; e < cn; e += kBinThreads) {
+        const int4 v = binned[own_beg + c0 + e];
+        const int cell = (((v.x & (kBlk - 1)) + g.hx) * g.gy + (v.y & (kBlk - 1)) + g.hy) * g.gz + (v.z & (kBlk - 1)) + g.hz;
+        s_own[e] = make_int2(cell, v.w);
+      }
       __syncthreads();
       for (int kc = 0; kc < num_chunks; ++kc) {
         const int k = kc * LPR + sub;
         const bool k_real = k < K, k_store = k < kp;
         const int l = k % g.kz, j = (k / g.kz) % g.ky, i = k / (g.kz * g.ky);
         const int ox = (i - g.cx) * g.dx, oy = (j - g.cy) * g.dy, oz = (l - g.cz) * g.dz;
+        const int delta = (ox * g.gy + oy) * g.gz + oz;  // cell offset of this lane's kernel offset
+        const bool centre = (ox | oy | oz) == 0;
+        int32_t* nbr_k = nbr + k;
         for (int e0 = 0; e0 < cn; e0 += kVoxPerIter) {
           const int e = e0 + vsel;
           int found = -1;
           int row = -1;
           if (e < cn) {
-            const int4 v = s_own[e];
-            row = v.w;
+            const int2 v = s_own[e];
+            row = v.y;
             if (k_real) {
-              const int lx = (v.x & (kBlk - 1)) + g.hx + ox, ly = (v.y & (kBlk - 1)) + g.hy + oy,
-                        lz = (v.z & (kBlk - 1)) + g.hz + oz;
-              found = (int)s_grid[(lx * g.gy + ly) * g.gz + lz];  // 0xFFFFFFFF -> -1
-              if ((ox | oy | oz) == 0 && found != row) atomicOr(status, (int)WCN_FLAG_DUPLICATE_COORD);
+              found = (int)s_grid[v.x + delta];  // 0xFFFFFFFF -> -1
+              if (centre && found != row) atomicOr(status, (int)WCN_FLAG_DUPLICATE_COORD);
             }
-            if (k_store) nbr[(int64_t)row * kp + k] = found;
+            if (k_store) nbr_k[(int64_t)row * kp] = found;
           }
           const unsigned long long ball = __ballot(found >= 0);
           if (row >= 0 && sub == 0) {
@@ -310,6 +326,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
       }
       __syncthreads();  // s_own is refilled by the next chunk
     }
+#ifdef WCN_PROF
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_bprof[blockIdx.x * 8 + 4] = own_cnt;
+#endif
+    BSTAMP(3);
     __syncthreads();  // grid is reused by the next block
   }
 }
@@ -415,7 +435,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(gn), dim3(256), 0, s, (const int32_t*)w.slot_id, (const int32_t*)w.cnt,
                      (const int4*)coords, n, (const int32_t*)w.vox_slot, (const int32_t*)w.vox_pos,
                      (const int32_t*)w.blk_off, w.binned);
-  const size_t shm = (((size_t)g.gx * g.gy * g.gz + 64 + 3) & ~(size_t)3) * 4 + (size_t)kOwnChunk * 16;
+  const size_t shm = (((size_t)g.gx * g.gy * g.gz + 64 + 3) & ~(size_t)3) * 4 + (size_t)kOwnChunk * 8;
   const int64_t want = n / 64 + 1;  // never more workgroups than could have work
   const dim3 grid((unsigned)(want < 4096 ? want : 4096)), block(kBinThreads);
 #define WCN_BIN_NB(L)                                                                                                  \
@@ -434,3 +454,9 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
 }
 
 }  // extern "C"
+
+#ifdef WCN_PROF
+extern "C" int wcn_debug_read_bprof(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wcn::g_bprof), bytes);
+}
+#endif
