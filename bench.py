@@ -200,6 +200,15 @@ def main():
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process;
+        # tools/collect_profiles.sh + tools/rocpd_stats.py produce the file from this very command line)
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if N == 1_000_000 and os.path.exists(pmc_file):
+            with open(pmc_file) as f:
+                pmc = json.load(f)
+            key = "fwd" if "(fwd)" in dom else ("dgrad" if "(dgrad)" in dom else "wgrad")
+            traffic, traffic_src = pmc[key]["hbm_bytes"], "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)"
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         total_bytes = sum(ab.values())
         result = {
@@ -222,7 +231,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
             },
             "phases_ms": {"kmap": round(t_kmap, 4), "fwd": round(t_fwd, 4), "dgrad": round(t_dgrad, 4), "wgrad": round(t_wgrad, 4),

@@ -54,7 +54,39 @@ def pmc(path):
         print(f"| `{short(k)}` | {c} | {n} | {t / n:.1f} | {t / n / 1024:.2f} |")
 
 
+def traffic(fetch_db, write_db):
+    """HBM bytes per launch of the three GEMM kernels from two separate --pmc passes (FETCH_SIZE / WRITE_SIZE, both in
+    KiB).  FETCH_SIZE is doubled: on gfx950 it tallies 128-B fabric requests at 64 B (MI355X_MICROARCH.md, HBM section);
+    WRITE_SIZE matched the known output size exactly on this workload (250000 KiB for 1 M x 128 bf16) and is used as is."""
+    import json
+
+    def avg(db, counter):
+        rows = sqlite3.connect(db).execute(
+            "select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+        agg = {}
+        for k, v in rows:
+            a = agg.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += v
+        return {k: t / n for k, (n, t) in agg.items()}
+
+    f, w = avg(fetch_db, "FETCH_SIZE"), avg(write_db, "WRITE_SIZE")
+    keys = {"fwd": "gather_gemm_mfma_kernelIDF16bLi64ELi128", "dgrad": "gather_gemm_mfma_kernelIDF16bLi64ELi64",
+            "wgrad": "wgrad_mfma_kernelIDF16bLi64ELi128ELb1"}
+    out = {"unit": "bytes per launch", "fetch_correction": 2.0, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 20 --warmup 5 --no-cpu-baseline`"}
+    for name, sub in keys.items():
+        fk = [v for k, v in f.items() if sub in k]
+        wk = [v for k, v in w.items() if sub in k]
+        fetch = 2.0 * 1024 * (fk[0] if fk else 0.0)
+        write = 1024 * (wk[0] if wk else 0.0)
+        out[name] = {"fetch_bytes": int(fetch), "write_bytes": int(write), "hbm_bytes": int(fetch + write)}
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3])
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "pmc":
         pmc(sys.argv[1])
     else:
