@@ -210,6 +210,23 @@ int wcn_conv_wgrad_bias(const void* x, const void* dy, float* dw, const int32_t*
                         int32_t num_offsets, int32_t dtype, int32_t self_offset, float* bias_grad, void* workspace,
                         size_t workspace_bytes, wcn_stream_t stream);
 
+/* ---- depthwise sparse convolution (weight [K, C], same dtype as the features) ----------------------------------------
+ * reference semantics: warpconvnet/nn/functional/sparse_conv_depth.py:227-306 (explicit depthwise forward/backward);
+ * replaces _C.fma.implicit_fma / _C.fma.implicit_reduction (call sites sparse_conv_depth.py:309-421).
+ *
+ * wcn_dwconv_gather: out[r][c] = bias[c] + sum_k in[nbr[r][kt]][c] * w[kw][c], kt = k_flip ? K-1-kw : kw, fp32
+ *   accumulate, fixed order, no atomics.  Forward: the forward table, k_flip = 0.  Dgrad: in = grad_output and either
+ *   the forward table of a submanifold map with k_flip = 1 or a reverse table (wcn_kmap_reverse) with k_flip = 0.
+ * wcn_dwconv_wgrad: dw[k][c] = sum over the pairs p of bucket k of x[in_p][c] * dy[out_p][c]  (fp32 [K, C],
+ *   overwritten, deterministic).  workspace: wcn_dwconv_wgrad_workspace(num_offsets, channels) bytes. */
+int wcn_dwconv_gather(const void* in, const void* w, void* out, const int32_t* nbr, const float* bias, int64_t n_in,
+                      int64_t n_out, int32_t channels, int32_t num_offsets, int32_t dtype, int32_t k_flip,
+                      wcn_stream_t stream);
+size_t wcn_dwconv_wgrad_workspace(int32_t num_offsets, int32_t channels);
+int wcn_dwconv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                     const int32_t* offsets, int64_t n_in, int64_t n_out, int32_t channels, int32_t num_offsets,
+                     int32_t dtype, void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

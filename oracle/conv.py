@@ -53,3 +53,46 @@ def backward(dy, x, w, in_maps, out_maps, offsets, identity_map_index: Optional[
         dx.index_add_(0, i, torch.matmul(g, w[k].T))
         dw[k] += torch.matmul(x[i].T, g)
     return dx, dw
+
+
+# ---- depthwise (weight [K, C]) -----------------------------------------------------------------------------------
+# Restates `warpconvnet/nn/functional/sparse_conv_depth.py`:
+#   forward  :227-257   identity offset as X * w[iden], then per non-empty offset X[in_map] * w[k] added at out_map
+#   backward :260-306   dX[in_map] += dY[out_map] * w[k] ; dw[k] += sum_rows X[in_map] * dY[out_map]
+# Pinned by tests/golden/depthwise_*.npz (produced by importing the reference).
+def depthwise_forward(x, w, in_maps, out_maps, offsets, num_out: int, identity_map_index: Optional[int] = None) -> torch.Tensor:
+    x, w = _t(x), _t(w)
+    in_maps, out_maps = _t(in_maps).long(), _t(out_maps).long()
+    offsets = [int(v) for v in np.asarray(offsets).tolist()]
+    K = len(offsets) - 1
+    if identity_map_index is not None:
+        y = x * w[identity_map_index].unsqueeze(0)
+    else:
+        y = torch.zeros(num_out, w.shape[-1], dtype=x.dtype)
+    for k in range(K):
+        if k == identity_map_index or offsets[k + 1] == offsets[k]:
+            continue
+        i, o = in_maps[offsets[k] : offsets[k + 1]], out_maps[offsets[k] : offsets[k + 1]]
+        y[o] += x[i] * w[k].unsqueeze(0)
+    return y
+
+
+def depthwise_backward(dy, x, w, in_maps, out_maps, offsets, identity_map_index: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    dy, x, w = _t(dy), _t(x), _t(w)
+    in_maps, out_maps = _t(in_maps).long(), _t(out_maps).long()
+    offsets = [int(v) for v in np.asarray(offsets).tolist()]
+    K = len(offsets) - 1
+    dw = torch.zeros_like(w)
+    if identity_map_index is not None:
+        dx = dy * w[identity_map_index].unsqueeze(0)
+        dw[identity_map_index] = torch.sum(x * dy, dim=0)
+    else:
+        dx = torch.zeros_like(x)
+    for k in range(K):
+        if k == identity_map_index or offsets[k + 1] == offsets[k]:
+            continue
+        i, o = in_maps[offsets[k] : offsets[k + 1]], out_maps[offsets[k] : offsets[k + 1]]
+        g = dy[o]
+        dx.index_add_(0, i, g * w[k].unsqueeze(0))
+        dw[k] += torch.sum(x[i] * g, dim=0)
+    return dx, dw

@@ -98,6 +98,57 @@ def make_grad_out(n, cout, dtype):
     return (row.unsqueeze(1) + col.unsqueeze(0)) / 2.0
 
 
+def main_depthwise():
+    """(g) depthwise sparse convolution: explicit forward/backward and seeded module init (reference:
+    nn/functional/sparse_conv_depth.py:227-306, nn/modules/sparse_conv_depth.py:43-183)."""
+    import_reference()
+    from warpconvnet.geometry.coords.search.search_results import IntSearchResult
+    from warpconvnet.nn.functional.sparse_conv_depth import (
+        _explicit_depthwise_backward_logic,
+        _explicit_depthwise_forward_logic,
+    )
+    from warpconvnet.nn.modules.sparse_conv_depth import SparseDepthwiseConv3d
+
+    from oracle import brute, kmap
+
+    def run_case(name, bc_in, bc_out, ksize, stride, C, dtype, use_identity, seed):
+        found, offsets, in_maps, out_maps = brute.kernel_map(bc_in, bc_out, ksize, stride)
+        K = len(offsets) - 1
+        iden = K // 2 if use_identity else None
+        g = torch.Generator().manual_seed(seed)
+        X = torch.randn(len(bc_in), C, generator=g, dtype=dtype)
+        W = torch.randn(K, C, generator=g, dtype=dtype) * 0.2
+        dY = torch.randn(len(bc_out), C, generator=g, dtype=dtype)
+        km = IntSearchResult(torch.from_numpy(in_maps), torch.from_numpy(out_maps), torch.from_numpy(offsets), iden)
+        Y = _explicit_depthwise_forward_logic(X, W, km, len(bc_out))
+        dX, dW = _explicit_depthwise_backward_logic(dY, X, W, km)
+        np.savez_compressed(
+            os.path.join(HERE, f"depthwise_{name}.npz"),
+            in_coords=bc_in, out_coords=bc_out, ksize=np.asarray(ksize, np.int32), stride=np.asarray(stride, np.int32),
+            in_maps=in_maps, out_maps=out_maps, offsets=offsets, identity=np.asarray(-1 if iden is None else iden),
+            X=X.numpy(), W=W.numpy(), dY=dY.numpy(), Y=Y.numpy(), dX=dX.numpy(), dW=dW.numpy(),
+        )
+        print("depthwise", name, "pairs", offsets[-1])
+
+    s = scene_u(600, 1)
+    run_case("u600_c64_f32", s, s, (3, 3, 3), (1, 1, 1), 64, torch.float32, True, 21)
+    run_case("u600_c64_f64", s, s, (3, 3, 3), (1, 1, 1), 64, torch.float64, True, 21)
+    s2 = np.concatenate([scene_u(300, 2, 0), scene_u(400, 3, 1)], 0)
+    run_case("b2_c13_f32_noiden", s2, s2, (3, 3, 3), (1, 1, 1), 13, torch.float32, False, 22)
+    coarse, _ = kmap.stride_coords(s, (2, 2, 2))
+    run_case("stride2_k2_c32_f32", s, coarse, (2, 2, 2), (2, 2, 2), 32, torch.float32, False, 23)
+
+    init = {}
+    for name, kwargs in [("c64_k3", dict(channels=64, kernel_size=3)),
+                         ("c32_k2_s2_tr", dict(channels=32, kernel_size=2, stride=2, transposed=True))]:
+        torch.manual_seed(0)
+        m = SparseDepthwiseConv3d(**kwargs)
+        init[name + "_weight"] = m.weight.detach().numpy()
+        init[name + "_bias"] = m.bias.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "module_init_depthwise.npz"), **init)
+    print("done (depthwise)")
+
+
 def main():
     import_reference()
     from warpconvnet.geometry.coords.search.cache import IntSearchCacheKey
@@ -206,4 +257,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "depthwise":
+        main_depthwise()  # only the (g) fixtures; the others are left untouched
+    else:
+        main()
+        main_depthwise()

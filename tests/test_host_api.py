@@ -174,3 +174,42 @@ def test_one_by_one_conv_and_errors():
         SparseConv3d(4, 8, 3)(v)
     with pytest.raises(NotImplementedError):
         SparseConv3d(4, 8, 3, generative=True)(v)
+
+
+# ---- depthwise (CPU: explicit backend) -----------------------------------------------------------------------------
+def test_depthwise_module_init_matches_reference_state_dict(golden_dir):
+    from warpconvnet_amd.nn.modules.sparse_conv_depth import SparseDepthwiseConv3d
+
+    g = np.load(os.path.join(golden_dir, "module_init_depthwise.npz"))
+    for name, kwargs in [("c64_k3", dict(channels=64, kernel_size=3)),
+                         ("c32_k2_s2_tr", dict(channels=32, kernel_size=2, stride=2, transposed=True))]:
+        torch.manual_seed(0)
+        m = SparseDepthwiseConv3d(**kwargs)
+        np.testing.assert_array_equal(m.weight.detach().numpy(), g[name + "_weight"])
+        np.testing.assert_array_equal(m.bias.detach().numpy(), g[name + "_bias"])
+        assert m.weight.shape == (int(np.prod(m.kernel_size)), kwargs["channels"])
+
+
+@pytest.mark.parametrize("name", ["depthwise_u600_c64_f32.npz", "depthwise_u600_c64_f64.npz", "depthwise_b2_c13_f32_noiden.npz",
+                                  "depthwise_stride2_k2_c32_f32.npz"])
+def test_depthwise_explicit_backend_matches_golden(golden_dir, name):
+    """CPU tensors take the explicit backend; autograd function == the reference's explicit depthwise outputs."""
+    from warpconvnet_amd.nn.functional.sparse_conv_depth import spatially_sparse_depthwise_conv
+
+    g = np.load(os.path.join(golden_dir, name))
+    iden = int(g["identity"])
+    km = IntSearchResult(torch.from_numpy(g["in_maps"]), torch.from_numpy(g["out_maps"]), torch.from_numpy(g["offsets"]),
+                         None if iden < 0 else iden)
+    X = torch.from_numpy(g["X"]).requires_grad_(True)
+    W = torch.from_numpy(g["W"]).requires_grad_(True)
+    Y = spatially_sparse_depthwise_conv(X, W, km, g["out_coords"].shape[0], fwd_algo="auto", bwd_algo="explicit_gemm")
+    Y.backward(torch.from_numpy(g["dY"]))
+    tol = 1e-12 if g["X"].dtype == np.float64 else 1e-6
+    for got, want in ((Y.detach(), g["Y"]), (X.grad, g["dX"]), (W.grad, g["dW"])):
+        want = torch.from_numpy(want)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        spatially_sparse_depthwise_conv(X, W, km, g["out_coords"].shape[0], fwd_algo="implicit")
+    with pytest.raises(ValueError):
+        spatially_sparse_depthwise_conv(X, W[:, :-1], km, g["out_coords"].shape[0])

@@ -43,6 +43,21 @@ def test_conv_oracle_matches_reference_explicit(golden_dir, name):
         assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "depthwise_*.npz"))))
+def test_depthwise_oracle_matches_reference_explicit(golden_dir, name):
+    """oracle.conv.depthwise_* vs the reference's `_explicit_depthwise_{forward,backward}_logic` outputs."""
+    g = _load(golden_dir, name)
+    iden = int(g["identity"])
+    iden = None if iden < 0 else iden
+    Y = conv.depthwise_forward(g["X"], g["W"], g["in_maps"], g["out_maps"], g["offsets"], g["out_coords"].shape[0], iden)
+    dX, dW = conv.depthwise_backward(g["dY"], g["X"], g["W"], g["in_maps"], g["out_maps"], g["offsets"], iden)
+    tol = 1e-12 if g["X"].dtype == np.float64 else 1e-6
+    for got, want in ((Y, g["Y"]), (dX, g["dX"]), (dW, g["dW"])):
+        want = torch.from_numpy(want)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+
+
 def test_kmap_oracle_reproduces_golden_maps(golden_dir):
     """The maps stored in the fixtures were made by the brute-force builder; the C restatement must agree."""
     for name in ("explicit_u2048_16x32_f32.npz", "explicit_b2_7x13_f32_noiden.npz", "explicit_stride2_k2_16x32_f32.npz"):

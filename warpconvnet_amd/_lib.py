@@ -80,6 +80,16 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
          c_int32, c_int32, c_void_p, c_size_t, c_void_p],
     ),
+    "wcn_dwconv_gather": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    ),
+    "wcn_dwconv_wgrad_workspace": (c_size_t, [c_int32, c_int32]),
+    "wcn_dwconv_wgrad": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+         c_void_p, c_size_t, c_void_p],
+    ),
     "wcn_mfma_wgrad_bias_supported": (c_int, [c_int32, c_int32, c_int32]),
     "wcn_conv_wgrad_bias": (
         c_int,

@@ -50,3 +50,8 @@ def get_fp16_accum() -> bool:
 def set_fp16_accum(enabled: bool) -> None:
     global _USE_FP16_ACCUM
     _USE_FP16_ACCUM = bool(enabled)
+
+# Depthwise convolution backends (reference `constants.py:159-172`; generic names are accepted as aliases)
+VALID_DEPTHWISE_ALGOS = ["explicit", "implicit", "explicit_gemm", "implicit_gemm", "auto"]
+WARPCONVNET_DEPTHWISE_CONV_FWD_ALGO_MODE = _env_choice("WARPCONVNET_DEPTHWISE_CONV_FWD_ALGO_MODE", "auto", VALID_DEPTHWISE_ALGOS)
+WARPCONVNET_DEPTHWISE_CONV_BWD_ALGO_MODE = _env_choice("WARPCONVNET_DEPTHWISE_CONV_BWD_ALGO_MODE", "auto", VALID_DEPTHWISE_ALGOS)

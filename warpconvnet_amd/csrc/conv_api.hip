@@ -23,6 +23,12 @@ bool mfma_wgrad_bias_supported(int cin, int cout, int dtype);
 int conv_wgrad_mfma(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                     const int32_t* offsets, int cin, int cout, int K, int dtype, void* workspace, size_t workspace_bytes,
                     int cs_k, float* bias_grad, hipStream_t s);
+// dwconv.hip
+int dwconv_gather(const void* in, const void* w, void* out, const int32_t* tbl, const float* bias, int64_t n_out, int C,
+                  int K, int dtype, int k_flip, hipStream_t s);
+size_t dwconv_wgrad_workspace(int K, int C);
+int dwconv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                 const int32_t* offsets, int C, int K, int dtype, void* workspace, size_t workspace_bytes, hipStream_t s);
 }  // namespace wcn
 
 using namespace wcn;
@@ -117,6 +123,28 @@ int wcn_conv_wgrad_bias(const void* x, const void* dy, float* dw, const int32_t*
   if (self_offset < 0 || self_offset >= num_offsets) return WCN_ERROR_INVALID_PARAMETERS;
   return conv_wgrad_mfma(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, workspace, workspace_bytes,
                          self_offset, bias_grad, (hipStream_t)stream);
+}
+
+int wcn_dwconv_gather(const void* in, const void* w, void* out, const int32_t* nbr, const float* bias, int64_t n_in,
+                      int64_t n_out, int32_t channels, int32_t num_offsets, int32_t dtype, int32_t k_flip,
+                      wcn_stream_t stream) {
+  if (n_in < 0 || n_out < 0 || channels < 1 || num_offsets < 1 || !dtype_ok(dtype)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n_out == 0) return WCN_SUCCESS;
+  if (!w || !out || !nbr || (n_in > 0 && !in)) return WCN_ERROR_INVALID_PARAMETERS;
+  return dwconv_gather(in, w, out, nbr, bias, n_out, channels, num_offsets, dtype, k_flip, (hipStream_t)stream);
+}
+
+size_t wcn_dwconv_wgrad_workspace(int32_t num_offsets, int32_t channels) {
+  return (num_offsets > 0 && channels > 0) ? dwconv_wgrad_workspace(num_offsets, channels) : 0;
+}
+
+int wcn_dwconv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
+                     const int32_t* offsets, int64_t n_in, int64_t n_out, int32_t channels, int32_t num_offsets,
+                     int32_t dtype, void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
+  if (n_in < 0 || n_out < 0 || channels < 1 || num_offsets < 1 || !dtype_ok(dtype) || !dw || !offsets)
+    return WCN_ERROR_INVALID_PARAMETERS;
+  return dwconv_wgrad(x, dy, dw, in_maps, out_maps, offsets, channels, num_offsets, dtype, workspace, workspace_bytes,
+                      (hipStream_t)stream);
 }
 
 }  // extern "C"
