@@ -213,3 +213,42 @@ def test_depthwise_explicit_backend_matches_golden(golden_dir, name):
         spatially_sparse_depthwise_conv(X, W, km, g["out_coords"].shape[0], fwd_algo="implicit")
     with pytest.raises(ValueError):
         spatially_sparse_depthwise_conv(X, W[:, :-1], km, g["out_coords"].shape[0])
+
+
+def _grouped_oracle(X, W4, dY, r, n_out, bias=None):
+    """Channel groups = G independent convolutions on channel slices (reference weight layout [K, G, Cin/G, Cout/G])."""
+    from oracle import conv as oconv
+
+    G = W4.shape[1]
+    cg_in, cg_out = X.shape[1] // G, dY.shape[1] // G
+    Ys, dXs, dWs = [], [], []
+    for g in range(G):
+        Xg, Wg, dYg = X[:, g * cg_in:(g + 1) * cg_in], W4[:, g], dY[:, g * cg_out:(g + 1) * cg_out]
+        Ys.append(oconv.forward(Xg, Wg, r["in_maps"], r["out_maps"], r["offsets"], n_out))
+        dx, dw = oconv.backward(dYg, Xg, Wg, r["in_maps"], r["out_maps"], r["offsets"])
+        dXs.append(dx)
+        dWs.append(dw)
+    Y = torch.cat(Ys, 1)
+    if bias is not None:
+        Y = Y + bias
+    return Y, torch.cat(dXs, 1), torch.stack(dWs, 1)
+
+
+def test_grouped_conv_cpu_explicit_module_vs_oracle():
+    """SparseConv3d(groups=4) on CPU tensors (explicit backend) == 4 independent convolutions on channel slices."""
+    bc = scene_u(1500, 9)
+    r = okmap.kernel_map(bc, bc, (3, 3, 3))
+    torch.manual_seed(3)
+    conv = SparseConv3d(16, 24, 3, groups=4, fwd_algo="explicit_gemm", dgrad_algo="explicit_gemm", wgrad_algo="explicit_gemm").double()
+    X = torch.randn(len(bc), 16, dtype=torch.float64, requires_grad=True)
+    km = IntSearchResult(torch.from_numpy(r["in_maps"]), torch.from_numpy(r["out_maps"]), torch.from_numpy(r["offsets"]))
+    from warpconvnet_amd.nn.functional.sparse_conv.detail.unified import UnifiedSpatiallySparseConvFunction
+
+    Y = UnifiedSpatiallySparseConvFunction.apply(X, conv.weight, km, len(bc), "explicit_gemm", "explicit_gemm", "explicit_gemm",
+                                                 None, None, None, None, None, 4, False, conv.bias)
+    dY = torch.randn(len(bc), 24, dtype=torch.float64)
+    Y.backward(dY)
+    Yr, dXr, dWr = _grouped_oracle(X.detach(), conv.weight.detach(), dY, r, len(bc), conv.bias.detach())
+    assert conv.weight.shape == (27, 4, 4, 6)
+    assert (Y.detach() - Yr).abs().max() < 1e-10 and (X.grad - dXr).abs().max() < 1e-10
+    assert (conv.weight.grad - dWr).abs().max() < 1e-10 and (conv.bias.grad - dY.sum(0)).abs().max() < 1e-10

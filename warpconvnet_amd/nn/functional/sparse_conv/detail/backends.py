@@ -6,6 +6,7 @@ Same plug-in interface as the reference (`warpconvnet/nn/functional/sparse_conv/
 ``run_forward`` / ``run_backward``.  Registered names: ``explicit_gemm``, ``hip_ref``, ``hip_mfma``,
 ``auto`` (static shape-class choice between the two HIP paths).
 """
+import dataclasses
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, Optional, Tuple
 
@@ -68,8 +69,6 @@ def _bwd_explicit(ctx: BwdCtx):
 
 def _make_hip_fwd(algo: str) -> FwdFn:
     def fn(ctx: FwdCtx):
-        if ctx.groups != 1:
-            return -1  # WCN_ERROR_PROBLEM_NOT_SUPPORTED: grouped conv is not covered by the HIP kernels yet
         dt = ctx.compute_dtype or ctx.in_features.dtype
         out = hip_gemm.hip_forward(ctx.in_features.to(dt), ctx.weight.to(dt), ctx.kernel_map, ctx.num_out_coords, algo,
                                    bias=ctx.bias)
@@ -80,8 +79,6 @@ def _make_hip_fwd(algo: str) -> FwdFn:
 
 def _make_hip_bwd(algo: str) -> BwdFn:
     def fn(ctx: BwdCtx):
-        if ctx.groups != 1:
-            return -1, None
         dt = ctx.compute_dtype or ctx.in_features.dtype
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dy = ctx.grad_output.to(dt)
@@ -118,11 +115,30 @@ BACKWARD_BACKENDS: Dict[str, BwdFn] = {
 }
 
 
+def _group_slices(t: Tensor, groups: int, g: int) -> Tensor:
+    c = t.shape[1] // groups
+    return t[:, g * c : (g + 1) * c].contiguous()
+
+
 def run_forward(algo: str, ctx: FwdCtx):
     try:
         fn = FORWARD_BACKENDS[algo]
     except KeyError:
         raise ValueError(f"Unsupported forward algorithm: {algo}")
+    if ctx.groups > 1:
+        # Channel groups (weight [K, G, Cin/G, Cout/G], reference sparse_conv.py:147-157): G independent problems on
+        # channel slices, same kernel map.  Slices are made contiguous (the kernels take dense [N, C] rows).
+        G = ctx.groups
+        outs = []
+        for g in range(G):
+            sub = dataclasses.replace(
+                ctx, in_features=_group_slices(ctx.in_features, G, g), weight=ctx.weight[:, g].contiguous(), groups=1,
+                bias=None if ctx.bias is None else ctx.bias.reshape(G, -1)[g].contiguous())
+            r = fn(sub)
+            if isinstance(r, int) and r != 0:
+                raise RuntimeError(f"{algo} fwd error: {_lib.status_string(r)}")
+            outs.append(r)
+        return torch.cat(outs, dim=1)
     result = fn(ctx)
     if isinstance(result, int) and result != 0:
         raise RuntimeError(f"{algo} fwd error: {_lib.status_string(result)}")
@@ -134,6 +150,23 @@ def run_backward(algo: str, ctx: BwdCtx):
         fn = BACKWARD_BACKENDS[algo]
     except KeyError:
         raise ValueError(f"Unsupported backward algorithm: {algo}")
+    if ctx.groups > 1:
+        G = ctx.groups
+        dxs, dws, dbs = [], [], []
+        for g in range(G):
+            sub = dataclasses.replace(
+                ctx, grad_output=_group_slices(ctx.grad_output, G, g), in_features=_group_slices(ctx.in_features, G, g),
+                weight=ctx.weight[:, g].contiguous(), groups=1, bias_grad=None)
+            dx, dw = fn(sub)
+            if isinstance(dx, int) and dx != 0:
+                raise RuntimeError(f"{algo} bwd error: {_lib.status_string(dx)}")
+            dxs.append(dx)
+            dws.append(dw)
+            dbs.append(sub.bias_grad)
+        dx = torch.cat(dxs, dim=1) if dxs[0] is not None else None
+        dw = torch.stack(dws, dim=1) if dws[0] is not None else None  # [K, G, Cin/G, Cout/G]
+        ctx.bias_grad = torch.cat(dbs) if all(b is not None for b in dbs) else None
+        return dx, dw
     result = fn(ctx)
     if isinstance(result[0], int) and result[0] != 0:
         raise RuntimeError(f"{algo} bwd error: {_lib.status_string(result[0])}")

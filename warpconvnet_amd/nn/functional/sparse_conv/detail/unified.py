@@ -121,7 +121,7 @@ class UnifiedSpatiallySparseConvFunction(Function):
 
                 grad_b = hip_colsum(grad_output.contiguous())
             else:
-                grad_b = grad_output.float().sum(0)
+                grad_b = grad_output.sum(0, dtype=torch.float64 if grad_output.dtype == torch.float64 else torch.float32)
         ctx.kernel_map = None  # release eagerly (reference unified.py:779-783)
         out = list(_pad_values(15, grad_in, grad_w))
         out[14] = grad_b
