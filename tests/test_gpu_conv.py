@@ -119,6 +119,33 @@ def test_wgrad_fused_bias_grad(dtype, cin, cout):
     assert dbd is None
 
 
+@pytest.mark.parametrize("ksize,stride,cin,cout", [((5, 5, 5), (1, 1, 1), 32, 64), ((5, 5, 5), (1, 1, 1), 64, 128),
+                                                    ((4, 4, 4), (2, 2, 2), 64, 64), ((7, 7, 7), (1, 1, 1), 32, 32)])
+def test_mfma_large_kernel_volumes(ksize, stride, cin, cout):
+    """K = 125 / 64 / 343 > 32: multi-word masks, one pass of the fused kernel per mask word (hip_mfma forced)."""
+    from warpconvnet_amd import _lib
+
+    dtype = torch.bfloat16
+    s_in = np.concatenate([scene_u(1500, 61, 0), scene_u(700, 62, 1)], 0)
+    same = all(v == 1 for v in stride)
+    s_out = s_in if same else okmap.stride_coords(s_in, stride)[0]
+    km = _kmap(s_in, s_out, ksize, stride, same=same)
+    r = okmap.kernel_map(s_in, s_out, ksize, stride)
+    K = int(np.prod(ksize))
+    np.testing.assert_array_equal(km.offsets.numpy(), r["offsets"])
+    assert _lib.lib().wcn_mfma_gather_supported(cin, cout, K, _lib.WCN_BF16) and km._mask.shape[1] == (K + 31) // 32
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(K + cin)
+    X = torch.randn(len(s_in), cin, generator=g).to(dev, dtype)
+    W = (torch.randn(K, cin, cout, generator=g) * 0.03).to(dev, dtype)
+    dY = torch.randn(len(s_out), cout, generator=g).to(dev, dtype)
+    Y, dX, dW = _run_all(km, X, W, dY, "hip_mfma", len(s_in), len(s_out))
+    Yr, dXr, dWr = _oracle(r, X, W, dY, len(s_out))
+    assert rel_max_err(Y, Yr) < TOL[dtype]
+    assert rel_max_err(dX, dXr) < TOL[dtype]
+    assert rel_max_err(dW, dWr) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype,cin,cout,groups", [(torch.bfloat16, 128, 256, 2), (torch.float16, 64, 64, 4),
                                                     (torch.float32, 24, 36, 3), (torch.bfloat16, 32, 32, 32)])
 def test_grouped_conv_hip_vs_oracle(dtype, cin, cout, groups):

@@ -48,7 +48,8 @@ template <> struct Frag<_Float16> {
 };
 
 constexpr int kWaves = 4;
-constexpr int kMaxKp = 32;  // fast path covers kernel volumes up to 32 (one mask word)
+constexpr int kMaxKp = 32;  // table columns staged per pass (one mask word)
+constexpr int kMaxK = 1024;  // kernel volumes up to 32 mask words (5^3 = 125 and 7^3 = 343 included)
 
 #ifdef WCN_PROF
 // dev-only phase stamps (wall clock, 10 ns ticks): [wg][8] = {entry, after perm, after slab, loop end, end, steps}
@@ -105,13 +106,13 @@ struct GatherGemm {
   typedef typename Frag<T>::type frag_t;
 };
 
-template <typename T, int CIC, int CO, int RB>
+template <typename T, int CIC, int CO, int RB, bool MULTI>
 __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __restrict__ in, const T* __restrict__ wp,
                                                                T* __restrict__ out, const int32_t* __restrict__ nbr,
                                                                const uint32_t* __restrict__ mask,
                                                                const int32_t* __restrict__ perm,
                                                                const float* __restrict__ bias, int64_t n_out, int cin,
-                                                               int K, int kp) {
+                                                               int K, int kp, int mw) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   typedef typename G::frag_t frag_t;
   constexpr int NS = G::NS, NB = G::NB, RPW = G::ROWS_PER_WAVE, TILE = G::TILE;
@@ -128,22 +129,39 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
   const int64_t row0 = (int64_t)blockIdx.x * TILE;
 
   WCN_STAMP(0);
-  // ---- stage output row ids, neighbour slab and masks ----
-  uint32_t my_mask = 0;
+  // ---- stage output row ids ----
   if (tid < TILE) {
     const int64_t pr = row0 + tid;
     int32_t r = -1;
     if (pr < n_out) r = perm ? perm[pr] : (int32_t)pr;
     s_rows[tid] = r;
-    // thread tid stages row tid, which belongs to wave tid / RPW
-    if (r >= 0) my_mask = mask[r];
   }
   __syncthreads();
   WCN_STAMP(1);
+
+  f32x16 acc[NB][RB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[b][rb][q] = 0.f;
+
+  // Kernel volumes above 32 offsets: one pass per 32-bit mask word - the index slab holds the 32 table columns of the
+  // current word, the accumulators persist across words.  (K <= 32: a single pass, as before.)
+  const int nwords = MULTI ? mw : 1;  // compile-time 1 for K <= 32: the accumulators are then not live during staging
+  for (int word = 0; word < nwords; ++word) {
+  const int kbase = word * 32;
+  const int kpw = (kp - kbase) < kMaxKp ? (kp - kbase) : kMaxKp;  // table columns staged for this word
+  uint32_t my_mask = 0;
+  if (tid < TILE) {
+    const int32_t r = s_rows[tid];
+    if (r >= 0) my_mask = mask[(int64_t)r * mw + word];  // thread tid stages row tid, which belongs to wave tid / RPW
+  }
   {
     // all row ids first, then all table loads, then all LDS writes: written as one loop, every s_rows read is ordered
     // behind the previous s_nbr write (same LDS array) and the global round trips serialise
-    const int vec_per_row = kp >> 2;
+    const int vec_per_row = kpw >> 2;
     constexpr int kIter = TILE * (kMaxKp / 4) / 256;
     int32_t rr[kIter];
     int4 vv[kIter];
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
       vv[t] = make_int4(-1, -1, -1, -1);
       if (rr[t] >= 0) {  // read once: non-temporal
         typedef __attribute__((ext_vector_type(4))) int i32x4;
-        const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * kp) + c);
+        const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * kp + kbase) + c);
         vv[t] = make_int4(q.x, q.y, q.z, q.w);
       }
     }
@@ -167,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
     for (int t = 0; t < kIter; ++t) {
       const int e = tid + t * 256;
       const int i = e / vec_per_row, c = e - i * vec_per_row;
-      if (e < TILE * vec_per_row) reinterpret_cast<int4*>(s_nbr + i * kp)[c] = vv[t];
+      if (e < TILE * vec_per_row) reinterpret_cast<int4*>(s_nbr + i * kpw)[c] = vv[t];
     }
   }
   // OR-reduce masks: rows of wave w are [w*RPW, (w+1)*RPW)
@@ -180,18 +198,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
   WCN_STAMP(2);
   WCN_STAMPV(5, (unsigned long long)__builtin_popcount(block_mask));
 
-  f32x16 acc[NB][RB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[b][rb][q] = 0.f;
-
   if (block_mask != 0u) {
     // ---- helpers ----
     auto dma_weights = [&](int buf, int k, int chunk) {
-      const T* src = wp + ((int64_t)k * nchunk + chunk) * G::SLAB_ELEMS;
+      const T* src = wp + ((int64_t)(kbase + k) * nchunk + chunk) * G::SLAB_ELEMS;
       char* dst = reinterpret_cast<char*>(s_w) + (size_t)buf * G::SLAB_BYTES;
 #pragma unroll
       for (int it = 0; it < (G::DMA_UNITS + kWaves - 1) / kWaves; ++it) {
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const int i = wave * RPW + rb * 32 + n;
-        int32_t idx = s_nbr[i * kp + k];
+        int32_t idx = s_nbr[i * kpw + k];
 #ifdef WCN_ABL_LOCAL
         if (idx >= 0) idx &= 1023;  // dev ablation: all gathers hit a 128 KB window
 #endif
@@ -307,6 +317,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
       for (int q = 0; q < 4; ++q) g_prof2[blockIdx.x * 4 + q] = 2 * pq[q];  // only even half-steps are timed
 #endif
   }
+  __syncthreads();  // the slab and the mask words are rewritten by the next pass
+  }  // word
 
   WCN_STAMP(3);
   // ---- epilogue: lane (h, n) holds out channels h*CO/2 + 16*b + q of row (rb, n).  Storing that straight to HBM
@@ -377,17 +389,23 @@ static int launch_gather_gemm(const void* in, const void* wp, void* out, const i
                               const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, hipStream_t s) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   const int kp = wcn_kmap_row_pitch(K);
-  auto kern = gather_gemm_mfma_kernel<T, CIC, CO, RB>;
+  const int mw = wcn_kmap_mask_words(K);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)G::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_mfma_kernel<T, CIC, CO, RB, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_mfma_kernel<T, CIC, CO, RB, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
       return WCN_ERROR_KERNEL_INITIALIZATION;
     attr_set = true;
   }
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm,
-                     bias, n_out, cin, K, kp);
+  if (mw == 1)
+    hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, false>), dim3(grid), dim3(256), G::LDS_BYTES, s,
+                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, mw);
+  else
+    hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, true>), dim3(grid), dim3(256), G::LDS_BYTES, s,
+                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, mw);
   return launch_status();
 }
 
@@ -414,7 +432,7 @@ int mfma_chunk_for(int cin) {
 
 bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
   if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
-  if (K < 1 || K > kMaxKp) return false;
+  if (K < 1 || K > kMaxK) return false;
   if (mfma_chunk_for(cin) == 0) return false;
   return cout == 32 || cout == 64 || cout == 96 || cout == 128 || cout == 192 || cout == 256;
 }
