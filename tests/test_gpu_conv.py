@@ -381,3 +381,41 @@ def test_full_size_properties():
     assert torch.equal(hip_gemm.hip_forward(X, W, km, N, "hip_mfma"), Y)
     assert torch.equal(hip_gemm.hip_dgrad(dY, W, km, N, "hip_mfma"), dX)
     assert torch.equal(hip_gemm.hip_wgrad(X, dY, km, (27, 64, 128), "hip_mfma"), dW)
+
+
+def test_feature_tensors_above_2gib_use_64bit_offsets():
+    """A [4.6 M, 256] bf16 feature tensor is 2.36 GB: row * C * 2 exceeds 2^31 for the upper rows.  The reference computes
+    that gather address in 32-bit int (warpgemm_a_loader_precomputed.cuh:16-17, 103); here every row offset is 64-bit.
+    1x1x1 kernel (K = 1) over all rows, so the expected output is a plain matmul; forward, dgrad and wgrad are checked on
+    the rows beyond the 2 GiB boundary."""
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    dev, dtype = _dev(), torch.bfloat16
+    N, cin, cout = 4_600_000, 256, 64
+    # distinct coordinates on a line; the map of a 1x1x1 kernel is the identity on rows
+    coords = torch.zeros(N, 4, dtype=torch.int32)
+    idx = torch.arange(N, dtype=torch.int64)
+    coords[:, 1], coords[:, 2], coords[:, 3] = (idx % 4096).int(), ((idx // 4096) % 4096).int(), (idx // (4096 * 4096)).int()
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+    c = coords.to(dev)
+    km = generate_kernel_map(c, c, (1, 1, 1), (1, 1, 1))
+    assert int(km.offsets[-1]) == N
+    g = torch.Generator().manual_seed(7)
+    X = torch.empty(N, cin, dtype=dtype, device=dev)
+    assert X.numel() * X.element_size() > 2**31
+    X.copy_(torch.randn(1024, cin, generator=g).to(dev, dtype).repeat(N // 1024 + 1, 1)[:N])
+    X[-1000:] = torch.randn(1000, cin, generator=g).to(dev, dtype)  # the tail is not a repeat of the head
+    W = (torch.randn(1, cin, cout, generator=g) * 0.05).to(dev, dtype)
+    Y = hip_gemm.hip_forward(X, W, km, N, "hip_mfma")
+    tail = slice(N - 4096, N)
+    assert rel_max_err(Y[tail], X[tail].float() @ W[0].float()) < 2e-2
+    dY = torch.empty(N, cout, dtype=dtype, device=dev)
+    dY.copy_(torch.randn(1024, cout, generator=g).to(dev, dtype).repeat(N // 1024 + 1, 1)[:N])
+    dX = hip_gemm.hip_dgrad(dY, W, km, N, "hip_mfma")
+    assert rel_max_err(dX[tail], dY[tail].float() @ W[0].float().T) < 2e-2
+    dW = hip_gemm.hip_wgrad(X, dY, km, (1, cin, cout), "hip_mfma")
+    ref = torch.zeros(cin, cout, dtype=torch.float64, device=dev)
+    for a in range(0, N, 1 << 20):
+        ref += X[a:a + (1 << 20)].double().T @ dY[a:a + (1 << 20)].double()
+    assert rel_max_err(dW[0], ref) < 2e-2
