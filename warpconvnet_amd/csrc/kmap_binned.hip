@@ -70,7 +70,7 @@ __global__ void bin_prepare_kernel(uint4* __restrict__ slots, int64_t capacity) 
 // pass 1a: create the block entries (CAS only on first touch; everybody else just reads) and remember the slot
 __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, const int4* __restrict__ coords, int64_t n,
                                   int32_t* __restrict__ vox_slot, int32_t* __restrict__ blk_slot,
-                                  int32_t* __restrict__ slot_id, int32_t* __restrict__ nblk,
+                                  int32_t* __restrict__ slot_id, int32_t* __restrict__ nblk, int32_t* __restrict__ cnt,
                                   int32_t* __restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -92,6 +92,10 @@ __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, cons
         const int id = atomicAdd(nblk, 1);
         blk_slot[id] = (int)s;
         slot_id[s] = id;  // read by the NEXT kernels only
+        // the block's position counters, used by bin_count (next kernel): cleared here by the one thread that created
+        // the block instead of a worst-case 32 MB memset (the block count is only known on the device)
+        reinterpret_cast<int4*>(cnt + (int64_t)id * (2 * kSub))[0] = make_int4(0, 0, 0, 0);
+        reinterpret_cast<int4*>(cnt + (int64_t)id * (2 * kSub))[1] = make_int4(0, 0, 0, 0);
         found = (int)s;
         break;
       }
@@ -422,10 +426,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   const uint32_t cmask = (uint32_t)(capacity - 1);
   const unsigned gn = (unsigned)ceil_div(n, 256);
   hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n, w.vox_slot,
-                     w.blk_slot, w.slot_id, w.nblk, status);
-  // counters of the blocks that exist: cnt[nblk][8]; nblk is only known on the device, so clear the worst case lazily:
-  // a block has at least one voxel, hence nblk <= n and the first n*8 ints cover every id
-  if (hipMemsetAsync(w.cnt, 0, (size_t)n * 2 * kSub * 4, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
+                     w.blk_slot, w.slot_id, w.nblk, w.cnt, status);
   hipLaunchKernelGGL(bin_count_kernel, dim3(gn), dim3(256), 0, s, (const int4*)coords, n, g.hx, g.hy, g.hz,
                      (const int32_t*)w.vox_slot, (const int32_t*)w.slot_id, w.cnt, w.vox_pos, status);
   hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, (const int32_t*)w.cnt, (const int32_t*)w.nblk, n,

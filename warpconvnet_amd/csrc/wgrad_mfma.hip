@@ -27,7 +27,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kWgradGrid = 512;   // G: pair ranges (2 workgroups per CU)
 constexpr int kPairs = 64;        // pairs per pipeline step
-constexpr int kZeroPage = 1024;   // bytes of zeros at the start of the workspace (source for padded pairs)
+constexpr int kZeroPage = 1024;   // bytes reserved at the start of the workspace (kept for layout compatibility)
+__device__ uint4 g_wgrad_zero_page[64];  // 1 KiB of zeros: source rows of padded pairs (no per-call memset)
 
 template <typename T> struct WFrag;
 template <> struct WFrag<__bf16> {
@@ -385,10 +386,10 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
     }
     attr_set = true;
   }
-  char* zero_page = (char*)workspace;
+  char* zero_page = nullptr;
+  if (hipGetSymbolAddress((void**)&zero_page, HIP_SYMBOL(g_wgrad_zero_page)) != hipSuccess) return WCN_ERROR_KERNEL_INITIALIZATION;
   float* slabs = (float*)((char*)workspace + kZeroPage);
   float* cs_slabs = slabs + (size_t)(kWgradGrid + K) * cin * cout;
-  if (hipMemsetAsync(zero_page, 0, kZeroPage, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
   const dim3 grid(kWgradGrid, (cin / CIT) * (cout / COT));
   if (bias_grad) {
     if constexpr (W::GRID) {
