@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--voxels", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)  # the whole configs[1] scene: ~10-15 s of CPU work
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -234,6 +234,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
             },
+            "roofline_all": {name: {"achieved": round(b / (ms * 1e-3) / 1e9, 1), "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(b)}
+                             for name, (ms, b) in {**kernels, "kernel map build (~20 launches)": (t_kmap, ab["kmap"])}.items()},
             "phases_ms": {"kmap": round(t_kmap, 4), "fwd": round(t_fwd, 4), "dgrad": round(t_dgrad, 4), "wgrad": round(t_wgrad, 4),
                           "fwd_kernel_only": round(tk_fwd, 4), "dgrad_kernel_only": round(tk_dgrad, 4)},
             "whole_step_hbm_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
