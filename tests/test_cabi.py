@@ -38,7 +38,8 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_mfma_gather_supported(64, 128, 27, _lib.WCN_BF16) == 1
     assert L.wcn_mfma_gather_supported(64, 128, 27, _lib.WCN_F32) == 0
     assert L.wcn_mfma_gather_supported(7, 13, 27, _lib.WCN_BF16) == 0
-    assert L.wcn_mfma_gather_supported(64, 128, 125, _lib.WCN_BF16) == 0
+    assert L.wcn_mfma_gather_supported(64, 128, 125, _lib.WCN_BF16) == 1  # multi-word masks
+    assert L.wcn_mfma_gather_supported(64, 128, 2000, _lib.WCN_BF16) == 0
     assert L.wcn_mfma_wgrad_supported(64, 128, _lib.WCN_F16) == 1 and L.wcn_mfma_wgrad_supported(96, 32, _lib.WCN_F16) == 1
     assert L.wcn_mfma_wgrad_supported(48, 64, _lib.WCN_F16) == 0 and L.wcn_mfma_wgrad_supported(64, 64, _lib.WCN_F32) == 0
     assert L.wcn_mfma_gather_supported(64, 192, 27, _lib.WCN_BF16) == 1
