@@ -60,7 +60,7 @@ __device__ __forceinline__ int block_find(const Slot* __restrict__ slots, uint32
 // 4 sub-counters for BOUNDARY voxels then 4 for INTERIOR voxels.  Same-address atomics serialise (~280 ns each,
 // ~455 voxels per 16^3 block on the uniform scene), so spreading a block's voxels over 4 counters per class cuts the
 // critical path 4x; the sub-counter is chosen by the voxel's row index.
-constexpr int kSub = 4;
+constexpr int kSub = 8;  // sub-counters per (block, class): spreads the same-address atomics of bin_count
 
 __global__ void bin_prepare_kernel(uint4* __restrict__ slots, int64_t capacity) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,8 +94,9 @@ __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, cons
         slot_id[s] = id;  // read by the NEXT kernels only
         // the block's position counters, used by bin_count (next kernel): cleared here by the one thread that created
         // the block instead of a worst-case 32 MB memset (the block count is only known on the device)
-        reinterpret_cast<int4*>(cnt + (int64_t)id * (2 * kSub))[0] = make_int4(0, 0, 0, 0);
-        reinterpret_cast<int4*>(cnt + (int64_t)id * (2 * kSub))[1] = make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < (2 * kSub) / 4; ++q)
+          reinterpret_cast<int4*>(cnt + (int64_t)id * (2 * kSub))[q] = make_int4(0, 0, 0, 0);
         found = (int)s;
         break;
       }
@@ -128,16 +129,18 @@ __global__ void bin_count_kernel(const int4* __restrict__ coords, int64_t n, int
 }
 
 // pass 2: bin size and boundary count per block
-__global__ void bin_assign_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ nblk, int64_t max_blocks,
+__global__ void bin_assign_kernel(int32_t* __restrict__ cnt, const int32_t* __restrict__ nblk, int64_t max_blocks,
                                   int32_t* __restrict__ blk_cnt, int32_t* __restrict__ blk_bnd) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= max_blocks || id >= *nblk) return;
-  const int32_t* c = cnt + id * (2 * kSub);
+  int32_t* c = cnt + id * (2 * kSub);
   int bnd = 0, tot = 0;
 #pragma unroll
   for (int g = 0; g < 2 * kSub; ++g) {
-    tot += c[g];
-    if (g < kSub) bnd += c[g];
+    const int v = c[g];
+    c[g] = tot;  // exclusive prefix over the groups: bin_scatter adds it to the position inside the group
+    tot += v;
+    if (g < kSub) bnd += v;
   }
   blk_cnt[id] = tot;
   blk_bnd[id] = bnd;
@@ -185,11 +188,8 @@ __global__ void bin_scatter_kernel(const int32_t* __restrict__ slot_id, const in
   const int4 c = coords[i];
   const int p = vox_pos[i];
   const int group = p >> 24;
-  int local = p & 0xFFFFFF;  // groups are laid out in order: boundary sub-bins 0..3, then interior sub-bins 0..3
-  const int32_t* cc = cnt + (int64_t)id * (2 * kSub);
-#pragma unroll
-  for (int g = 0; g < 2 * kSub; ++g)
-    if (g < group) local += cc[g];
+  // groups are laid out in order: boundary sub-bins, then interior sub-bins; cnt holds their exclusive prefix
+  const int local = (p & 0xFFFFFF) + cnt[(int64_t)id * (2 * kSub) + group];
   binned[blk_off[id] + local] = make_int4(c.y, c.z, c.w, (int)i);
 }
 
@@ -429,7 +429,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
                      w.blk_slot, w.slot_id, w.nblk, w.cnt, status);
   hipLaunchKernelGGL(bin_count_kernel, dim3(gn), dim3(256), 0, s, (const int4*)coords, n, g.hx, g.hy, g.hz,
                      (const int32_t*)w.vox_slot, (const int32_t*)w.slot_id, w.cnt, w.vox_pos, status);
-  hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, (const int32_t*)w.cnt, (const int32_t*)w.nblk, n,
+  hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, w.cnt, (const int32_t*)w.nblk, n,
                      w.blk_cnt, w.blk_bnd);
   hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)w.blk_cnt, (const int32_t*)w.nblk,
                      w.blk_off);
