@@ -182,6 +182,15 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
                          int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
                          int32_t algo, int32_t w_transposed, int32_t k_flip, wcn_stream_t stream);
 
+/* As wcn_conv_gather_gemm with algo = WCN_ALGO_MFMA, but the result is written as fp32 straight from the fp32
+ * accumulators (in / w_packed are WCN_F16 or WCN_BF16).  Used for fp32 feature tensors: operands are cast to fp16 with
+ * an exact power-of-two rescale by the caller, the product is scaled back in fp32 - the reference's production
+ * treatment of fp32 inputs (warpconvnet/nn/functional/sparse_conv/detail/mask_gemm.py:72-103, 696-745). */
+int wcn_conv_gather_gemm_f32out(const void* in, const void* w_packed, float* out, const int32_t* nbr,
+                                const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_in,
+                                int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
+                                wcn_stream_t stream);
+
 /* out[c] = sum_r in[r][c] in fp32 (bias gradient; reference: autograd of `out + bias`, helper.py:339-342).
  * Deterministic two-pass reduction; workspace: wcn_colsum_workspace(channels) bytes. */
 size_t wcn_colsum_workspace(int32_t channels);

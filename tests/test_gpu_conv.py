@@ -119,6 +119,35 @@ def test_wgrad_fused_bias_grad(dtype, cin, cout):
     assert dbd is None
 
 
+@pytest.mark.parametrize("scale", [1.0, 3.0e5])
+def test_fp32_features_take_fp16_operand_kernels(scale):
+    """fp32 features under `auto`: fp16 operands (exact power-of-two rescale beyond the fp16 range), fp32 accumulation and
+    output - the reference's production treatment (mask_gemm.py:72-103); tolerance of its fp32 tests (1e-3).
+    grad_output at 3e5 is the GradScaler case the reference documents: finite in, finite out."""
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    s = np.concatenate([scene_u(3000, 71, 0), scene_u(900, 72, 1)], 0)
+    km = _kmap(s, s, (3, 3, 3), same=True)
+    r = okmap.kernel_map(s, s, (3, 3, 3))
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    X = (torch.randn(len(s), 64, generator=g) * scale).to(dev)
+    W = (torch.randn(27, 64, 128, generator=g) * 0.05).to(dev)
+    dY = (torch.randn(len(s), 128, generator=g) * scale).to(dev)
+    Y, dX, dW = _run_all(km, X, W, dY, "auto", len(s), len(s))
+    assert Y.dtype == torch.float32 and dX.dtype == torch.float32 and dW.dtype == torch.float32
+    assert torch.isfinite(Y).all() and torch.isfinite(dX).all() and torch.isfinite(dW).all()
+    Yr, dXr, dWr = _oracle(r, X, W, dY, len(s))
+    assert rel_max_err(Y, Yr) < 1e-3 and rel_max_err(dX, dXr) < 1e-3 and rel_max_err(dW, dWr) < 1e-3
+    # hip_ref keeps fp32 operands: an order of magnitude closer
+    Y2, dX2, dW2 = _run_all(km, X, W, dY, "hip_ref", len(s), len(s))
+    assert rel_max_err(Y2, Yr) < 1e-5 and rel_max_err(dX2, dXr) < 1e-5 and rel_max_err(dW2, dWr) < 1e-4
+    # the scale is a power of two, computed on the device
+    x16, sc = hip_gemm.fp16_safe_cast(X)
+    assert x16.dtype == torch.float16 and float(torch.log2(sc)) == round(float(torch.log2(sc)))
+    assert torch.equal(x16.float() * sc, (X / sc).half().float() * sc)
+
+
 @pytest.mark.parametrize("ksize,stride,cin,cout", [((5, 5, 5), (1, 1, 1), 32, 64), ((5, 5, 5), (1, 1, 1), 64, 128),
                                                     ((4, 4, 4), (2, 2, 2), 64, 64), ((7, 7, 7), (1, 1, 1), 32, 32)])
 def test_mfma_large_kernel_volumes(ksize, stride, cin, cout):

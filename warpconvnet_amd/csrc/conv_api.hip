@@ -13,7 +13,7 @@ int conv_wgrad_ref(const void* x, const void* dy, float* dw, const int32_t* in_m
 bool mfma_gather_supported(int cin, int cout, int K, int dtype);
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                           const int32_t* perm, const float* bias, int64_t n_out, int cin, int cout, int K, int dtype,
-                          hipStream_t s);
+                          float* out32, hipStream_t s);
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s);
 // wgrad_mfma.hip
@@ -72,11 +72,22 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
     case WCN_ALGO_MFMA:
       // `w` must be the packed image (wcn_pack_weight already applied transpose / flip)
       if (!mask) return WCN_ERROR_INVALID_PARAMETERS;
-      return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, s);
+      return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, nullptr, s);
     default:
       // AUTO cannot be resolved here because the two algorithms take different weight images.
       return WCN_ERROR_INVALID_PARAMETERS;
   }
+}
+
+int wcn_conv_gather_gemm_f32out(const void* in, const void* w, float* out, const int32_t* nbr, const uint32_t* mask,
+                                const int32_t* perm, const float* bias, int64_t n_in, int64_t n_out, int32_t cin,
+                                int32_t cout, int32_t num_offsets, int32_t dtype, wcn_stream_t stream) {
+  if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || (dtype != WCN_F16 && dtype != WCN_BF16))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  if (n_out == 0) return WCN_SUCCESS;
+  if (!w || !out || !nbr || !mask || (n_in > 0 && !in)) return WCN_ERROR_INVALID_PARAMETERS;
+  return conv_gather_gemm_mfma(in, w, nullptr, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, out,
+                               (hipStream_t)stream);
 }
 
 size_t wcn_colsum_workspace(int32_t channels) { return channels > 0 ? colsum_workspace(channels) : 0; }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
                                                                const uint32_t* __restrict__ mask,
                                                                const int32_t* __restrict__ perm,
                                                                const float* __restrict__ bias, int64_t n_out, int cin,
-                                                               int K, int kp, int mw) {
+                                                               int K, int kp, int mw, float* __restrict__ out32) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   typedef typename G::frag_t frag_t;
   constexpr int NS = G::NS, NB = G::NB, RPW = G::ROWS_PER_WAVE, TILE = G::TILE;
@@ -327,6 +327,29 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
   constexpr int kPitch = CO * 2 + 16;               // bytes; +16 keeps the b128 stage writes conflict-free
   constexpr int kStage = 32 * kPitch;               // one 32-row block per wave
   constexpr bool kStaged = (size_t)kWaves * kStage <= 2 * (size_t)G::SLAB_BYTES + (size_t)TILE * kMaxKp * 4;
+  if (out32) {
+    // fp32 output (the fp32-feature path: fp16 operands, fp32 accumulate, unrounded result): every lane stores its
+    // 16 contiguous channels per block straight from the accumulators
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int32_t r = s_rows[wave * RPW + rb * 32 + n];
+      if (r < 0) continue;
+      float* dst = out32 + (int64_t)r * CO + h * (CO / 2);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float4 o = make_float4(acc[b][rb][4 * v + 0], acc[b][rb][4 * v + 1], acc[b][rb][4 * v + 2], acc[b][rb][4 * v + 3]);
+          if (bias) {
+            const float4 bv = reinterpret_cast<const float4*>(bias + h * (CO / 2) + 16 * b)[v];
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+          }
+          reinterpret_cast<float4*>(dst + 16 * b)[v] = o;
+        }
+      }
+    }
+    return;
+  }
   if (kStaged) __syncthreads();  // the weight / index slabs are dead from here on: reuse them as the stage
   char* stage = smem + wave * kStage;
   constexpr int kLanesPerRow = CO / 8;              // 16-B pieces per output row
@@ -386,7 +409,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 
 template <typename T, int CIC, int CO, int RB>
 static int launch_gather_gemm(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                              const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, hipStream_t s) {
+                              const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, float* out32,
+                              hipStream_t s) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   const int kp = wcn_kmap_row_pitch(K);
   const int mw = wcn_kmap_mask_words(K);
@@ -402,23 +426,24 @@ static int launch_gather_gemm(const void* in, const void* wp, void* out, const i
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
   if (mw == 1)
     hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, false>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, mw);
+                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, mw, out32);
   else
     hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, true>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, mw);
+                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, mw, out32);
   return launch_status();
 }
 
 template <typename T, int CIC>
 static int dispatch_co(int cout, const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                       const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, hipStream_t s) {
+                       const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, float* out32,
+                       hipStream_t s) {
   switch (cout) {
-    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
-    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
-    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
-    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
-    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
-    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
@@ -439,21 +464,22 @@ bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
 
 template <typename T>
 static int dispatch_cic(int cin, int cout, const void* in, const void* wp, void* out, const int32_t* nbr,
-                        const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_out, int K, hipStream_t s) {
+                        const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_out, int K, float* out32,
+                        hipStream_t s) {
   switch (mfma_chunk_for(cin)) {
-    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
-    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
-    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, s);
+    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
 
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                           const int32_t* perm, const float* bias, int64_t n_out, int cin, int cout, int K, int dtype,
-                          hipStream_t s) {
+                          float* out32, hipStream_t s) {
   if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
-  if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, s);
-  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, s);
+  if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, out32, s);
+  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, out32, s);
 }
 
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,

@@ -5,6 +5,12 @@
 * ``auto``     - ``hip_mfma`` when the shape is covered, else ``hip_ref``; a pure function of
   (C_in, C_out, K, dtype), so every rank of a data-parallel job takes the same path.
 
+fp32 feature tensors under ``auto`` / ``hip_mfma`` follow the reference's production treatment
+(`mask_gemm.py:72-103, 696-745, 818-963`): operands are cast to fp16 - rescaled by an exact power of two when their
+magnitude exceeds the fp16 range, computed on the device, no host sync - the matrix cores accumulate in fp32, the
+fused kernels write fp32 results and the product of the operand scales is multiplied back.  ``hip_ref`` /
+``explicit_gemm`` keep full fp32 operands.
+
 Role of the reference's `_mask_gemm_forward_logic` / `_mask_gemm_backward_logic`
 (`warpconvnet/nn/functional/sparse_conv/detail/mask_gemm.py:661-745, 818-963`).
 """
@@ -22,6 +28,26 @@ def _prep(t: Tensor, name: str) -> Tensor:
     t = t.contiguous()
     _lib.require_gpu_tensor(t, name)
     return t
+
+
+_FP16_RESCALE_TARGET = 32768.0
+
+
+def fp16_safe_cast(t: Tensor) -> Tuple[Tensor, Tensor]:
+    """``(t_fp16, scale)`` with ``t == t_fp16 * scale`` exact in the exponent; scale = 2^max(0, ceil(log2(absmax / 32768)))
+    as a 0-dim device tensor (restates the reference's `_fp16_safe_cast`, mask_gemm.py:72-103)."""
+    if t.numel() == 0:
+        return t.half(), torch.ones((), dtype=torch.float32, device=t.device)
+    m = t.abs().max().float()
+    exp = torch.clamp(torch.ceil(torch.log2(m / _FP16_RESCALE_TARGET)), min=0.0)
+    return (t * torch.exp2(-exp)).half(), torch.exp2(exp)
+
+
+def _fp32_via_fp16(algo: str, kin: int, kout: int, K: int, dtype: torch.dtype) -> bool:
+    """fp32 features take the fp16-operand fused kernels when the algorithm allows and the shape is covered."""
+    if dtype != torch.float32 or algo == "hip_ref":
+        return False
+    return bool(_lib.lib().wcn_mfma_gather_supported(kin, kout, K, _lib.WCN_F16))
 
 
 def resolve_gather_algo(algo: str, cin: int, cout: int, K: int, dtype: torch.dtype) -> int:
@@ -63,14 +89,22 @@ def pack_weight(weight: Tensor, transpose: bool, flip: bool) -> Tensor:
 
 def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: Optional[Tensor], n_out: int,
                  cin: int, cout: int, K: int, algo_code: int, transposed: bool, flip: bool,
-                 bias: Optional[Tensor] = None) -> Tensor:
-    out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
+                 bias: Optional[Tensor] = None, f32_out: bool = False) -> Tensor:
+    out = torch.empty((n_out, cout), dtype=torch.float32 if f32_out else inp.dtype, device=inp.device)
     if n_out == 0:
         return out
     if algo_code == _lib.WCN_ALGO_MFMA:
         w_arg = pack_weight(weight, transposed, flip)
     else:
         w_arg = weight
+    if f32_out:
+        _lib.check(
+            _lib.lib().wcn_conv_gather_gemm_f32out(
+                _lib.ptr(inp), _lib.ptr(w_arg), _lib.ptr(out), _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(perm), _lib.ptr(bias),
+                inp.shape[0], n_out, cin, cout, K, _lib.dtype_code(inp.dtype), _lib.stream_handle(inp.device)),
+            "wcn_conv_gather_gemm_f32out",
+        )
+        return out
     _lib.check(
         _lib.lib().wcn_conv_gather_gemm(
             _lib.ptr(inp), _lib.ptr(w_arg), _lib.ptr(out), _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(perm), _lib.ptr(bias),
@@ -96,6 +130,13 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
     assert K == len(kernel_map) and cin == x.shape[1]
     kernel_map.poll()
     attach_tables_from_csr(kernel_map, x.shape[0], num_out_coords)
+    if _fp32_via_fp16(algo, cin, cout, K, x.dtype):
+        x16, sx = fp16_safe_cast(x)
+        w16, sw = fp16_safe_cast(w)
+        y = _gather_gemm(x16, w16, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K,
+                         _lib.WCN_ALGO_MFMA, transposed=False, flip=False, bias=None, f32_out=True)
+        y = y * (sx * sw)  # exact power-of-two multiply-back, no host sync
+        return y if bias is None else y + bias
     code = resolve_gather_algo(algo, cin, cout, K, x.dtype)
     return _gather_gemm(x, w, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K, code,
                         transposed=False, flip=False, bias=bias)
@@ -131,6 +172,12 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
     else:
         tbl, mask, perm = reverse_tables(kernel_map, num_in_coords)
         flip = False
+    if _fp32_via_fp16(algo, cout, cin, K, dy.dtype):
+        g16, sg = fp16_safe_cast(dy)
+        w16, sw = fp16_safe_cast(w)
+        dx = _gather_gemm(g16, w16, tbl, mask, perm, num_in_coords, cout, cin, K, _lib.WCN_ALGO_MFMA, transposed=True,
+                          flip=flip, f32_out=True)
+        return dx * (sg * sw)
     code = resolve_gather_algo(algo, cout, cin, K, dy.dtype)
     return _gather_gemm(dy, w, tbl, mask, perm, num_in_coords, cout, cin, K, code, transposed=True, flip=flip)
 
@@ -149,6 +196,11 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
     K, cin, cout = weight_shape
     dev = x.device
     kernel_map.poll()
+    scale = None
+    if x.dtype == torch.float32 and algo != "hip_ref" and bool(_lib.lib().wcn_mfma_wgrad_supported(cin, cout, _lib.WCN_F16)):
+        x, sx = fp16_safe_cast(x)      # fp16 operands, fp32 accumulate and output; scales multiplied back below
+        dy, sg = fp16_safe_cast(dy)
+        scale = sx * sg
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
     if kernel_map._offsets_dev is None:
         kernel_map._offsets_dev = kernel_map.offsets.to(device=dev, dtype=torch.int32)
@@ -156,7 +208,8 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
     code = resolve_wgrad_algo(algo, cin, cout, x.dtype)
     ws_bytes = L.wcn_conv_wgrad_workspace(K, cin, cout, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    fuse = (want_bias_grad and code == _lib.WCN_ALGO_MFMA and getattr(kernel_map, "_self_exact", False)
+    # (not for fp32 features routed through fp16 operands: the bias gradient then stays an exact fp32 column sum)
+    fuse = (want_bias_grad and scale is None and code == _lib.WCN_ALGO_MFMA and getattr(kernel_map, "_self_exact", False)
             and x.shape[0] == dy.shape[0] and dy.shape[0] > 0
             and bool(L.wcn_mfma_wgrad_bias_supported(cin, cout, _lib.dtype_code(x.dtype))))
     if fuse:
@@ -175,4 +228,6 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
                          cout, K, _lib.dtype_code(x.dtype), code, _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)),
         "wcn_conv_wgrad",
     )
+    if scale is not None:
+        dw = dw * scale
     return (dw, None) if want_bias_grad else dw
