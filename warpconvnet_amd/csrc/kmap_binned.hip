@@ -85,7 +85,11 @@ __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, cons
   int found = -1;
   for (uint32_t a = 0; a <= cmask; ++a) {
     unsigned long long* kp = reinterpret_cast<unsigned long long*>(&slots[s].key);
-    unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // optimistic cached read first: a key, once written, never changes, so a matching value is final; an empty or
+    // stale value falls through to the coherent read below
+    unsigned long long cur = *reinterpret_cast<const volatile unsigned long long*>(kp);
+    if (cur == key) { found = (int)s; break; }
+    cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == 0ull) {
       cur = atomicCAS(kp, 0ull, (unsigned long long)key);
       if (cur == 0ull) {  // this thread created the block: give it a dense id
