@@ -448,3 +448,44 @@ def test_feature_tensors_above_2gib_use_64bit_offsets():
     for a in range(0, N, 1 << 20):
         ref += X[a:a + (1 << 20)].double().T @ dY[a:a + (1 << 20)].double()
     assert rel_max_err(dW[0], ref) < 2e-2
+
+
+@pytest.mark.parametrize("transposed,ksize,stride", [(False, 3, 1), (False, 2, 2), (True, 2, 2)])
+def test_generative_convolution_module(transposed, ksize, stride):
+    """generative=True: output coordinates = expanded (strided / up-scaled) inputs, kernel map as the reference builds it
+    (helper.py:58-146, 512-540); features vs the oracle on the oracle's own map of the same coordinate sets."""
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    s = scene_u(1200, 91, 0)
+    torch.manual_seed(2)
+    conv = SparseConv3d(16, 32, ksize, stride=stride, transposed=transposed, generative=True).to(dev)
+    X = torch.randn(len(s), 16, device=dev, requires_grad=True)
+    # a transposed (up-sampling) layer consumes a coarse tensor: tensor stride = conv stride there
+    x = Voxels(torch.from_numpy(s[:, 1:]).to(dev), X, offsets=torch.tensor([0, len(s)]),
+               tensor_stride=(stride,) * 3 if transposed else None)
+    y = conv(x)
+    out_c = y.batch_indexed_coordinates.cpu().numpy()
+    ks3, st3 = (ksize,) * 3, (stride,) * 3
+    from oracle import brute
+
+    offs = brute.kernel_offsets(ks3, (1, 1, 1))
+    if transposed:
+        base = s * np.array([1, stride, stride, stride], np.int32)
+        r = okmap.kernel_map(out_c, base, ks3, (1, 1, 1))  # built out -> in, then swapped
+        in_maps, out_maps = r["out_maps"], r["in_maps"]
+    else:
+        base = s if stride == 1 else okmap.stride_coords(s, st3)[0]
+        r = okmap.kernel_map(s, out_c, ks3, st3)
+        in_maps, out_maps = r["in_maps"], r["out_maps"]
+    want_set = np.unique(np.concatenate([base] + [base + np.concatenate([[0], o]) for o in offs], 0), axis=0)
+    np.testing.assert_array_equal(np.unique(out_c, axis=0), want_set)
+    assert y.tensor_stride == ((1, 1, 1) if (transposed or stride == 1) else (stride,) * 3)
+    dY = torch.randn(len(out_c), 32, device=dev)
+    y.feature_tensor.backward(dY)
+    Xd, Wd = X.detach().double().cpu(), conv.weight.detach().double().cpu()
+    Yr = oconv.forward(Xd, Wd, in_maps, out_maps, r["offsets"], len(out_c)) + conv.bias.detach().double().cpu()
+    dXr, dWr = oconv.backward(dY.double().cpu(), Xd, Wd, in_maps, out_maps, r["offsets"])
+    assert rel_max_err(y.feature_tensor.detach(), Yr) < 1e-3
+    assert rel_max_err(X.grad, dXr) < 1e-3 and rel_max_err(conv.weight.grad, dWr) < 1e-3

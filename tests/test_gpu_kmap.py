@@ -209,3 +209,26 @@ def test_surface_scene_map(kmap_method):
     s = scene_surface(160, 2)
     km = _gen(s, s, (3, 3, 3), same=True)
     _check_against_oracle(km, s, s, (3, 3, 3))
+
+
+def test_expand_coords_matches_set_union():
+    """Generative output coordinates: inputs U (inputs + every kernel offset), de-duplicated, batch-sorted, deterministic
+    (reference coords/ops/expand.py:17-75 builds the same set; its row order is hash-table / unstable-argsort dependent)."""
+    from warpconvnet_amd.geometry.coords.ops.expand import expand_coords
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import kernel_offsets_from_size
+
+    s = np.concatenate([scene_u(1500, 81, 0), scene_u(700, 82, 1)], 0)
+    dev = torch.device("cuda:0")
+    for ks, dl in (((3, 3, 3), (1, 1, 1)), ((2, 2, 2), (1, 1, 1)), ((3, 1, 3), (2, 1, 1))):
+        out, offsets = expand_coords(torch.from_numpy(s).to(dev), ks, dl)
+        out = out.cpu().numpy()
+        off = kernel_offsets_from_size(ks, dl).numpy()
+        want = np.unique(np.concatenate([s] + [s + o for o in off], 0), axis=0)
+        assert len(out) == len(want) and len(np.unique(out, axis=0)) == len(out)
+        np.testing.assert_array_equal(np.unique(out, axis=0), want)
+        assert (np.diff(out[:, 0]) >= 0).all()
+        np.testing.assert_array_equal(offsets.numpy(), [0, (out[:, 0] == 0).sum(), len(out)])
+        # every batch starts with its input rows in input order (first occurrences win)
+        np.testing.assert_array_equal(out[:1500], s[:1500])
+        out2, _ = expand_coords(torch.from_numpy(s).to(dev), ks, dl, kernel_batch=1)
+        np.testing.assert_array_equal(np.unique(out2.cpu().numpy(), axis=0), want)

@@ -172,7 +172,7 @@ def test_one_by_one_conv_and_errors():
         conv(torch.zeros(3, 4))
     with pytest.raises(RuntimeError):  # CPU voxels without a cached map: kernel-map construction is GPU-only
         SparseConv3d(4, 8, 3)(v)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="no CPU fallback"):  # generative: coordinate expansion is GPU-only, like the reference
         SparseConv3d(4, 8, 3, generative=True)(v)
 
 

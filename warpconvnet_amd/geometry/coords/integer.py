@@ -63,6 +63,16 @@ class IntCoords(Coords):
         offsets = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(self.offsets.dtype)
         return self._like(self.batched_tensor[mask], offsets)
 
+    def expand(self, kernel_size: Union[int, Tuple[int, ...]], dilation: Union[int, Tuple[int, ...]] = 1) -> "IntCoords":
+        """Coordinates plus all their kernel offsets, de-duplicated, batch-sorted (reference `integer.py:147-190`);
+        the tensor stride is kept - expansion does not scale coordinates."""
+        from warpconvnet_amd.geometry.coords.ops.expand import expand_coords
+
+        nd = self.num_spatial_dims
+        bcoords = batch_indexed_coordinates(self.batched_tensor, self.offsets)
+        out, offsets = expand_coords(bcoords, ntuple(kernel_size, ndim=nd), ntuple(dilation, ndim=nd))
+        return self._like(out[:, 1:].contiguous(), offsets)
+
     @property
     def hashmap(self):
         from warpconvnet_amd.geometry.coords.search.packed_hashmap import PackedHashTable

@@ -63,17 +63,32 @@ def generate_output_coords_and_kernel_map(
     out_code_backend: Optional[str] = None,
 ) -> Tuple[Tensor, Tensor, IntSearchResult]:
     """Returns ``(batch_indexed_out_coords [M, D+1], out_offsets (CPU), kernel_map)``."""
-    if generative:
-        raise NotImplementedError("generative convolution is outside the built hot path (SURVEY.md §8f rank 3)")
     if stride_mode != STRIDED_CONV_MODE.STRIDE_ONLY and any(s != 1 for s in stride):
         raise NotImplementedError("REDUCE_AND_STRIDE is outside the built hot path (SURVEY.md §2a P9)")
     bcoords_in = input_sparse_tensor.batch_indexed_coordinates
     if bcoords_in.dtype != torch.int32:
         bcoords_in = bcoords_in.to(torch.int32)
+    map_stride = stride  # in -> out ratio used for the kernel map
 
     if output_spatially_sparse_tensor is not None:
+        assert not generative, "Output spatially sparse tensor is not supported with generative convolution"
         bcoords_out = output_spatially_sparse_tensor.batch_indexed_coordinates.to(torch.int32)
         out_offsets = output_spatially_sparse_tensor.offsets
+    elif generative:
+        # reference `_apply_generative_policy` (helper.py:58-146): expand the (strided / up-scaled) coordinates
+        from warpconvnet_amd.geometry.coords.ops.expand import expand_coords
+
+        if all(s == 1 for s in stride):
+            base = bcoords_in
+        elif transposed:  # up-sampling + densification: scale the coordinates, then expand; map built at stride 1
+            scale = torch.tensor([1, *stride], dtype=torch.int32, device=bcoords_in.device)
+            base = bcoords_in * scale
+            bcoords_in = base
+        else:             # stride first, then expand; the map still pairs the original inputs with the outputs
+            base, _ = stride_coords(bcoords_in, stride)
+        bcoords_out, out_offsets = expand_coords(base, kernel_size, kernel_dilation)
+        if transposed:
+            map_stride = tuple(1 for _ in stride)
     elif any(s != 1 for s in stride):
         bcoords_out, out_offsets = stride_coords(bcoords_in, stride)
     else:
@@ -95,9 +110,9 @@ def generate_output_coords_and_kernel_map(
                 fwd = source.cache.get(fwd_key)
                 if fwd is not None:
                     return bcoords_out, out_offsets, _swap(fwd)
-        kernel_map = _swap(generate_kernel_map(bcoords_out, bcoords_in, stride, kernel_size, kernel_dilation))
+        kernel_map = _swap(generate_kernel_map(bcoords_out, bcoords_in, map_stride, kernel_size, kernel_dilation))
     else:
-        kernel_map = generate_kernel_map(bcoords_in, bcoords_out, stride, kernel_size, kernel_dilation)
+        kernel_map = generate_kernel_map(bcoords_in, bcoords_out, map_stride, kernel_size, kernel_dilation)
 
     if input_sparse_tensor.cache is None:
         input_sparse_tensor._extra_attributes["_cache"] = IntSearchCache()
