@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--voxels", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)  # the whole configs[1] scene: ~10-15 s of CPU work
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--coord-order", choices=["generator", "block"], default="generator",
+                    help="generator: rows in the order the reference's generator emits them (the headline workload); "
+                         "block: the same scene with rows sorted by 16^3 block then x,y,z (what a voxelised scan looks like) - "
+                         "a locality study, never the headline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +121,11 @@ def main():
     _lib.lib()  # fail loudly if the HIP extension is missing
 
     # ---- resident inputs: one scene per GPU (weak scaling), identical weights on every rank ----
-    coords = torch.from_numpy(scene_u(args.voxels, seed=1000 + rank)).to(dev)
+    c_np = scene_u(args.voxels, seed=1000 + rank)
+    if args.coord_order == "block":
+        key = (((c_np[:, 0] >> 4) * 4096 + (c_np[:, 1] >> 4)) * 4096 + (c_np[:, 2] >> 4)).astype(np.int64)
+        c_np = c_np[np.lexsort((c_np[:, 2], c_np[:, 1], c_np[:, 0], key))]
+    coords = torch.from_numpy(np.ascontiguousarray(c_np)).to(dev)
     N = coords.shape[0]
     g = torch.Generator().manual_seed(rank)
     # bf16 features resident in HBM; a leaf that requires grad, so the backward pass runs ABt (dgrad) as well as AtB
@@ -227,7 +235,7 @@ def main():
             "config": {
                 "workload": f"configs[1]: one {N}-voxel uniform (U) scene per GPU, SparseConv3d 64->128 k=3, bf16 autocast, "
                             "kernel-map build + AB fwd + ABt dgrad + AtB wgrad per step",
-                "voxels_per_gpu": N, "pairs_per_scene": L, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)",
+                "voxels_per_gpu": N, "pairs_per_scene": L, "coord_order": args.coord_order, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -304,26 +304,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const T* __restrict_
 }
 
 // dw[k][e] = sum over ranges g that intersect bucket k (ascending) of slab[g + k][e].
-// 4 threads share an element (g mod 4), combined through LDS in a fixed order => deterministic.
+// 16 threads share four consecutive elements (ranges g mod 16), 16-B loads, partial sums combined through LDS in a fixed
+// order => deterministic.  (ce is a multiple of 64: channel counts are multiples of 32.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs,
                                                            const int32_t* __restrict__ offsets, int K, int64_t ce, int G,
                                                            float* __restrict__ dw) {
-  __shared__ float s_part[4][64];
-  const int part = threadIdx.x >> 6, el = threadIdx.x & 63;
-  const int64_t e = (int64_t)blockIdx.x * 64 + el;
+  __shared__ float4 s_part[16][16];
+  const int part = threadIdx.x >> 4, el = threadIdx.x & 15;
+  const int64_t e = (int64_t)blockIdx.x * 64 + el * 4;
   const int k = blockIdx.y;
   const int64_t L = offsets[K];
   int64_t Q = (L + G - 1) / G;
   Q = ((Q + kPairs - 1) / kPairs) * kPairs;
   const int64_t b = offsets[k], en = offsets[k + 1];
-  float s = 0.f;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < ce && en > b && Q > 0) {
     const int g_lo = (int)(b / Q), g_hi = (int)((en - 1) / Q);
-    for (int g = g_lo + part; g <= g_hi; g += 4) s += slabs[(int64_t)(g + k) * ce + e];
+    for (int g = g_lo + part; g <= g_hi; g += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)(g + k) * ce + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
   s_part[part][el] = s;
   __syncthreads();
-  if (part == 0 && e < ce) dw[(int64_t)k * ce + e] = (s_part[0][el] + s_part[1][el]) + (s_part[2][el] + s_part[3][el]);
+  if (part == 0 && e < ce) {
+    float4 t = s_part[0][el];
+#pragma unroll
+    for (int p = 1; p < 16; ++p) {
+      const float4 v = s_part[p][el];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dw + (int64_t)k * ce + e) = t;
+  }
 }
 
 // bias_grad[co] = sum over the ranges g that intersect bucket cs_k (ascending) of cs_slabs[g][co]; one wavefront per
