@@ -236,6 +236,22 @@ int wcn_dwconv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in
                      const int32_t* offsets, int64_t n_in, int64_t n_out, int32_t channels, int32_t num_offsets,
                      int32_t dtype, void* workspace, size_t workspace_bytes, wcn_stream_t stream);
 
+/* ---- point-cloud front end (PointConv path) ----------------------------------------------------------------------------
+ * wcn_knn_grid: exact k nearest reference points of every query (k <= 64), ascending by distance.  The caller bins the
+ *   reference points of ONE batch element into a uniform grid: cell = floor((p - origin) / cell_size) clamped to dims,
+ *   cell id = (z * dims[1] + y) * dims[0] + x; `ref_sorted` [N,3] fp32 holds the points sorted by cell id, `ref_ids` [N]
+ *   their original row ids, `cell_start` [cells + 1] the CSR over cells.  out_index [M,k] int64 (-1 if fewer than k
+ *   points exist), out_dist2 [M,k] fp32 squared distances (may be NULL).  Equals the brute-force answer (up to ties);
+ *   replaces the chunked cdist + topk of warpconvnet/geometry/coords/search/knn.py:11-26, 108-142.
+ * wcn_segment_reduce: out[m][c] = op over rows [row_splits[m], row_splits[m+1]) of in[.][c], op: 0 sum, 1 mean, 2 max,
+ *   3 min (empty segment -> 0); arg_rows [M,C] int64 (max / min only, may be NULL) = row of the first extremum, for the
+ *   backward pass.  Role of torch_scatter.segment_csr in warpconvnet/ops/reductions.py:36-75. */
+int wcn_knn_grid(const float* ref_sorted, const int32_t* ref_ids, const int32_t* cell_start, const float origin[3],
+                 float cell_size, const int32_t dims[3], const float* query, int64_t num_query, int32_t k,
+                 int64_t* out_index, float* out_dist2, wcn_stream_t stream);
+int wcn_segment_reduce(const void* in, const int64_t* row_splits, int64_t num_segments, int32_t channels, int32_t dtype,
+                       int32_t op, void* out, int64_t* arg_rows, wcn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

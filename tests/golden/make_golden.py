@@ -149,6 +149,54 @@ def main_depthwise():
     print("done (depthwise)")
 
 
+def main_pointconv():
+    """(h) PointConv (knn) forward / backward on CPU with seeded weights (reference nn/modules/point_conv.py:36-282).
+    torch_scatter is a third-party dependency absent from this image: segment_csr is stubbed with a plain loop."""
+    import_reference()
+    import torch_scatter
+
+    def segment_csr(src, indptr, reduce="sum"):
+        rows = []
+        for i in range(indptr.numel() - 1):
+            seg = src[int(indptr[i]) : int(indptr[i + 1])]
+            rows.append({"sum": lambda t: t.sum(0), "mean": lambda t: t.mean(0), "max": lambda t: t.max(0).values,
+                         "min": lambda t: t.min(0).values}[reduce](seg))
+        return torch.stack(rows)
+
+    torch_scatter.segment_csr = segment_csr
+    import warpconvnet.ops.reductions as R
+
+    R.segment_csr = segment_csr
+    from warpconvnet.geometry.coords.search.search_configs import RealSearchConfig
+    from warpconvnet.geometry.types.points import Points
+    from warpconvnet.nn.modules.point_conv import PointConv
+
+    out = {}
+    for name, kw in [("knn8_relpos_mean_max", dict(use_rel_pos=True, reductions=("mean", "max"))),
+                     ("knn8_plain_sum", dict(reductions=("sum",)))]:
+        g = torch.Generator().manual_seed(31)
+        c0, c1 = torch.rand(180, 3, generator=g), torch.rand(140, 3, generator=g) * 2.0
+        f0, f1 = torch.randn(180, 8, generator=g), torch.randn(140, 8, generator=g)
+        feats = torch.cat([f0, f1]).requires_grad_(True)
+        pc = Points(torch.cat([c0, c1]), feats, offsets=torch.tensor([0, 180, 320]))
+        torch.manual_seed(0)
+        conv = PointConv(8, 16, RealSearchConfig(mode="knn", knn_k=8), **kw)
+        y = conv(pc).feature_tensor
+        dY = torch.randn(y.shape, generator=g)
+        y.backward(dY)
+        out[name + "_coords"] = torch.cat([c0, c1]).numpy()
+        out[name + "_feats"] = feats.detach().numpy()
+        out[name + "_dY"] = dY.numpy()
+        out[name + "_Y"] = y.detach().numpy()
+        out[name + "_dX"] = feats.grad.numpy()
+        for k, v in conv.state_dict().items():
+            out[f"{name}_param_{k}"] = v.numpy()
+        for k, p in conv.named_parameters():
+            out[f"{name}_grad_{k}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "pointconv.npz"), **out)
+    print("done (pointconv)")
+
+
 def main():
     import_reference()
     from warpconvnet.geometry.coords.search.cache import IntSearchCacheKey
@@ -259,6 +307,9 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "depthwise":
         main_depthwise()  # only the (g) fixtures; the others are left untouched
+    elif len(sys.argv) > 1 and sys.argv[1] == "pointconv":
+        main_pointconv()  # only the (h) fixture
     else:
         main()
         main_depthwise()
+        main_pointconv()

@@ -252,3 +252,52 @@ def test_grouped_conv_cpu_explicit_module_vs_oracle():
     assert conv.weight.shape == (27, 4, 4, 6)
     assert (Y.detach() - Yr).abs().max() < 1e-10 and (X.grad - dXr).abs().max() < 1e-10
     assert (conv.weight.grad - dWr).abs().max() < 1e-10 and (conv.bias.grad - dY.sum(0)).abs().max() < 1e-10
+
+
+# ---- PointConv (CPU tensors: torch kNN + torch segment reduce = the reference's algorithm) ----------------------------
+def _pointconv_case(g, name, device, kw):
+    from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
+    from warpconvnet_amd.nn.modules.point_conv import PointConv
+
+    feats = torch.from_numpy(g[name + "_feats"]).to(device).requires_grad_(True)
+    pc = Points(torch.from_numpy(g[name + "_coords"]).to(device), feats, offsets=torch.tensor([0, 180, 320]))
+    conv = PointConv(8, 16, RealSearchConfig(mode="knn", knn_k=8), **kw)
+    state = {k[len(name) + 7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + "_param_")}
+    conv.load_state_dict(state, strict=True)  # same parameter / buffer names as the reference module
+    conv = conv.to(device)
+    y = conv(pc).feature_tensor
+    y.backward(torch.from_numpy(g[name + "_dY"]).to(device))
+    grads = {k: p.grad for k, p in conv.named_parameters()}
+    return y.detach(), feats.grad, grads
+
+
+@pytest.mark.parametrize("name,kw", [("knn8_relpos_mean_max", dict(use_rel_pos=True, reductions=("mean", "max"))),
+                                     ("knn8_plain_sum", dict(reductions=("sum",)))])
+def test_pointconv_cpu_matches_reference_golden(golden_dir, name, kw):
+    g = np.load(os.path.join(golden_dir, "pointconv.npz"))
+    y, dx, grads = _pointconv_case(g, name, torch.device("cpu"), kw)
+    torch.testing.assert_close(y, torch.from_numpy(g[name + "_Y"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dx, torch.from_numpy(g[name + "_dX"]), rtol=1e-4, atol=1e-5)
+    for k, v in grads.items():
+        torch.testing.assert_close(v, torch.from_numpy(g[f"{name}_grad_{k}"]), rtol=1e-3, atol=1e-4)
+
+
+def test_row_reduction_cpu_and_voxel_downsample():
+    from warpconvnet_amd.ops.reductions import row_reduction
+
+    f = torch.randn(12, 5, dtype=torch.float64, requires_grad=True)
+    splits = torch.tensor([0, 4, 4, 9, 12])
+    for op, ref in (("sum", lambda t: t.sum(0)), ("mean", lambda t: t.mean(0)), ("max", lambda t: t.max(0).values),
+                    ("min", lambda t: t.min(0).values)):
+        out = row_reduction(f, splits, op)
+        want = torch.stack([ref(f[a:b]) if b > a else torch.zeros(5, dtype=f.dtype) for a, b in zip(splits[:-1], splits[1:])])
+        torch.testing.assert_close(out, want)
+    assert torch.autograd.gradcheck(lambda t: row_reduction(t, splits, "mean"), (f,))
+    assert torch.autograd.gradcheck(lambda t: row_reduction(t, splits, "max"), (f,))
+    pc = Points([torch.rand(300, 3)], [torch.randn(300, 4)])
+    down = pc.voxel_downsample(0.25, reduction="mean")
+    q = torch.floor(pc.coordinate_tensor / 0.25).int()
+    uniq, inv = torch.unique(q, dim=0, return_inverse=True)
+    want = torch.zeros(len(uniq), 4).index_add_(0, inv, pc.feature_tensor) / torch.bincount(inv).unsqueeze(1)
+    assert down.feature_tensor.shape == want.shape
+    torch.testing.assert_close(down.feature_tensor, want, rtol=1e-5, atol=1e-6)

@@ -95,6 +95,12 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
          c_void_p, c_size_t, c_void_p],
     ),
+    "wcn_knn_grid": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, ctypes.c_float * 3, ctypes.c_float, c_int32 * 3, c_void_p, c_int64, c_int32, c_void_p,
+         c_void_p, c_void_p],
+    ),
+    "wcn_segment_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "wcn_mfma_wgrad_bias_supported": (c_int, [c_int32, c_int32, c_int32]),
     "wcn_conv_wgrad_bias": (
         c_int,

@@ -29,6 +29,11 @@ int dwconv_gather(const void* in, const void* w, void* out, const int32_t* tbl, 
 size_t dwconv_wgrad_workspace(int K, int C);
 int dwconv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                  const int32_t* offsets, int C, int K, int dtype, void* workspace, size_t workspace_bytes, hipStream_t s);
+// points.hip
+int knn_grid(const float* ref, const int32_t* ref_id, const int32_t* cell_start, const float origin[3], float h,
+             const int32_t dims[3], const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2, hipStream_t s);
+int segment_reduce(const void* in, const int64_t* splits, int64_t m, int c, int dtype, int op, void* out, int64_t* arg,
+                   hipStream_t s);
 }  // namespace wcn
 
 using namespace wcn;
@@ -156,6 +161,24 @@ int wcn_dwconv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in
     return WCN_ERROR_INVALID_PARAMETERS;
   return dwconv_wgrad(x, dy, dw, in_maps, out_maps, offsets, channels, num_offsets, dtype, workspace, workspace_bytes,
                       (hipStream_t)stream);
+}
+
+int wcn_knn_grid(const float* ref_sorted, const int32_t* ref_ids, const int32_t* cell_start, const float origin[3],
+                 float cell_size, const int32_t dims[3], const float* query, int64_t num_query, int32_t k,
+                 int64_t* out_index, float* out_dist2, wcn_stream_t stream) {
+  if (num_query < 0 || !origin || !dims) return WCN_ERROR_INVALID_PARAMETERS;
+  if (num_query == 0) return WCN_SUCCESS;
+  if (!ref_sorted || !ref_ids || !cell_start || !query || !out_index) return WCN_ERROR_INVALID_PARAMETERS;
+  return knn_grid(ref_sorted, ref_ids, cell_start, origin, cell_size, dims, query, num_query, k, out_index, out_dist2,
+                  (hipStream_t)stream);
+}
+
+int wcn_segment_reduce(const void* in, const int64_t* row_splits, int64_t num_segments, int32_t channels, int32_t dtype,
+                       int32_t op, void* out, int64_t* arg_rows, wcn_stream_t stream) {
+  if (num_segments < 0 || channels < 0 || !dtype_ok(dtype)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (num_segments == 0 || channels == 0) return WCN_SUCCESS;
+  if (!row_splits || !out) return WCN_ERROR_INVALID_PARAMETERS;
+  return segment_reduce(in, row_splits, num_segments, channels, dtype, op, out, arg_rows, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,21 +1,76 @@
-"""k-nearest-neighbour search: chunked cdist + topk per batch element.
+"""k-nearest-neighbour search.
 
-Same algorithm as the reference (`warpconvnet/geometry/coords/search/knn.py:11-26, 108-142`, pure
-torch there too); indices are global row ids (local index + batch offset).
+GPU tensors: exact grid search in HIP (``wcn_knn_grid``, `csrc/points.hip`): the reference points of a batch element
+are binned into a uniform grid sized for a few points per cell (device-side sort by cell id + CSR over cells), then one
+thread per query walks the cell shells around its cell and stops when the k-th distance is inside the searched cube -
+O(M*k) instead of the reference's O(M*N) chunked ``cdist`` + ``topk``
+(`warpconvnet/geometry/coords/search/knn.py:11-26, 108-142`), same neighbours (ties may come back in another order).
+CPU tensors: the reference's own algorithm (cdist + topk), which is also the oracle of the GPU tests.
+Indices are global row ids (local index + batch offset).
 """
+import ctypes
+import math
+
 import torch
 from torch import Tensor
 
+from warpconvnet_amd import _lib
 
-@torch.no_grad()
-def knn_search(ref: Tensor, query: Tensor, k: int, chunk: int = 4096) -> Tensor:
-    """[M, k] int64 indices into ``ref`` of the k nearest reference points of every query."""
-    assert k <= ref.shape[0], f"knn_k={k} exceeds the number of reference points {ref.shape[0]}"
+_MAX_CELLS = 1 << 24
+
+
+def _knn_cdist(ref: Tensor, query: Tensor, k: int, chunk: int = 4096) -> Tensor:
     out = []
     for s in range(0, query.shape[0], chunk):
         d = torch.cdist(query[s : s + chunk], ref)
         out.append(torch.topk(d, k, dim=1, largest=False).indices)
     return torch.cat(out, 0) if out else torch.zeros((0, k), dtype=torch.int64, device=ref.device)
+
+
+def _knn_grid(ref: Tensor, query: Tensor, k: int, return_dist2: bool = False):
+    dev = ref.device
+    ref32, q32 = ref.float().contiguous(), query.float().contiguous()
+    n = ref32.shape[0]
+    lo_t, hi_t = ref32.min(0).values, ref32.max(0).values
+    lo, hi = lo_t.cpu().tolist(), hi_t.cpu().tolist()  # one host read per search (the result is cached by Points.neighbors)
+    ext = [max(h - l, 1e-6) for l, h in zip(lo, hi)]
+    # a few points per cell on average: shell 1 (27 cells) then usually holds k <= 32 candidates
+    h = (4.0 * ext[0] * ext[1] * ext[2] / max(n, 1)) ** (1.0 / 3.0)
+    h = max(h, max(ext) / 1024.0, 1e-6)
+    dims = [int(math.floor(e / h)) + 1 for e in ext]
+    while dims[0] * dims[1] * dims[2] > _MAX_CELLS:
+        h *= 1.5
+        dims = [int(math.floor(e / h)) + 1 for e in ext]
+    origin = torch.tensor(lo, device=dev, dtype=torch.float32)
+    cell3 = torch.floor((ref32 - origin) / h).to(torch.int64)
+    for a in range(3):
+        cell3[:, a].clamp_(0, dims[a] - 1)
+    cell = (cell3[:, 2] * dims[1] + cell3[:, 1]) * dims[0] + cell3[:, 0]
+    order = torch.argsort(cell, stable=True)
+    sorted_cell = cell[order]
+    ncells = dims[0] * dims[1] * dims[2]
+    cell_start = torch.searchsorted(sorted_cell, torch.arange(ncells + 1, device=dev, dtype=torch.int64)).to(torch.int32)
+    ref_sorted = ref32[order].contiguous()
+    ref_ids = order.to(torch.int32).contiguous()
+    m = q32.shape[0]
+    out = torch.empty((m, k), dtype=torch.int64, device=dev)
+    d2 = torch.empty((m, k), dtype=torch.float32, device=dev) if return_dist2 else None
+    _lib.check(
+        _lib.lib().wcn_knn_grid(_lib.ptr(ref_sorted), _lib.ptr(ref_ids), _lib.ptr(cell_start), (ctypes.c_float * 3)(*lo),
+                                ctypes.c_float(h), _lib.i3(dims), _lib.ptr(q32), m, k, _lib.ptr(out), _lib.ptr(d2),
+                                _lib.stream_handle(dev)),
+        "wcn_knn_grid",
+    )
+    return (out, d2) if return_dist2 else out
+
+
+@torch.no_grad()
+def knn_search(ref: Tensor, query: Tensor, k: int, chunk: int = 4096) -> Tensor:
+    """[M, k] int64 indices into ``ref`` of the k nearest reference points of every query, ascending by distance."""
+    assert k <= ref.shape[0], f"knn_k={k} exceeds the number of reference points {ref.shape[0]}"
+    if ref.is_cuda and k <= 64:
+        return _knn_grid(ref, query, k)
+    return _knn_cdist(ref, query, k, chunk)
 
 
 @torch.no_grad()

@@ -61,15 +61,36 @@ class Points(Geometry):
             )
         return cache[key]
 
-    def voxel_downsample(self, voxel_size: float) -> "Points":
-        """One (first) point per voxel of edge ``voxel_size``."""
+    def voxel_downsample(self, voxel_size: float, reduction="random") -> "Points":
+        """One point per voxel of edge ``voxel_size`` (reference `points.py:122-190`): ``random`` keeps the first point
+        and its features; any other reduction pools the features of the voxel's points (``row_reduction``) and keeps the
+        first point's coordinates."""
+        from warpconvnet_amd.geometry.coords.ops.batch_index import batch_indexed_coordinates, offsets_from_batch_index
         from warpconvnet_amd.geometry.coords.ops.voxel import voxel_downsample_random_indices
+        from warpconvnet_amd.ops.reductions import REDUCTIONS, row_reduction
 
-        idx, offsets = voxel_downsample_random_indices(self.coordinate_tensor, self.offsets, voxel_size)
+        if isinstance(reduction, str):
+            reduction = REDUCTIONS(reduction)
+        extra = {**self.extra_attributes, "voxel_size": voxel_size}
+        if reduction == REDUCTIONS.RANDOM:
+            idx, offsets = voxel_downsample_random_indices(self.coordinate_tensor, self.offsets, voxel_size)
+            return self.__class__(
+                RealCoords(self.coordinate_tensor[idx], offsets),
+                CatFeatures(self.batched_features.batched_tensor[idx], offsets),
+                **extra,
+            )
+        q = torch.floor(self.coordinate_tensor / voxel_size).to(torch.int32)
+        bq = batch_indexed_coordinates(q, self.offsets)
+        uniq, inverse = torch.unique(bq, dim=0, return_inverse=True)  # lexicographic => batch-sorted voxels
+        perm = torch.argsort(inverse, stable=True)                    # points grouped by voxel, input order inside
+        counts = torch.bincount(inverse, minlength=uniq.shape[0])
+        splits = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+        feats = row_reduction(self.feature_tensor[perm], splits, reduction)
+        offsets = offsets_from_batch_index(uniq[:, 0], num_batches=self.batch_size)
         return self.__class__(
-            RealCoords(self.coordinate_tensor[idx], offsets),
-            CatFeatures(self.batched_features.batched_tensor[idx], offsets),
-            **{**self.extra_attributes, "voxel_size": voxel_size},
+            RealCoords(self.coordinate_tensor[perm[splits[:-1]]], offsets),
+            CatFeatures(feats, offsets),
+            **extra,
         )
 
     def to_voxels(self, voxel_size: float, reduction: str = "mean"):

@@ -1,7 +1,9 @@
 from .base_module import BaseSpatialModel, BaseSpatialModule
+from .mlp import MLPBlock
+from .point_conv import PointConv
 from .sequential import Sequential
 from .sparse_conv import SparseConv2d, SparseConv3d, SpatiallySparseConv
 from .sparse_conv_depth import SparseDepthwiseConv2d, SparseDepthwiseConv3d, SpatiallySparseDepthwiseConv
 
-__all__ = ["BaseSpatialModel", "BaseSpatialModule", "Sequential", "SparseConv2d", "SparseConv3d", "SpatiallySparseConv",
+__all__ = ["BaseSpatialModel", "BaseSpatialModule", "MLPBlock", "PointConv", "Sequential", "SparseConv2d", "SparseConv3d", "SpatiallySparseConv",
            "SparseDepthwiseConv2d", "SparseDepthwiseConv3d", "SpatiallySparseDepthwiseConv"]
