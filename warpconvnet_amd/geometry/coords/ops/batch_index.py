@@ -27,6 +27,8 @@ def batch_index_from_offset(offsets: Tensor, device=None) -> Tensor:
 @torch.no_grad()
 def batch_indexed_coordinates(batched_coords: Tensor, offsets: Tensor) -> Tensor:
     """[N, D] + offsets -> [N, D+1] with the batch index in column 0 (same dtype/device)."""
+    if offsets.numel() == 2:  # one batch element: a constant column, one kernel instead of fill + cat
+        return torch.nn.functional.pad(batched_coords, (1, 0), value=0)
     bidx = batch_index_from_offset(offsets, device=batched_coords.device).to(batched_coords.dtype)
     return torch.cat([bidx.unsqueeze(1), batched_coords], dim=1)
 
