@@ -96,11 +96,17 @@ int64_t wcn_kmap_num_blocks(int64_t m);
 int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, int64_t m,
                    const int32_t ksize[3], const int32_t stride[3], const int32_t dilation[3],
                    int32_t* nbr, uint32_t* mask, wcn_stream_t stream);
+/* [n, num_dims] int32 coordinates -> [n, num_dims + 1] with the batch index of the row in column 0; `offsets`
+ * [num_batches + 1] int32 on the device (may be NULL for one batch).  One launch; replaces the batch-index kernel +
+ * torch.cat of warpconvnet/geometry/coords/ops/batch_index.py:90-148. */
+int wcn_batch_indexed_coords(const int32_t* coords, int64_t n, int32_t num_dims, const int32_t* offsets,
+                             int32_t num_batches, int32_t* out, wcn_stream_t stream);
+
 /* LDS-binned neighbour search for SUBMANIFOLD maps (query coords == input coords, stride 1): replaces
  * wcn_hash_insert + wcn_kmap_probe.  Voxels are binned into 16^3 blocks through a block-level hash table
  * (`slots`, capacity >= 2n, power of two; prepared by the call), then every block and its halo are staged in an
  * LDS grid and all K probes are answered from LDS.  Same outputs as the hash path (bit-exact), incl. the
- * range flags in *status.  Returns WCN_ERROR_PROBLEM_NOT_SUPPORTED when the kernel halo exceeds 4 cells
+ * range flags in *status (the status word is CLEARED by this call, it need not be zeroed beforehand).  Returns WCN_ERROR_PROBLEM_NOT_SUPPORTED when the kernel halo exceeds 4 cells
  * (wcn_kmap_binned_supported == 0): the caller then uses the hash path.
  * reference being replaced: cuhash_hash_table.cu:179-220 + cuhash_kernel_map.cu:93-134. */
 size_t wcn_kmap_binned_workspace(int64_t n);

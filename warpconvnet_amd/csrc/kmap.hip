@@ -254,6 +254,31 @@ __global__ __launch_bounds__(kThreads) void kmap_scatter_kernel(const int32_t* _
   if (overflow) atomicOr(status, (int)WCN_FLAG_PAIR_OVERFLOW);
 }
 
+// [n, d] int32 coordinates + batch offsets -> [n, d+1] with the batch index in column 0 (one launch instead of
+// repeat_interleave + fill + cat; reference: warpconvnet/geometry/coords/ops/batch_index.py:90-148)
+__global__ __launch_bounds__(256) void batch_indexed_coords_kernel(const int32_t* __restrict__ coords, int64_t n, int d,
+                                                                   const int32_t* __restrict__ offsets, int num_batches,
+                                                                   int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int b = 0;
+  if (num_batches > 1) {  // last batch whose offset is <= i
+    int lo = 0, hi = num_batches;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    b = lo;
+  }
+  if (d == 3) {
+    const int32_t* c = coords + i * 3;
+    *reinterpret_cast<int4*>(out + i * 4) = make_int4(b, c[0], c[1], c[2]);
+  } else {
+    out[i * (d + 1)] = b;
+    for (int j = 0; j < d; ++j) out[i * (d + 1) + 1 + j] = coords[i * d + j];
+  }
+}
+
 // nbr [m][kp] -> pair_table [K][m]
 __global__ __launch_bounds__(kThreads) void kmap_transpose_kernel(const int32_t* __restrict__ nbr, int64_t m, int K,
                                                                   int kp, int32_t* __restrict__ pair_table) {
@@ -433,6 +458,16 @@ int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_
   hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(nwb, kThreads / 64)), dim3(kThreads), 0,
                      (hipStream_t)stream, nbr, mask, m, K, kp, mw, nwb, counts, offsets, in_maps, out_maps, pair_capacity,
                      status);
+  return launch_status();
+}
+
+int wcn_batch_indexed_coords(const int32_t* coords, int64_t n, int32_t num_dims, const int32_t* offsets,
+                             int32_t num_batches, int32_t* out, wcn_stream_t stream) {
+  if (n < 0 || num_dims < 1 || num_dims > 8 || num_batches < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n == 0) return WCN_SUCCESS;
+  if (!coords || !out || (num_batches > 1 && !offsets)) return WCN_ERROR_INVALID_PARAMETERS;
+  hipLaunchKernelGGL(batch_indexed_coords_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, coords,
+                     n, (int)num_dims, offsets, (int)num_batches, out);
   return launch_status();
 }
 

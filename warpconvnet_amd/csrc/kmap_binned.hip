@@ -62,9 +62,14 @@ __device__ __forceinline__ int block_find(const Slot* __restrict__ slots, uint32
 // critical path 4x; the sub-counter is chosen by the voxel's row index.
 constexpr int kSub = 8;  // sub-counters per (block, class): spreads the same-address atomics of bin_count
 
-__global__ void bin_prepare_kernel(uint4* __restrict__ slots, int64_t capacity) {
+// clears the block table and - in the same launch - the block counter and the caller's status word (every extra
+// memset / fill is a ~5 us launch on this pipeline of ~20 short kernels)
+__global__ void bin_prepare_kernel(uint4* __restrict__ slots, int64_t capacity, int32_t* __restrict__ nblk,
+                                   int32_t* __restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < capacity) slots[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (i < 64) nblk[i] = 0;
+  if (i == 0) *status = 0;
 }
 
 // pass 1a: create the block entries (CAS only on first touch; everybody else just reads) and remember the slot
@@ -425,8 +430,8 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   g.hx = halo(g.kx, g.cx, g.dx); g.hy = halo(g.ky, g.cy, g.dy); g.hz = halo(g.kz, g.cz, g.dz);
   g.gx = kBlk + 2 * g.hx; g.gy = kBlk + 2 * g.hy; g.gz = kBlk + 2 * g.hz;
 
-  if (hipMemsetAsync(w.nblk, 0, 256, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
-  hipLaunchKernelGGL(bin_prepare_kernel, dim3((unsigned)ceil_div(capacity, 256)), dim3(256), 0, s, (uint4*)slots, capacity);
+  hipLaunchKernelGGL(bin_prepare_kernel, dim3((unsigned)ceil_div(capacity, 256)), dim3(256), 0, s, (uint4*)slots, capacity,
+                     w.nblk, status);
   const uint32_t cmask = (uint32_t)(capacity - 1);
   const unsigned gn = (unsigned)ceil_div(n, 256);
   hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n, w.vox_slot,

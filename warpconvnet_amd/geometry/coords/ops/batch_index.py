@@ -27,8 +27,17 @@ def batch_index_from_offset(offsets: Tensor, device=None) -> Tensor:
 @torch.no_grad()
 def batch_indexed_coordinates(batched_coords: Tensor, offsets: Tensor) -> Tensor:
     """[N, D] + offsets -> [N, D+1] with the batch index in column 0 (same dtype/device)."""
-    if offsets.numel() == 2:  # one batch element: a constant column, one kernel instead of fill + cat
-        return torch.nn.functional.pad(batched_coords, (1, 0), value=0)
+    if batched_coords.is_cuda and batched_coords.dtype == torch.int32 and batched_coords.ndim == 2:
+        from warpconvnet_amd import _lib  # one HIP launch (wcn_batch_indexed_coords) instead of fill + copy kernels
+
+        c = batched_coords.contiguous()
+        n, d = c.shape
+        B = offsets.numel() - 1
+        out = torch.empty((n, d + 1), dtype=torch.int32, device=c.device)
+        off_dev = offsets.to(device=c.device, dtype=torch.int32) if B > 1 else None
+        _lib.check(_lib.lib().wcn_batch_indexed_coords(_lib.ptr(c), n, d, _lib.ptr(off_dev), max(B, 1), _lib.ptr(out),
+                                                       _lib.stream_handle(c.device)), "wcn_batch_indexed_coords")
+        return out
     bidx = batch_index_from_offset(offsets, device=batched_coords.device).to(batched_coords.dtype)
     return torch.cat([bidx.unsqueeze(1), batched_coords], dim=1)
 

@@ -176,7 +176,7 @@ def generate_kernel_map(
     nblk = L.wcn_kmap_num_blocks(M)
 
     # meta[0:K+1] = offsets, meta[K+1] = status flags -> one D2H copy
-    meta = torch.zeros(K + 2, dtype=torch.int32, device=dev)
+    meta = None  # allocated below: the binned path clears the status word itself, the hash path needs zeros
     nbr = torch.empty((M, kp), dtype=torch.int32, device=dev)
     mask = torch.empty((M, mw), dtype=torch.int32, device=dev)
     block_counts = torch.empty(K * (nblk + 1), dtype=torch.int32, device=dev)  # k-major counts + K totals
@@ -189,6 +189,7 @@ def generate_kernel_map(
     if method_env == "binned" and not use_binned:
         raise RuntimeError("WARPCONVNET_AMD_KMAP_METHOD=binned needs a submanifold map (same coordinate tensor, stride 1, halo <= 4)")
     table = PackedHashTable(max(16, 2 * N), device=dev)
+    meta = (torch.empty if (use_binned and N > 0) else torch.zeros)(K + 2, dtype=torch.int32, device=dev)
     if use_binned:
         # LDS-binned path: block-level hash + counting sort + LDS grid probes (csrc/kmap_binned.hip)
         table._slots = torch.empty((table.capacity, 2), dtype=torch.int64, device=dev)
