@@ -94,7 +94,7 @@ def _make_hip_bwd(algo: str) -> BwdFn:
                                                        algo, want_bias_grad=True)
             else:
                 dw = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape), algo)
-            dw = dw.to(ctx.weight.dtype)
+            # stays fp32 here: the autograd function casts once to the dtype of the weight it was given
         return dx, dw
 
     return fn

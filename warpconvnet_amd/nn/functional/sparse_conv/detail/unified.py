@@ -75,6 +75,9 @@ class UnifiedSpatiallySparseConvFunction(Function):
         ctx.groups = groups
         ctx.dgrad_algo = _algo_name(dgrad_algo, on_gpu)
         ctx.wgrad_algo = _algo_name(wgrad_algo, on_gpu)
+        ctx.weight_dtype = weight.dtype
+        if compute_dtype is not None and weight.dtype != compute_dtype and weight.is_floating_point():
+            weight = weight.to(compute_dtype)  # saved in compute precision (reference helper.py:256-262 casts before apply)
         ctx.save_for_backward(in_features, weight)
         ctx.has_bias = bias is not None
         cout = weight.shape[-1] * (groups if weight.ndim == 4 else 1)
@@ -122,6 +125,8 @@ class UnifiedSpatiallySparseConvFunction(Function):
                 grad_b = hip_colsum(grad_output.contiguous())
             else:
                 grad_b = grad_output.sum(0, dtype=torch.float64 if grad_output.dtype == torch.float64 else torch.float32)
+        if grad_w is not None and grad_w.dtype != ctx.weight_dtype:
+            grad_w = grad_w.to(ctx.weight_dtype)
         ctx.kernel_map = None  # release eagerly (reference unified.py:779-783)
         out = list(_pad_values(15, grad_in, grad_w))
         out[14] = grad_b

@@ -195,7 +195,8 @@ def spatially_sparse_conv(
     feats = input_sparse_tensor.feature_tensor
     if feats.dtype != effective_dtype:
         feats = feats.to(effective_dtype)
-    w = weight if weight.dtype == effective_dtype else weight.to(effective_dtype)
+    w = weight  # cast to the compute dtype INSIDE the autograd function: the low-precision copy is what gets saved, and the
+    #            weight gradient goes back to the fp32 master without a bf16 round trip (fp32 -> bf16 -> fp32, two launches)
 
     out_feats = UnifiedSpatiallySparseConvFunction.apply(
         feats, w, kernel_map, num_out, fwd_algo, dgrad_algo, wgrad_algo, effective_dtype,
