@@ -199,12 +199,24 @@ def main():
             Lc.wcn_conv_gather_gemm(_lib.ptr(grad_out), _lib.ptr(wp_d), _lib.ptr(dx_buf), _lib.ptr(km._nbr), _lib.ptr(km._mask),
                                     _lib.ptr(km._perm), None, N, N, COUT, CIN, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 1, 1, stream)
 
-        tk_fwd, tk_dgrad = time_events(k_fwd, it), time_events(k_dgrad, it)
+        # the weight-gradient entry point as the training step calls it (bias gradient fused): main kernel + the two
+        # small fixed-order reduce kernels, nothing else inside the event pair
+        dw_buf = torch.empty(KVOL, CIN, COUT, dtype=torch.float32, device=dev)
+        db_buf = torch.empty(COUT, dtype=torch.float32, device=dev)
+        ws_bytes = Lc.wcn_conv_wgrad_workspace(KVOL, CIN, COUT, _lib.WCN_ALGO_MFMA)
+        ws_buf = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+
+        def k_wgrad():
+            Lc.wcn_conv_wgrad_bias(_lib.ptr(X), _lib.ptr(grad_out), _lib.ptr(dw_buf), _lib.ptr(km.in_maps_device),
+                                   _lib.ptr(km.out_maps_device), _lib.ptr(km._offsets_dev), N, N, CIN, COUT, KVOL, _lib.WCN_BF16,
+                                   KVOL // 2, _lib.ptr(db_buf), _lib.ptr(ws_buf), ws_bytes, stream)
+
+        tk_fwd, tk_dgrad, tk_wgrad = time_events(k_fwd, it), time_events(k_dgrad, it), time_events(k_wgrad, it)
         ab = algorithmic_bytes(N, L)
         kernels = {
             "gather_gemm_mfma_kernel<bf16,64,128> (fwd)": (tk_fwd, ab["fwd"]),
             "gather_gemm_mfma_kernel<bf16,64,64> (dgrad)": (tk_dgrad, ab["dgrad"]),
-            "wgrad_mfma_kernel<bf16,64,128> (+reduce)": (t_wgrad, ab["wgrad"]),
+            "wgrad_mfma_kernel<bf16,64,128> (+ wgrad_reduce, wgrad_colsum_reduce)": (tk_wgrad, ab["wgrad"]),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
@@ -246,7 +258,7 @@ def main():
                                     "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(b)}
                              for name, (ms, b) in {**kernels, "kernel map build (~20 launches)": (t_kmap, ab["kmap"])}.items()},
             "phases_ms": {"kmap": round(t_kmap, 4), "fwd": round(t_fwd, 4), "dgrad": round(t_dgrad, 4), "wgrad": round(t_wgrad, 4),
-                          "fwd_kernel_only": round(tk_fwd, 4), "dgrad_kernel_only": round(tk_dgrad, 4)},
+                          "fwd_kernel_only": round(tk_fwd, 4), "dgrad_kernel_only": round(tk_dgrad, 4), "wgrad_kernels_only": round(tk_wgrad, 4)},
             "whole_step_hbm_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
