@@ -102,6 +102,15 @@ int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, in
 int wcn_batch_indexed_coords(const int32_t* coords, int64_t n, int32_t num_dims, const int32_t* offsets,
                              int32_t num_batches, int32_t* out, wcn_stream_t stream);
 
+/* Z-order (Morton) codes of integer coordinates: int64 codes[n].  num_dims 3: rows (x,y,z), 21 bits per axis
+ * interleaved with x in the lowest bit of every triple; num_dims 4: rows (b,x,y,z), (b << 48) | interleave of the low 16
+ * bits per axis.  `origin` [num_dims] int32 on the DEVICE (may be NULL) is subtracted first (the reference normalises by
+ * the per-column minimum); `axis[3]` (host) names the spatial column that feeds the x / y / z slot (MORTON_XYZ = {0,1,2},
+ * MORTON_ZYX = {2,1,0}, ...).  Replaces _C.coords.morton_code_20bit / morton_code_16bit
+ * (warpconvnet/csrc/morton_code.cu:27-103, call site geometry/coords/ops/serialization.py:196-245). */
+int wcn_morton_code(const int32_t* coords, int64_t n, int32_t num_dims, const int32_t* origin, const int32_t axis[3],
+                    int64_t* codes, wcn_stream_t stream);
+
 /* LDS-binned neighbour search for SUBMANIFOLD maps (query coords == input coords, stride 1): replaces
  * wcn_hash_insert + wcn_kmap_probe.  Voxels are binned into 16^3 blocks through a block-level hash table
  * (`slots`, capacity >= 2n, power of two; prepared by the call), then every block and its halo are staged in an
@@ -257,6 +266,21 @@ int wcn_knn_grid(const float* ref_sorted, const int32_t* ref_ids, const int32_t*
                  int64_t* out_index, float* out_dist2, wcn_stream_t stream);
 int wcn_segment_reduce(const void* in, const int64_t* row_splits, int64_t num_segments, int32_t channels, int32_t dtype,
                        int32_t op, void* out, int64_t* arg_rows, wcn_stream_t stream);
+
+/* Sparse pooling over a kernel map (REDUCE_AND_STRIDE, SparsePool / SparseMaxPool / SparseUnpool): out[m][c] =
+ * reduce over the present neighbours k of in[tbl[m][k]][c]; `tbl` is the row-major neighbour table [n_out][row pitch of
+ * num_offsets] (-1 = absent) that wcn_kmap_probe / wcn_kmap_from_csr / wcn_kmap_reverse produce.  op: 0 sum, 1 mean,
+ * 2 max, 3 min; rows without a neighbour give 0.  `arg` (may be NULL) int32 [n_out][channels] = winning input row of
+ * max / min (first extremum in offset order, -1 if none); `count` (may be NULL) int32 [n_out] = neighbours per row.
+ * One pass, no intermediate tensors; replaces to_csr + index gather + torch_scatter.segment_csr
+ * (warpconvnet/nn/functional/sparse_pool.py:84-110). */
+int wcn_pool_gather(const void* in, const int32_t* tbl, int64_t n_in, int64_t n_out, int32_t channels, int32_t num_offsets,
+                    int32_t dtype, int32_t op, void* out, int32_t* arg, int32_t* count, wcn_stream_t stream);
+/* Gradient of max / min pooling, output-stationary and deterministic: dx[n][c] = sum over the present k of
+ * dy[r][c] where r = tbl[n][k] and arg[r][c] == n.  `tbl` is the REVERSE table [n_in][pitch] (pooled rows per input
+ * row), `arg` the forward pass's [n_out][channels]. */
+int wcn_pool_select(const void* dy, const int32_t* arg, const int32_t* tbl, int64_t n_in, int64_t n_out, int32_t channels,
+                    int32_t num_offsets, int32_t dtype, void* dx, wcn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -301,3 +301,20 @@ def test_row_reduction_cpu_and_voxel_downsample():
     want = torch.zeros(len(uniq), 4).index_add_(0, inv, pc.feature_tensor) / torch.bincount(inv).unsqueeze(1)
     assert down.feature_tensor.shape == want.shape
     torch.testing.assert_close(down.feature_tensor, want, rtol=1e-5, atol=1e-6)
+
+
+def test_intsearchresult_pytree_roundtrip():
+    """IntSearchResult is a pytree node with children (in_maps, out_maps, offsets)
+    (reference tests/nn/test_torch_compile.py:190-207)."""
+    import warpconvnet_amd  # noqa: F401  (registers the node)
+    from torch.utils._pytree import tree_flatten, tree_unflatten
+    from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+
+    isr = IntSearchResult(torch.arange(10, dtype=torch.int32), torch.arange(10, dtype=torch.int32),
+                          torch.tensor([0, 3, 7, 10]), identity_map_index=1)
+    flat, spec = tree_flatten(isr)
+    assert len(flat) == 3
+    back = tree_unflatten(flat, spec)
+    assert isinstance(back, IntSearchResult) and back.identity_map_index == 1 and len(back) == 3
+    assert torch.equal(back.in_maps, isr.in_maps) and torch.equal(back.offsets, isr.offsets)
+    assert back[1][0].tolist() == [3, 4, 5, 6]

@@ -155,3 +155,39 @@ def test_stride_coords_oracle():
     full = np.concatenate([a[:, :1], want], 1)
     assert len(np.unique(full, axis=0)) == len(out)
     assert (np.diff(first) > 0).all() and (np.diff(out[:, 0]) >= 0).all()
+
+
+def test_morton_and_pool_oracle_known_answers():
+    """The numpy restatement of the z-order codes / orderings / sparse pooling against hand-computed values and the
+    properties the reference's tests pin (tests/coords/test_serialization.py:67-135, 193-240)."""
+    from oracle import serialization as oser
+
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1], [2, 0, 0], [3, 5, 7]], np.int32)
+    np.testing.assert_array_equal(oser.morton_code(pts), [0, 1, 2, 4, 7, 8, 431])  # x lowest bit; (3,5,7) = 7 + 5*8 + 6*64
+    np.testing.assert_array_equal(oser.morton_code(pts + 11), oser.morton_code(pts))  # per-column minimum removed
+    # axis permutation == encoding the permuted columns with xyz (test_serialization.py:116-135)
+    np.testing.assert_array_equal(oser.morton_code(pts, "morton_yxz"), oser.morton_code(pts[:, [1, 0, 2]]))
+    np.testing.assert_array_equal(oser.morton_code(pts, "morton_zyx"), oser.morton_code(pts[:, [2, 1, 0]]))
+    # batched: (b << 48) | 16-bit interleave
+    b = np.array([[0, 0, 0, 0], [2, 1, 1, 1], [1, 65535, 65535, 65535]], np.int32)
+    np.testing.assert_array_equal(oser.morton_code(b), [0, (2 << 48) | 7, (1 << 48) | ((1 << 48) - 1)])
+    # 21-bit single-batch range: the largest coordinate fills all 63 bits
+    big = np.array([[0, 0, 0], [(1 << 21) - 1] * 3], np.int32)
+    assert oser.morton_code(big)[1] == (1 << 63) - 1
+    # per-batch permutation: sorted inside every segment, segments stay put, distinct coordinates -> distinct codes
+    rng = np.random.default_rng(0)
+    c = np.unique(rng.integers(0, 40, size=(500, 3)), axis=0).astype(np.int32)
+    rng.shuffle(c)
+    offs = np.array([0, 100, 101, len(c)])
+    codes, perm = oser.encode_perm(c, offs)
+    assert len(np.unique(codes)) == len(c) and sorted(perm.tolist()) == list(range(len(c)))
+    for i in range(3):
+        seg = perm[offs[i] : offs[i + 1]]
+        assert ((seg >= offs[i]) & (seg < offs[i + 1])).all() and (np.diff(codes[seg]) > 0).all()
+    # pooling: two windows, one empty output row
+    f = np.array([[1.0, -2.0], [3.0, 5.0], [-4.0, 0.5]])
+    im, om = np.array([0, 1, 2]), np.array([0, 0, 2])
+    np.testing.assert_array_equal(oser.sparse_reduce(f, im, om, 3, "max"), [[3, 5], [0, 0], [-4, 0.5]])
+    np.testing.assert_array_equal(oser.sparse_reduce(f, im, om, 3, "min"), [[1, -2], [0, 0], [-4, 0.5]])
+    np.testing.assert_array_equal(oser.sparse_reduce(f, im, om, 3, "sum"), [[4, 3], [0, 0], [-4, 0.5]])
+    np.testing.assert_array_equal(oser.sparse_reduce(f, im, om, 3, "mean"), [[2, 1.5], [0, 0], [-4, 0.5]])

@@ -38,6 +38,10 @@ SIGNATURES = {
         [c_void_p, c_int64, c_void_p, c_int64, _3I, _3I, _3I, c_void_p, c_void_p, c_void_p],
     ),
     "wcn_batch_indexed_coords": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "wcn_pool_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    "wcn_pool_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "wcn_morton_code": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wcn_kmap_binned_workspace": (c_size_t, [c_int64]),
     "wcn_kmap_binned_supported": (c_int, [_3I, _3I]),
     "wcn_kmap_build_binned": (

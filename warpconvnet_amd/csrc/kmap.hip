@@ -279,6 +279,41 @@ __global__ __launch_bounds__(256) void batch_indexed_coords_kernel(const int32_t
   }
 }
 
+// Z-order codes.  spread3: bit i of a 21-bit value -> bit 3i (the usual shift-and-mask ladder).
+__device__ __forceinline__ uint64_t spread3(uint64_t v) {
+  v &= 0x1FFFFFull;
+  v = (v | (v << 32)) & 0x001F00000000FFFFull;
+  v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+  v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+  v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+// num_dims 3: [n,3] (x,y,z) -> 63-bit interleave, x in the lowest bit of every triple (single-batch "20-bit" path of the
+// reference, csrc/morton_code.cu:49-58).  num_dims 4: [n,4] (b,x,y,z) -> (b << 48) | 48-bit interleave of the low 16
+// bits per axis (batched "16-bit" path, morton_code.cu:27-45).  `origin` (device, may be NULL) is subtracted first -
+// the reference normalises by the per-column minimum (serialization.py:211-212); `axis[3]` = which spatial column feeds
+// the x / y / z slot (the MORTON_xyz permutations, serialization.py:44-51, 215-225).
+__global__ __launch_bounds__(256) void morton_code_kernel(const int32_t* __restrict__ coords, int64_t n, int d,
+                                                          const int32_t* __restrict__ origin, int a0, int a1, int a2,
+                                                          int64_t* __restrict__ codes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* c = coords + i * d;
+  const int sp = d - 3;  // first spatial column
+  int64_t v[3];
+  const int ax[3] = {a0, a1, a2};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) v[j] = (int64_t)c[sp + ax[j]] - (origin ? (int64_t)origin[sp + ax[j]] : 0);
+  uint64_t m = spread3((uint64_t)v[0]) | (spread3((uint64_t)v[1]) << 1) | (spread3((uint64_t)v[2]) << 2);
+  if (d == 4) {
+    const int64_t b = (int64_t)c[0] - (origin ? (int64_t)origin[0] : 0);
+    m = (m & 0x0000FFFFFFFFFFFFull) | ((uint64_t)b << 48);
+  }
+  codes[i] = (int64_t)m;
+}
+
 // nbr [m][kp] -> pair_table [K][m]
 __global__ __launch_bounds__(kThreads) void kmap_transpose_kernel(const int32_t* __restrict__ nbr, int64_t m, int K,
                                                                   int kp, int32_t* __restrict__ pair_table) {
@@ -468,6 +503,22 @@ int wcn_batch_indexed_coords(const int32_t* coords, int64_t n, int32_t num_dims,
   if (!coords || !out || (num_batches > 1 && !offsets)) return WCN_ERROR_INVALID_PARAMETERS;
   hipLaunchKernelGGL(batch_indexed_coords_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, coords,
                      n, (int)num_dims, offsets, (int)num_batches, out);
+  return launch_status();
+}
+
+int wcn_morton_code(const int32_t* coords, int64_t n, int32_t num_dims, const int32_t* origin, const int32_t axis[3],
+                    int64_t* codes, wcn_stream_t stream) {
+  if (n < 0 || (num_dims != 3 && num_dims != 4) || !axis) return WCN_ERROR_INVALID_PARAMETERS;
+  int seen = 0;
+  for (int j = 0; j < 3; ++j) {
+    if (axis[j] < 0 || axis[j] > 2) return WCN_ERROR_INVALID_PARAMETERS;
+    seen |= 1 << axis[j];
+  }
+  if (seen != 7) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n == 0) return WCN_SUCCESS;
+  if (!coords || !codes) return WCN_ERROR_INVALID_PARAMETERS;
+  hipLaunchKernelGGL(morton_code_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, coords, n,
+                     (int)num_dims, origin, (int)axis[0], (int)axis[1], (int)axis[2], codes);
   return launch_status();
 }
 

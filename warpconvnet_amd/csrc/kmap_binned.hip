@@ -76,13 +76,18 @@ __global__ void bin_prepare_kernel(uint4* __restrict__ slots, int64_t capacity, 
 __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, const int4* __restrict__ coords, int64_t n,
                                   int32_t* __restrict__ vox_slot, int32_t* __restrict__ blk_slot,
                                   int32_t* __restrict__ slot_id, int32_t* __restrict__ nblk, int32_t* __restrict__ cnt,
-                                  int32_t* __restrict__ status) {
+                                  int32_t* __restrict__ status, int kp, int mw, int32_t* __restrict__ nbr,
+                                  uint32_t* __restrict__ mask) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = coords[i];
   if (!coord_in_range(c.x, c.y, c.z, c.w)) {
     atomicOr(status, (int)WCN_FLAG_COORD_RANGE);
     vox_slot[i] = -1;
+    // the voxel is in no bin, so bin_neighbors never visits it: give its table row defined ("no neighbour") content -
+    // consumers may already be queued behind this build when the host sees the flag
+    for (int k = 0; k < kp; ++k) nbr[i * kp + k] = -1;
+    for (int w = 0; w < mw; ++w) mask[i * mw + w] = 0u;
     return;
   }
   const uint64_t key = block_key(c.x, c.y >> kBlkShift, c.z >> kBlkShift, c.w >> kBlkShift);
@@ -435,7 +440,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   const uint32_t cmask = (uint32_t)(capacity - 1);
   const unsigned gn = (unsigned)ceil_div(n, 256);
   hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n, w.vox_slot,
-                     w.blk_slot, w.slot_id, w.nblk, w.cnt, status);
+                     w.blk_slot, w.slot_id, w.nblk, w.cnt, status, kp, mw, nbr, mask);
   hipLaunchKernelGGL(bin_count_kernel, dim3(gn), dim3(256), 0, s, (const int4*)coords, n, g.hx, g.hy, g.hz,
                      (const int32_t*)w.vox_slot, (const int32_t*)w.slot_id, w.cnt, w.vox_pos, status);
   hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, w.cnt, (const int32_t*)w.nblk, n,

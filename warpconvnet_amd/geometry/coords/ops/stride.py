@@ -3,7 +3,7 @@
 Reference: `warpconvnet/geometry/coords/ops/stride.py:18-56` (floor-divide, hash de-duplicate,
 ``torch.unique`` of winner indices, UNSTABLE argsort by batch).  Here the surviving rows are the first
 occurrences in input order; because inputs are batch-sorted, so are the outputs - no argsort, and the
-output row order is deterministic.
+output row order is deterministic.  A Morton ``order`` re-sorts the survivors by (batch, z-order code).
 """
 from typing import Tuple
 
@@ -26,4 +26,9 @@ def stride_coords(batch_indexed_coords: Tensor, stride: Tuple[int, ...], order=N
     coarse = torch.div(batch_indexed_coords, div, rounding_mode="floor").to(torch.int32)
     idx = unique_first_indices(coarse)
     out = coarse[idx].contiguous()
+    from warpconvnet_amd.geometry.coords.ops.serialization import POINT_ORDERING, encode, to_point_ordering
+
+    order = to_point_ordering(order)
+    if order != POINT_ORDERING.RANDOM:  # (batch, z-order) sort: the batch index sits above the code bits (stride.py:52-54)
+        out = out[encode(out, order=order, return_perm=True).perm].contiguous()
     return out, offsets_from_batch_index(out[:, 0])

@@ -120,6 +120,7 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
     return kmap._rev
 
 
+@torch.compiler.disable
 @torch.no_grad()
 def generate_kernel_map(
     batch_indexed_in_coords: Tensor,

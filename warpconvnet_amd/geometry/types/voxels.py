@@ -81,6 +81,24 @@ class Voxels(Geometry):
         feats = CatFeatures(self.batched_features.batched_tensor[idx], offsets)
         return self.__class__(coords, feats, **self.extra_attributes)
 
+    def sort(self, ordering="morton_xyz") -> "Voxels":
+        """Rows of every batch element in space-filling-curve order (reference `types/voxels.py:248-269`); the
+        codes are kept as the ``code`` attribute, the ordering as ``ordering``."""
+        from warpconvnet_amd.geometry.coords.ops.serialization import encode, to_point_ordering
+
+        ordering = to_point_ordering(ordering)
+        if ordering == self.ordering:
+            return self
+        assert isinstance(self.batched_features, CatFeatures), "Features must be a CatFeatures to sort."
+        res = encode(self.coordinate_tensor, batch_offsets=self.offsets, order=ordering, return_perm=True)
+        kwargs = self.extra_attributes
+        kwargs["ordering"], kwargs["code"] = ordering, res.codes
+        kwargs.pop("_cache", None)  # cached kernel maps index rows of the old order
+        kwargs.pop("_spatial_cache", None)
+        coords = IntCoords(self.coordinate_tensor[res.perm], self.offsets, tensor_stride=self.tensor_stride)
+        feats = CatFeatures(self.batched_features.batched_tensor[res.perm], self.offsets)
+        return self.__class__(coords, feats, **kwargs)
+
     def to_dense(self, channel_dim: int = 1, spatial_shape: Optional[Tuple[int, ...]] = None,
                  min_coords: Optional[Tuple[int, ...]] = None, max_coords: Optional[Tuple[int, ...]] = None) -> Tensor:
         """[B, C, *spatial] dense tensor (channel position selectable), zeros where no voxel exists."""

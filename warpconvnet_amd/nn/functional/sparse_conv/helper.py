@@ -1,9 +1,8 @@
 """Orchestration of one sparse convolution: output coordinates, kernel-map cache, dtype policy, GEMM dispatch.
 
 Counterpart of `warpconvnet/nn/functional/sparse_conv/helper.py:147-567` (``spatially_sparse_conv``,
-``generate_output_coords_and_kernel_map``) with the same argument surface.  Not built (out of the hot-path
-scope): generative convolution, ``REDUCE_AND_STRIDE`` pooling and non-random output orderings
-raise ``NotImplementedError``.
+``generate_output_coords_and_kernel_map``) with the same argument surface, incl. generative convolution,
+``REDUCE_AND_STRIDE`` (pool, then convolve at stride 1) and Morton orderings of the output rows.
 """
 from enum import Enum
 from typing import List, Optional, Tuple, Union
@@ -49,6 +48,7 @@ def _cpu_kernel_map(in_coords: Tensor, out_coords: Tensor, stride, kernel_size, 
 
 
 @torch.no_grad()
+@torch.compiler.disable
 def generate_output_coords_and_kernel_map(
     input_sparse_tensor: Voxels,
     kernel_size: Tuple[int, ...],
@@ -63,8 +63,6 @@ def generate_output_coords_and_kernel_map(
     out_code_backend: Optional[str] = None,
 ) -> Tuple[Tensor, Tensor, IntSearchResult]:
     """Returns ``(batch_indexed_out_coords [M, D+1], out_offsets (CPU), kernel_map)``."""
-    if stride_mode != STRIDED_CONV_MODE.STRIDE_ONLY and any(s != 1 for s in stride):
-        raise NotImplementedError("REDUCE_AND_STRIDE is outside the built hot path (SURVEY.md §2a P9)")
     bcoords_in = input_sparse_tensor.batch_indexed_coordinates
     if bcoords_in.dtype != torch.int32:
         bcoords_in = bcoords_in.to(torch.int32)
@@ -94,7 +92,19 @@ def generate_output_coords_and_kernel_map(
     else:
         bcoords_out, out_offsets = bcoords_in, input_sparse_tensor.offsets
 
-    key = IntSearchCacheKey(kernel_size, kernel_dilation, transposed, generative, str(stride_mode), False,
+    # optional space-filling-curve order of the OUTPUT rows (reference helper.py:435-443): every batch element is sorted
+    # on its own, so the offsets stay valid
+    from warpconvnet_amd.geometry.coords.ops.serialization import POINT_ORDERING, encode, to_point_ordering
+
+    order = to_point_ordering(order)
+    if order != POINT_ORDERING.RANDOM and bcoords_out.shape[0] > 0:
+        perm = encode(bcoords_out[:, 1:], batch_offsets=out_offsets, order=order, return_perm=True).perm
+        bcoords_out = bcoords_out[perm].contiguous()
+
+    # (the reference's key ignores the ordering, so an ordered and an unordered layer on the same tensor would share one
+    # map and one of them would read rows of the other's order; here the ordering is part of the key)
+    mode_key = str(stride_mode) if order == POINT_ORDERING.RANDOM else f"{stride_mode}|{order.value}"
+    key = IntSearchCacheKey(kernel_size, kernel_dilation, transposed, generative, mode_key, False,
                             input_sparse_tensor.offsets, out_offsets)
     if input_sparse_tensor.cache is not None:
         hit = input_sparse_tensor.cache.get(key)
@@ -120,6 +130,7 @@ def generate_output_coords_and_kernel_map(
     return bcoords_out, out_offsets, kernel_map
 
 
+@torch.compiler.disable
 def spatially_sparse_conv(
     input_sparse_tensor: Geometry,
     weight: Tensor,
@@ -184,6 +195,14 @@ def spatially_sparse_conv(
         effective_dtype = input_sparse_tensor.feature_tensor.dtype
     if use_fp16_accum is None:
         use_fp16_accum = get_fp16_accum()  # accepted for API parity: MFMA accumulates in fp32 regardless
+
+    # REDUCE_AND_STRIDE: pool the input over stride-sized windows first, then convolve the pooled tensor at stride 1
+    # (reference helper.py:273-289); the pooled tensor carries the output tensor stride already
+    if stride_mode == STRIDED_CONV_MODE.REDUCE_AND_STRIDE and any(s != 1 for s in _stride):
+        from warpconvnet_amd.nn.functional.sparse_pool import sparse_reduce
+
+        input_sparse_tensor = sparse_reduce(input_sparse_tensor, kernel_size=_stride, stride=_stride, reduction=stride_reduce)
+        _stride = ntuple(1, ndim=nd)
 
     bcoords_out, out_offsets, kernel_map = generate_output_coords_and_kernel_map(
         input_sparse_tensor, _kernel_size, _dilation, _stride, generative=generative, transposed=transposed,

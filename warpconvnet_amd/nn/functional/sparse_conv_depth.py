@@ -207,6 +207,7 @@ class UnifiedSpatiallySparseDepthwiseConvFunction(Function):
         return grad_in, grad_w, None, None, None, None, None
 
 
+@torch.compiler.disable
 def spatially_sparse_depthwise_conv(
     in_features: Tensor,
     weight: Tensor,
