@@ -222,6 +222,27 @@ def main():
         dom_ms, dom_bytes = kernels[dom]
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process;
         # tools/collect_profiles.sh + tools/rocpd_stats.py produce the file from this very command line)
+        # map-cached variant (networks amortise the map over the layers of a resolution level): the same
+        # module step on a geometry whose cache already holds the kernel map - GEMMs only, through autograd
+        x_cached = Voxels(coords, feats, offsets=offsets)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            conv(x_cached)  # fills x_cached.cache
+
+        def cached_step():
+            for p in params:
+                p.grad = None
+            feats.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                yc = conv(x_cached)
+            yc.batched_features.batched_tensor.backward(grad_out)
+
+        t_cached = time_events(cached_step, it)
+        # compulsory-traffic lower bound: every L*C term replaced by N*C - what an ideal cache would leave
+        e = 2
+        compulsory = (ab["kmap"]
+                      + (N * CIN * e + KVOL * CIN * COUT * e + N * COUT * e + 4 * KVOL * N)
+                      + (N * COUT * e + KVOL * CIN * COUT * e + N * CIN * e + 4 * KVOL * N)
+                      + (N * (CIN + COUT) * e + 4 * KVOL * CIN * COUT + 4 * KVOL * N))
         traffic, traffic_src = None, None
         pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
         if N == 1_000_000 and os.path.exists(pmc_file):
@@ -260,6 +281,9 @@ def main():
             "phases_ms": {"kmap": round(t_kmap, 4), "fwd": round(t_fwd, 4), "dgrad": round(t_dgrad, 4), "wgrad": round(t_wgrad, 4),
                           "fwd_kernel_only": round(tk_fwd, 4), "dgrad_kernel_only": round(tk_dgrad, 4), "wgrad_kernels_only": round(tk_wgrad, 4)},
             "whole_step_hbm_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "whole_step_compulsory_hbm_frac": round(compulsory / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "map_cached": {"value": round(N / (t_cached * 1e-3) / 1e6, 3), "unit": "M voxels/s", "ms_per_step": round(t_cached, 4),
+                           "note": "same step with the kernel map taken from the geometry's cache (fwd + dgrad + wgrad only)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)

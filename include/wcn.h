@@ -206,6 +206,18 @@ int wcn_conv_gather_gemm_f32out(const void* in, const void* w_packed, float* out
                                 int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
                                 wcn_stream_t stream);
 
+/* Gather GEMM with the elementwise chain of a ConvBlock folded into the store (the reference runs
+ * conv -> BatchNorm1d -> ReLU (+ residual add) as separate kernels, models/mink_unet.py:31-53, 161-175):
+ *   out[m][co] = act( (sum_k in[nbr[m][k]] . W[k] + bias[co]) * scale[co] + shift[co] + residual[m][co] )
+ * evaluated in fp32 before the single rounding to the storage dtype.  bias / scale+shift / residual may be NULL
+ * (scale and shift only together); BatchNorm in inference mode is scale = gamma / sqrt(var + eps),
+ * shift = beta - mean * scale; relu != 0 applies max(., 0).  `residual` [n_out, cout] has the storage dtype and must not
+ * alias `out`.  MFMA path only (f16 / bf16, shapes of wcn_mfma_gather_supported, `w_packed` from wcn_pack_weight). */
+int wcn_conv_gather_gemm_fused(const void* in, const void* w_packed, void* out, const int32_t* nbr, const uint32_t* mask,
+                               const int32_t* perm, const float* bias, const float* scale, const float* shift,
+                               const void* residual, int32_t relu, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout,
+                               int32_t num_offsets, int32_t dtype, wcn_stream_t stream);
+
 /* out[c] = sum_r in[r][c] in fp32 (bias gradient; reference: autograd of `out + bias`, helper.py:339-342).
  * Deterministic two-pass reduction; workspace: wcn_colsum_workspace(channels) bytes. */
 size_t wcn_colsum_workspace(int32_t channels);

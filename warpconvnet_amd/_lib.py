@@ -82,6 +82,11 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
          c_int32, c_int32, c_void_p],
     ),
+    "wcn_conv_gather_gemm_fused": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+         c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    ),
     "wcn_colsum_workspace": (c_size_t, [c_int32]),
     "wcn_colsum": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wcn_conv_wgrad_workspace": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),

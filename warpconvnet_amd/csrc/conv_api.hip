@@ -12,7 +12,7 @@ int conv_wgrad_ref(const void* x, const void* dy, float* dw, const int32_t* in_m
 // conv_mfma.hip
 bool mfma_gather_supported(int cin, int cout, int K, int dtype);
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                          const int32_t* perm, const float* bias, int64_t n_out, int cin, int cout, int K, int dtype,
+                          const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
                           float* out32, hipStream_t s);
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s);
@@ -77,7 +77,11 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
     case WCN_ALGO_MFMA:
       // `w` must be the packed image (wcn_pack_weight already applied transpose / flip)
       if (!mask) return WCN_ERROR_INVALID_PARAMETERS;
-      return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, nullptr, s);
+      {
+        ConvEpilogue epi;
+        epi.bias = bias;
+        return conv_gather_gemm_mfma(in, w, out, nbr, mask, perm, epi, n_out, cin, cout, num_offsets, dtype, nullptr, s);
+      }
     default:
       // AUTO cannot be resolved here because the two algorithms take different weight images.
       return WCN_ERROR_INVALID_PARAMETERS;
@@ -91,7 +95,24 @@ int wcn_conv_gather_gemm_f32out(const void* in, const void* w, float* out, const
     return WCN_ERROR_INVALID_PARAMETERS;
   if (n_out == 0) return WCN_SUCCESS;
   if (!w || !out || !nbr || !mask || (n_in > 0 && !in)) return WCN_ERROR_INVALID_PARAMETERS;
-  return conv_gather_gemm_mfma(in, w, nullptr, nbr, mask, perm, bias, n_out, cin, cout, num_offsets, dtype, out,
+  ConvEpilogue epi;
+  epi.bias = bias;
+  return conv_gather_gemm_mfma(in, w, nullptr, nbr, mask, perm, epi, n_out, cin, cout, num_offsets, dtype, out,
+                               (hipStream_t)stream);
+}
+
+int wcn_conv_gather_gemm_fused(const void* in, const void* w_packed, void* out, const int32_t* nbr, const uint32_t* mask,
+                               const int32_t* perm, const float* bias, const float* scale, const float* shift,
+                               const void* residual, int32_t relu, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout,
+                               int32_t num_offsets, int32_t dtype, wcn_stream_t stream) {
+  if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || (dtype != WCN_F16 && dtype != WCN_BF16) ||
+      ((scale == nullptr) != (shift == nullptr)))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  if (n_out == 0) return WCN_SUCCESS;
+  if (!w_packed || !out || !nbr || !mask || (n_in > 0 && !in) || residual == out) return WCN_ERROR_INVALID_PARAMETERS;
+  ConvEpilogue epi;
+  epi.bias = bias; epi.scale = scale; epi.shift = shift; epi.residual = residual; epi.relu = relu ? 1 : 0;
+  return conv_gather_gemm_mfma(in, w_packed, out, nbr, mask, perm, epi, n_out, cin, cout, num_offsets, dtype, nullptr,
                                (hipStream_t)stream);
 }
 

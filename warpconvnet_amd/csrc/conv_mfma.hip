@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
                                                                T* __restrict__ out, const int32_t* __restrict__ nbr,
                                                                const uint32_t* __restrict__ mask,
                                                                const int32_t* __restrict__ perm,
-                                                               const float* __restrict__ bias, int64_t n_out, int cin,
+                                                               const ConvEpilogue epi, int64_t n_out, int cin,
                                                                int K, int kp, int mw, float* __restrict__ out32) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   typedef typename G::frag_t frag_t;
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           float4 o = make_float4(acc[b][rb][4 * v + 0], acc[b][rb][4 * v + 1], acc[b][rb][4 * v + 2], acc[b][rb][4 * v + 3]);
-          if (bias) {
-            const float4 bv = reinterpret_cast<const float4*>(bias + h * (CO / 2) + 16 * b)[v];
+          if (epi.bias) {
+            const float4 bv = reinterpret_cast<const float4*>(epi.bias + h * (CO / 2) + 16 * b)[v];
             o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
           }
           reinterpret_cast<float4*>(dst + 16 * b)[v] = o;
@@ -362,14 +362,34 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       frag_t lo, hi;
-      if (bias) {  // fused epilogue: + bias[co] in fp32 before the rounding to the storage dtype
-        const float4* bp = reinterpret_cast<const float4*>(bias + h * (CO / 2) + 16 * b);
+      if (epi.bias) {  // fused epilogue: + bias[co] in fp32 before the rounding to the storage dtype
+        const float4* bp = reinterpret_cast<const float4*>(epi.bias + h * (CO / 2) + 16 * b);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const float4 bv = bp[v];
           acc[b][rb][4 * v + 0] += bv.x; acc[b][rb][4 * v + 1] += bv.y;
           acc[b][rb][4 * v + 2] += bv.z; acc[b][rb][4 * v + 3] += bv.w;
         }
+      }
+      if (epi.scale) {  // per-channel affine (BatchNorm in inference mode)
+        const float4* sp4 = reinterpret_cast<const float4*>(epi.scale + h * (CO / 2) + 16 * b);
+        const float4* tp4 = reinterpret_cast<const float4*>(epi.shift + h * (CO / 2) + 16 * b);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float4 sv = sp4[v], tv = tp4[v];
+          acc[b][rb][4 * v + 0] = acc[b][rb][4 * v + 0] * sv.x + tv.x; acc[b][rb][4 * v + 1] = acc[b][rb][4 * v + 1] * sv.y + tv.y;
+          acc[b][rb][4 * v + 2] = acc[b][rb][4 * v + 2] * sv.z + tv.z; acc[b][rb][4 * v + 3] = acc[b][rb][4 * v + 3] * sv.w + tv.w;
+        }
+      }
+      if (!kStaged && epi.residual && r >= 0) {  // direct path: the lane owns 16 contiguous channels of its row
+        const T* rp = reinterpret_cast<const T*>(epi.residual) + (int64_t)r * CO + h * (CO / 2) + 16 * b;
+        const frag_t r0 = *reinterpret_cast<const frag_t*>(rp), r1 = *reinterpret_cast<const frag_t*>(rp + 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { acc[b][rb][q] += (float)r0[q]; acc[b][rb][8 + q] += (float)r1[q]; }
+      }
+      if (epi.relu && !(kStaged && epi.residual)) {  // (with a staged residual the activation follows the add below)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[b][rb][q] = fmaxf(acc[b][rb][q], 0.f);
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -393,9 +413,21 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
         const int row = r0 + rsub;
         if (rsub < kRowsPerInstr && row < 32) {
           const int32_t rr = s_rows[wave * RPW + rb * 32 + row];
-          if (rr >= 0)  // streamed once: non-temporal, so the output does not push the gathered input out of the caches
-            __builtin_nontemporal_store(*reinterpret_cast<const frag_t*>(stage + row * kPitch + piece * 16),
-                                        reinterpret_cast<frag_t*>(out + (int64_t)rr * CO + piece * 8));
+          if (rr >= 0) {
+            frag_t o = *reinterpret_cast<const frag_t*>(stage + row * kPitch + piece * 16);
+            if (epi.residual) {  // residual rows are read the way the output is written: whole rows, adjacent lanes
+              const frag_t rv = __builtin_nontemporal_load(
+                  reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(epi.residual) + (int64_t)rr * CO + piece * 8));
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                float f = (float)o[q] + (float)rv[q];
+                if (epi.relu) f = fmaxf(f, 0.f);
+                o[q] = (T)f;
+              }
+            }
+            // streamed once: non-temporal, so the output does not push the gathered input out of the caches
+            __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)rr * CO + piece * 8));
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // next block overwrites the stage
@@ -409,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 
 template <typename T, int CIC, int CO, int RB>
 static int launch_gather_gemm(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                              const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, float* out32,
+                              const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
                               hipStream_t s) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   const int kp = wcn_kmap_row_pitch(K);
@@ -426,24 +458,24 @@ static int launch_gather_gemm(const void* in, const void* wp, void* out, const i
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
   if (mw == 1)
     hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, false>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, mw, out32);
+                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32);
   else
     hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, true>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, bias, n_out, cin, K, kp, mw, out32);
+                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32);
   return launch_status();
 }
 
 template <typename T, int CIC>
 static int dispatch_co(int cout, const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                       const int32_t* perm, const float* bias, int64_t n_out, int cin, int K, float* out32,
+                       const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
                        hipStream_t s) {
   switch (cout) {
-    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
-    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
-    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
-    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
-    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
-    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
@@ -464,22 +496,22 @@ bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
 
 template <typename T>
 static int dispatch_cic(int cin, int cout, const void* in, const void* wp, void* out, const int32_t* nbr,
-                        const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_out, int K, float* out32,
+                        const uint32_t* mask, const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int K, float* out32,
                         hipStream_t s) {
   switch (mfma_chunk_for(cin)) {
-    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
-    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
-    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, bias, n_out, cin, K, out32, s);
+    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
 
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                          const int32_t* perm, const float* bias, int64_t n_out, int cin, int cout, int K, int dtype,
+                          const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
                           float* out32, hipStream_t s) {
   if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
-  if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, out32, s);
-  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, bias, n_out, K, out32, s);
+  if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, out32, s);
+  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, out32, s);
 }
 
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,

@@ -94,4 +94,15 @@ inline int launch_status() {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Epilogue of the gather GEMM, applied in fp32 before the result is rounded to the storage dtype:
+//   y = act((acc + bias) * scale + shift + residual)      every term optional (null / 0 = absent)
+// BatchNorm in inference mode is scale = gamma / sqrt(var + eps), shift = beta - mean * scale.
+struct ConvEpilogue {
+  const float* bias = nullptr;     // [cout]
+  const float* scale = nullptr;    // [cout], used together with shift
+  const float* shift = nullptr;    // [cout]
+  const void* residual = nullptr;  // [n_out][cout] in the storage dtype
+  int relu = 0;
+};
+
 }  // namespace wcn

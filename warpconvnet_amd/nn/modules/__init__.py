@@ -1,4 +1,5 @@
 from .base_module import BaseSpatialModel, BaseSpatialModule
+from .fused_block import FusedSparseConvBlock
 from .mlp import MLPBlock
 from .point_conv import PointConv
 from .sequential import Sequential
@@ -8,4 +9,4 @@ from .sparse_conv_depth import SparseDepthwiseConv2d, SparseDepthwiseConv3d, Spa
 
 __all__ = ["BaseSpatialModel", "BaseSpatialModule", "MLPBlock", "PointConv", "Sequential", "SparseConv2d", "SparseConv3d", "SpatiallySparseConv",
            "SparseDepthwiseConv2d", "SparseDepthwiseConv3d", "SpatiallySparseDepthwiseConv",
-           "GlobalPool", "SparseMaxPool", "SparseMinPool", "SparsePool", "SparseUnpool"]
+           "FusedSparseConvBlock", "GlobalPool", "SparseMaxPool", "SparseMinPool", "SparsePool", "SparseUnpool"]
