@@ -276,6 +276,17 @@ int wcn_dwconv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in
 int wcn_knn_grid(const float* ref_sorted, const int32_t* ref_ids, const int32_t* cell_start, const float origin[3],
                  float cell_size, const int32_t dims[3], const float* query, int64_t num_query, int32_t k,
                  int64_t* out_index, float* out_dist2, wcn_stream_t stream);
+/* Radius search over the same cell layout (cell_size >= radius, so the 27 cells around a query hold every point within
+ * the radius; test `dist^2 <= radius^2`).  Two passes like the reference (warpconvnet/csrc/radius_search_kernels.cu:30-134,
+ * call site geometry/coords/search/radius.py:16-124): wcn_radius_grid_count writes counts [M] int32; the caller scans them
+ * into splits [M+1] int64 (device) and sizes the outputs; wcn_radius_grid_write fills out_index [total] int32 (original row
+ * ids) and out_dist [total] fp32 distances (may be NULL).  Rows are in cell-walk order, deterministic. */
+int wcn_radius_grid_count(const float* ref_sorted, const int32_t* ref_ids, const int32_t* cell_start, const float origin[3],
+                          float cell_size, const int32_t dims[3], const float* query, int64_t num_query, float radius,
+                          int32_t* counts, wcn_stream_t stream);
+int wcn_radius_grid_write(const float* ref_sorted, const int32_t* ref_ids, const int32_t* cell_start, const float origin[3],
+                          float cell_size, const int32_t dims[3], const float* query, int64_t num_query, float radius,
+                          const int64_t* splits, int32_t* out_index, float* out_dist, wcn_stream_t stream);
 int wcn_segment_reduce(const void* in, const int64_t* row_splits, int64_t num_segments, int32_t channels, int32_t dtype,
                        int32_t op, void* out, int64_t* arg_rows, wcn_stream_t stream);
 

@@ -91,3 +91,70 @@ def test_pointconv_config5_shape_runs():
     assert y.feature_tensor.shape == vox.feature_tensor.shape and torch.isfinite(y.feature_tensor).all()
     y.feature_tensor.sum().backward()
     assert conv.edge_transform_mlp.block[0].weight.grad is not None and dw.weight.grad is not None
+
+
+@pytest.mark.parametrize("n,m,radius,shape", [(20000, 4000, 0.05, "cube"), (5000, 5000, 0.0, "cube"), (30000, 1500, 2.0, "slab"),
+                                              (300, 200, 5.0, "cube"), (900, 400, 0.7, "line")])
+def test_radius_grid_equals_brute_force(n, m, radius, shape):
+    """Every point with dist <= radius, nothing else; per-query rows compared as sets (the order inside a row is
+    implementation-defined in the reference too), distances = sqrt of the fp32 squared distance."""
+    from warpconvnet_amd.geometry.coords.search.radius import radius_search
+
+    g = torch.Generator().manual_seed(n + m)
+    scale = {"cube": torch.tensor([1.0, 1.0, 1.0]), "slab": torch.tensor([50.0, 50.0, 4.0]), "line": torch.tensor([100.0, 0.01, 0.01])}[shape]
+    ref = (torch.rand(n, 3, generator=g) * scale).to(_dev())
+    qry = ((torch.rand(m, 3, generator=g) * 1.2 - 0.1) * scale).to(_dev())
+    if radius == 0.0:
+        qry = ref[:m].clone()  # radius 0: a query finds exactly the points at its own position
+    idx, dist, split = radius_search(ref, qry, radius)
+    assert idx.dtype == torch.int32 and dist.dtype == torch.float32 and split.dtype == torch.int32
+    assert split.shape == (m + 1,) and int(split[-1]) == idx.shape[0] == dist.shape[0]
+    # brute force with the kernel's own arithmetic (fp32 differences, fp32 sum of squares)
+    d2 = ((qry.unsqueeze(1) - ref.unsqueeze(0)) ** 2).sum(-1) if n * m <= 4e7 else None
+    if d2 is None:
+        d2 = torch.cat([((qry[s : s + 512].unsqueeze(1) - ref.unsqueeze(0)) ** 2).sum(-1) for s in range(0, m, 512)])
+    inside = d2 <= radius * radius
+    np.testing.assert_array_equal((split[1:] - split[:-1]).cpu().numpy(), inside.sum(1).cpu().numpy())
+    rows = torch.repeat_interleave(torch.arange(m, device=_dev()), (split[1:] - split[:-1]).long())
+    got = torch.zeros_like(inside)
+    got[rows, idx.long()] = True
+    # fp32 summation order of the three squares may differ by an ulp from torch's: allow disagreement only on the boundary
+    diff = got != inside
+    assert (diff.sum() == 0) or ((d2[diff] - radius * radius).abs() <= 1e-6 * max(radius * radius, 1e-12)).all()
+    torch.testing.assert_close(dist, d2[rows, idx.long()].sqrt(), rtol=1e-5, atol=1e-7)
+    assert (dist <= radius * (1 + 1e-6) + 1e-12).all()
+
+
+def test_batched_radius_and_pointconv_radius():
+    """Batched search (global row ids, no pair across batch elements), `Points.neighbors`, and PointConv on a radius
+    graph (ragged rows) against the same module on CPU tensors (cdist brute force + torch reductions)."""
+    from warpconvnet_amd.geometry.coords.search.radius import batched_radius_search
+    from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
+    from warpconvnet_amd.geometry.types.points import Points
+    from warpconvnet_amd.nn.modules.point_conv import PointConv
+
+    g = torch.Generator().manual_seed(3)
+    pts = [torch.rand(1500, 3, generator=g), torch.rand(900, 3, generator=g) + 0.5]  # overlapping boxes: batches must not mix
+    feats = [torch.randn(len(p), 8, generator=g) for p in pts]
+    ref = torch.cat(pts).to(_dev())
+    offs = torch.tensor([0, 1500, 2400])
+    idx, dist, split = batched_radius_search(ref, offs, ref, offs, 0.08)
+    assert idx.dtype == torch.int64 and split.dtype == torch.int64 and split.shape == (2401,) and int(split[-1]) == len(idx)
+    rows = torch.repeat_interleave(torch.arange(2400, device=_dev()), split[1:] - split[:-1])
+    assert ((rows < 1500) == (idx < 1500)).all()
+    want = torch.cat([(torch.cdist(p, p) <= 0.08).sum(1) for p in pts])
+    assert ((split[1:] - split[:-1]).cpu() - want).abs().max() <= 1  # cdist's own rounding at the boundary
+    cfg = RealSearchConfig("radius", radius=0.08)
+    pc_gpu = Points(pts, feats, device=_dev())
+    pc_cpu = Points(pts, feats)
+    nb = pc_gpu.neighbors(cfg)
+    assert int(nb.neighbor_row_splits[-1]) == len(nb.neighbor_indices)
+    torch.manual_seed(0)
+    conv = PointConv(8, 16, neighbor_search_args=cfg, out_point_type="same")
+    y_cpu = conv(pc_cpu)
+    conv_gpu = conv.to(_dev())
+    x = pc_gpu.replace(batched_features=pc_gpu.feature_tensor.clone().requires_grad_(True))
+    y_gpu = conv_gpu(x)
+    torch.testing.assert_close(y_gpu.feature_tensor.cpu(), y_cpu.feature_tensor, rtol=2e-3, atol=2e-4)
+    y_gpu.feature_tensor.square().sum().backward()
+    assert torch.isfinite(x.feature_tensor.grad).all() and x.feature_tensor.grad.abs().sum() > 0

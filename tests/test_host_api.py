@@ -318,3 +318,29 @@ def test_intsearchresult_pytree_roundtrip():
     assert isinstance(back, IntSearchResult) and back.identity_map_index == 1 and len(back) == 3
     assert torch.equal(back.in_maps, isr.in_maps) and torch.equal(back.offsets, isr.offsets)
     assert back[1][0].tolist() == [3, 4, 5, 6]
+
+
+def test_radius_search_cpu_contract():
+    """Result types / shapes of the radius search front end (reference radius.py:162-291, continuous.py:36-53) on the
+    CPU path: int32 index + split, fp32 distance; batched: global int64 ids, no neighbour across batch elements."""
+    from warpconvnet_amd.geometry.coords.search.continuous import neighbor_search
+    from warpconvnet_amd.geometry.coords.search.radius import batched_radius_search, radius_search
+    from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
+
+    g = torch.Generator().manual_seed(0)
+    p, q = torch.rand(300, 3, generator=g), torch.rand(40, 3, generator=g)
+    idx, dist, split = radius_search(p, q, 0.25)
+    assert idx.dtype == torch.int32 and dist.dtype == torch.float32 and split.dtype == torch.int32 and split.shape == (41,)
+    d = torch.cdist(q, p)
+    for i in (0, 7, 39):
+        row = idx[split[i] : split[i + 1]].long()
+        assert set(row.tolist()) == set(torch.nonzero(d[i] <= 0.25).view(-1).tolist())
+        assert torch.allclose(dist[split[i] : split[i + 1]], d[i, row])
+    e = radius_search(p, torch.empty(0, 3), 0.1)
+    assert e[0].shape == (0,) and e[2].tolist() == [0]
+    offs_p, offs_q = torch.tensor([0, 100, 300]), torch.tensor([0, 10, 40])
+    bi, bd, bs = batched_radius_search(p, offs_p, q, offs_q, 0.25)
+    assert bi.dtype == torch.int64 and bs.dtype == torch.int64 and bs.shape == (41,) and int(bs[-1]) == len(bi)
+    assert (bi[: bs[10]] < 100).all() and (bi[bs[10] :] >= 100).all()
+    r = neighbor_search(p, offs_p, q, offs_q, RealSearchConfig("radius", radius=0.25))
+    assert torch.equal(r.neighbor_indices, bi) and torch.equal(r.neighbor_row_splits, bs)

@@ -105,6 +105,16 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
          c_void_p, c_size_t, c_void_p],
     ),
+    "wcn_radius_grid_count": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, ctypes.c_float * 3, ctypes.c_float, c_int32 * 3, c_void_p, c_int64, ctypes.c_float,
+         c_void_p, c_void_p],
+    ),
+    "wcn_radius_grid_write": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, ctypes.c_float * 3, ctypes.c_float, c_int32 * 3, c_void_p, c_int64, ctypes.c_float,
+         c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "wcn_knn_grid": (
         c_int,
         [c_void_p, c_void_p, c_void_p, ctypes.c_float * 3, ctypes.c_float, c_int32 * 3, c_void_p, c_int64, c_int32, c_void_p,

@@ -32,6 +32,11 @@ int dwconv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_map
 // points.hip
 int knn_grid(const float* ref, const int32_t* ref_id, const int32_t* cell_start, const float origin[3], float h,
              const int32_t dims[3], const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2, hipStream_t s);
+int radius_grid_count(const float* ref, const int32_t* ref_id, const int32_t* cell_start, const float origin[3], float h,
+                      const int32_t dims[3], const float* query, int64_t m, float radius, int32_t* counts, hipStream_t s);
+int radius_grid_write(const float* ref, const int32_t* ref_id, const int32_t* cell_start, const float origin[3], float h,
+                      const int32_t dims[3], const float* query, int64_t m, float radius, const int64_t* splits,
+                      int32_t* out_idx, float* out_dist, hipStream_t s);
 int segment_reduce(const void* in, const int64_t* splits, int64_t m, int c, int dtype, int op, void* out, int64_t* arg,
                    hipStream_t s);
 }  // namespace wcn
@@ -192,6 +197,26 @@ int wcn_knn_grid(const float* ref_sorted, const int32_t* ref_ids, const int32_t*
   if (!ref_sorted || !ref_ids || !cell_start || !query || !out_index) return WCN_ERROR_INVALID_PARAMETERS;
   return knn_grid(ref_sorted, ref_ids, cell_start, origin, cell_size, dims, query, num_query, k, out_index, out_dist2,
                   (hipStream_t)stream);
+}
+
+int wcn_radius_grid_count(const float* ref_sorted, const int32_t* ref_ids, const int32_t* cell_start, const float origin[3],
+                          float cell_size, const int32_t dims[3], const float* query, int64_t num_query, float radius,
+                          int32_t* counts, wcn_stream_t stream) {
+  if (num_query < 0 || !origin || !dims) return WCN_ERROR_INVALID_PARAMETERS;
+  if (num_query == 0) return WCN_SUCCESS;
+  if (!ref_sorted || !ref_ids || !cell_start || !query || !counts) return WCN_ERROR_INVALID_PARAMETERS;
+  return radius_grid_count(ref_sorted, ref_ids, cell_start, origin, cell_size, dims, query, num_query, radius, counts,
+                           (hipStream_t)stream);
+}
+
+int wcn_radius_grid_write(const float* ref_sorted, const int32_t* ref_ids, const int32_t* cell_start, const float origin[3],
+                          float cell_size, const int32_t dims[3], const float* query, int64_t num_query, float radius,
+                          const int64_t* splits, int32_t* out_index, float* out_dist, wcn_stream_t stream) {
+  if (num_query < 0 || !origin || !dims) return WCN_ERROR_INVALID_PARAMETERS;
+  if (num_query == 0) return WCN_SUCCESS;
+  if (!ref_sorted || !ref_ids || !cell_start || !query || !splits || !out_index) return WCN_ERROR_INVALID_PARAMETERS;
+  return radius_grid_write(ref_sorted, ref_ids, cell_start, origin, cell_size, dims, query, num_query, radius, splits,
+                           out_index, out_dist, (hipStream_t)stream);
 }
 
 int wcn_segment_reduce(const void* in, const int64_t* row_splits, int64_t num_segments, int32_t channels, int32_t dtype,

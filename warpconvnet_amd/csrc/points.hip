@@ -111,6 +111,79 @@ int knn_grid(const float* ref, const int32_t* ref_id, const int32_t* cell_start,
   return launch_status();
 }
 
+// ---- radius search -----------------------------------------------------------------------------------------------------
+// Cell-list radius search over the same sorted-by-cell layout as the kNN: cell size >= radius, so the 27 cells around the
+// query's cell hold every point within the radius (reference: warpconvnet/csrc/radius_search_kernels.cu:30-134 - a
+// hash-table cell list with the same 27-cell walk and the same `dist^2 <= radius^2` test; two passes: count, then
+// write at the exclusive scan of the counts).  Rows come out in cell-walk order (z, y, x ascending), points of one cell
+// in ascending original index (the cell sort is stable) - deterministic, unlike the reference's argsort order.
+template <bool WRITE>
+__global__ __launch_bounds__(128) void radius_grid_kernel(const float* __restrict__ ref, const int32_t* __restrict__ ref_id,
+                                                          const int32_t* __restrict__ cell_start, float ox, float oy,
+                                                          float oz, float inv_h, int gx, int gy, int gz,
+                                                          const float* __restrict__ query, int64_t m, float r2,
+                                                          int32_t* __restrict__ counts, const int64_t* __restrict__ splits,
+                                                          int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  const float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
+  // queries may lie outside the grid: clamp the CELL RANGE, not the cell (float -> int conversion saturates)
+  const float fx = floorf((qx - ox) * inv_h), fy = floorf((qy - oy) * inv_h), fz = floorf((qz - oz) * inv_h);
+  const float big = 1.0e9f;
+  const int cx = (int)fminf(fmaxf(fx, -big), big), cy = (int)fminf(fmaxf(fy, -big), big), cz = (int)fminf(fmaxf(fz, -big), big);
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gx - 1);
+  const int y0 = max(cy - 1, 0), y1 = min(cy + 1, gy - 1);
+  const int z0 = max(cz - 1, 0), z1 = min(cz + 1, gz - 1);
+  int n = 0;
+  int64_t at = WRITE ? splits[q] : 0;
+  for (int z = z0; z <= z1; ++z) {
+    for (int y = y0; y <= y1; ++y) {
+      if (x0 > x1) continue;
+      // the cells x0..x1 of one (y, z) row are contiguous in the sorted array: one range instead of three
+      const int row = (z * gy + y) * gx;
+      const int p0 = cell_start[row + x0], p1 = cell_start[row + x1 + 1];
+      for (int p = p0; p < p1; ++p) {
+        const float ex = qx - ref[p * 3 + 0], ey = qy - ref[p * 3 + 1], ez = qz - ref[p * 3 + 2];
+        const float d2 = ex * ex + ey * ey + ez * ez;
+        if (d2 <= r2) {
+          if (WRITE) {
+            out_idx[at] = ref_id[p];
+            if (out_dist) out_dist[at] = sqrtf(d2);
+            ++at;
+          }
+          ++n;
+        }
+      }
+    }
+  }
+  if (!WRITE) counts[q] = n;
+}
+
+static int radius_args_ok(float h, const int32_t dims[3], float radius) {
+  return h > 0.f && radius >= 0.f && radius <= h && dims[0] >= 1 && dims[1] >= 1 && dims[2] >= 1;
+}
+
+int radius_grid_count(const float* ref, const int32_t* ref_id, const int32_t* cell_start, const float origin[3], float h,
+                      const int32_t dims[3], const float* query, int64_t m, float radius, int32_t* counts, hipStream_t s) {
+  if (!radius_args_ok(h, dims, radius)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  hipLaunchKernelGGL(radius_grid_kernel<false>, dim3((unsigned)ceil_div(m, 128)), dim3(128), 0, s, ref, ref_id, cell_start,
+                     origin[0], origin[1], origin[2], 1.0f / h, dims[0], dims[1], dims[2], query, m, radius * radius, counts,
+                     (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+  return launch_status();
+}
+
+int radius_grid_write(const float* ref, const int32_t* ref_id, const int32_t* cell_start, const float origin[3], float h,
+                      const int32_t dims[3], const float* query, int64_t m, float radius, const int64_t* splits,
+                      int32_t* out_idx, float* out_dist, hipStream_t s) {
+  if (!radius_args_ok(h, dims, radius)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  hipLaunchKernelGGL(radius_grid_kernel<true>, dim3((unsigned)ceil_div(m, 128)), dim3(128), 0, s, ref, ref_id, cell_start,
+                     origin[0], origin[1], origin[2], 1.0f / h, dims[0], dims[1], dims[2], query, m, radius * radius,
+                     (int32_t*)nullptr, splits, out_idx, out_dist);
+  return launch_status();
+}
+
 // ---- segment reduce ---------------------------------------------------------------------------------------------------
 enum { kRedSum = 0, kRedMean = 1, kRedMax = 2, kRedMin = 3 };
 

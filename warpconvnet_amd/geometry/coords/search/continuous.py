@@ -2,6 +2,7 @@
 from torch import Tensor
 
 from .knn import batched_knn_search
+from .radius import batched_radius_search
 from .search_configs import RealSearchConfig, RealSearchMode
 from .search_results import RealSearchResult
 
@@ -13,4 +14,9 @@ def neighbor_search(ref_positions: Tensor, ref_offsets: Tensor, query_positions:
         return RealSearchResult(
             batched_knn_search(ref_positions, ref_offsets, query_positions, query_offsets, search_args.knn_k)
         )
-    raise NotImplementedError(f"search mode {search_args.mode} is outside the SparseConv3d hot path (SURVEY.md §2a P3)")
+    if search_args.mode == RealSearchMode.RADIUS:
+        assert search_args.radius is not None, "Radius must be provided for radius search"
+        index, _, split = batched_radius_search(ref_positions, ref_offsets, query_positions, query_offsets,
+                                                search_args.radius, search_args.grid_dim)
+        return RealSearchResult(index, split)
+    raise ValueError(f"search_args.mode {search_args.mode} not supported.")

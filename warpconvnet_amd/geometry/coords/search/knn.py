@@ -27,16 +27,22 @@ def _knn_cdist(ref: Tensor, query: Tensor, k: int, chunk: int = 4096) -> Tensor:
     return torch.cat(out, 0) if out else torch.zeros((0, k), dtype=torch.int64, device=ref.device)
 
 
-def _knn_grid(ref: Tensor, query: Tensor, k: int, return_dist2: bool = False):
-    dev = ref.device
-    ref32, q32 = ref.float().contiguous(), query.float().contiguous()
+def build_cell_grid(ref32: Tensor, cell_size: float = None, min_cell_size: float = 0.0):
+    """Bin ``ref32`` [N, 3] fp32 into a uniform grid over its bounding box: (ref_sorted, ref_ids, cell_start, lo, h, dims).
+
+    ``cell_size=None`` sizes the cells for a few points each (kNN); otherwise the cell is at least ``cell_size`` (radius
+    search needs cell >= radius).  Cells grow until the grid fits ``_MAX_CELLS``.  One host read (the bounding box)."""
+    dev = ref32.device
     n = ref32.shape[0]
     lo_t, hi_t = ref32.min(0).values, ref32.max(0).values
-    lo, hi = lo_t.cpu().tolist(), hi_t.cpu().tolist()  # one host read per search (the result is cached by Points.neighbors)
+    lo, hi = lo_t.cpu().tolist(), hi_t.cpu().tolist()
     ext = [max(h - l, 1e-6) for l, h in zip(lo, hi)]
-    # a few points per cell on average: shell 1 (27 cells) then usually holds k <= 32 candidates
-    h = (4.0 * ext[0] * ext[1] * ext[2] / max(n, 1)) ** (1.0 / 3.0)
-    h = max(h, max(ext) / 1024.0, 1e-6)
+    if cell_size is None:
+        # a few points per cell on average: shell 1 (27 cells) then usually holds k <= 32 candidates
+        h = (4.0 * ext[0] * ext[1] * ext[2] / max(n, 1)) ** (1.0 / 3.0)
+        h = max(h, max(ext) / 1024.0, 1e-6)
+    else:
+        h = max(float(cell_size), min_cell_size, 1e-6)
     dims = [int(math.floor(e / h)) + 1 for e in ext]
     while dims[0] * dims[1] * dims[2] > _MAX_CELLS:
         h *= 1.5
@@ -50,8 +56,13 @@ def _knn_grid(ref: Tensor, query: Tensor, k: int, return_dist2: bool = False):
     sorted_cell = cell[order]
     ncells = dims[0] * dims[1] * dims[2]
     cell_start = torch.searchsorted(sorted_cell, torch.arange(ncells + 1, device=dev, dtype=torch.int64)).to(torch.int32)
-    ref_sorted = ref32[order].contiguous()
-    ref_ids = order.to(torch.int32).contiguous()
+    return ref32[order].contiguous(), order.to(torch.int32).contiguous(), cell_start, lo, h, dims
+
+
+def _knn_grid(ref: Tensor, query: Tensor, k: int, return_dist2: bool = False):
+    dev = ref.device
+    ref32, q32 = ref.float().contiguous(), query.float().contiguous()
+    ref_sorted, ref_ids, cell_start, lo, h, dims = build_cell_grid(ref32)
     m = q32.shape[0]
     out = torch.empty((m, k), dtype=torch.int64, device=dev)
     d2 = torch.empty((m, k), dtype=torch.float32, device=dev) if return_dist2 else None
