@@ -7,9 +7,10 @@
 // K probes of its voxels from LDS.  Global traffic becomes streaming bin reads + full-line row writes.
 //
 //   pass 1a bin_insert   voxel -> block slot (CAS on the block key only on first touch), dense block ids
-//   pass 1b bin_count    position inside the bin: 4 sub-counters per class (same-address atomics serialise); voxels
-//                        within H cells of a block face - the only ones a NEIGHBOUR block can need - go first
-//   pass 2  bin_assign   bin size / boundary count per block
+//   pass 1b bin_count    position inside the bin.  Voxels within H cells of a block face - the only ones a NEIGHBOUR
+//                        block can need - go first, grouped by the first face they are near (6 groups); interior
+//                        voxels use 8 row-keyed sub-counters (same-address atomics serialise)
+//   pass 2  bin_assign   bin size per block, exclusive prefix over the block's groups
 //   pass 3  bin_scan     exclusive scan of bin sizes
 //   pass 4  bin_scatter  voxels -> binned array {x, y, z, row}
 //   pass 5  bin_neighbors  per block: LDS grid of (16+2H)^3 row ids (atomicMin => duplicates keep the smallest
@@ -56,11 +57,11 @@ __device__ __forceinline__ int block_find(const Slot* __restrict__ slots, uint32
   return -1;
 }
 
-// Slot use on this path: key = block key, value / pad unused (zeroed).  Bin sizes live in cnt[id][8]:
-// 4 sub-counters for BOUNDARY voxels then 4 for INTERIOR voxels.  Same-address atomics serialise (~280 ns each,
-// ~455 voxels per 16^3 block on the uniform scene), so spreading a block's voxels over 4 counters per class cuts the
-// critical path 4x; the sub-counter is chosen by the voxel's row index.
-constexpr int kSub = 8;  // sub-counters per (block, class): spreads the same-address atomics of bin_count
+// Slot use on this path: key = block key, value / pad unused (zeroed).  Bin sizes live in cnt[id][2 * kSub]:
+// groups 0..5 = BOUNDARY voxels by first near face (x-, x+, y-, y+, z-, z+; 6, 7 unused), groups kSub.. = INTERIOR
+// voxels spread over kSub sub-counters chosen by the row index.  Same-address atomics serialise (~280 ns each,
+// ~455 voxels per 16^3 block on the uniform scene: ~25 per face group, ~38 per interior sub-counter).
+constexpr int kSub = 8;
 
 // clears the block table and - in the same launch - the block counter and the caller's status word (every extra
 // memset / fill is a ~5 us launch on this pipeline of ~20 short kernels)
@@ -135,29 +136,37 @@ __global__ void bin_count_kernel(const int4* __restrict__ coords, int64_t n, int
   if (s < 0) return;
   const int4 c = coords[i];
   const int lx = c.y & (kBlk - 1), ly = c.z & (kBlk - 1), lz = c.w & (kBlk - 1);
-  const bool boundary = lx < hx || lx >= kBlk - hx || ly < hy || ly >= kBlk - hy || lz < hz || lz >= kBlk - hz;
-  const int group = (boundary ? 0 : kSub) + (int)(i & (kSub - 1));
+  // boundary voxels are grouped by the FIRST face they are near (x-, x+, y-, y+, z-, z+): a neighbour block then reads
+  // only the groups that can hold voxels near the face it shares with this block (see bin_neighbors) instead of the
+  // whole boundary shell - 3x fewer halo candidates on the uniform scene.  Interior voxels keep kSub row-keyed
+  // sub-counters (same-address atomics serialise).
+  int face = -1;
+  if (lx < hx) face = 0;
+  else if (lx >= kBlk - hx) face = 1;
+  else if (ly < hy) face = 2;
+  else if (ly >= kBlk - hy) face = 3;
+  else if (lz < hz) face = 4;
+  else if (lz >= kBlk - hz) face = 5;
+  const int group = face >= 0 ? face : kSub + (int)(i & (kSub - 1));
   const int pos = atomicAdd(&cnt[(int64_t)slot_id[s] * (2 * kSub) + group], 1);
   if (pos >= (1 << 24)) atomicOr(status, (int)WCN_FLAG_TABLE_FULL);
   vox_pos[i] = (group << 24) | (pos & 0xFFFFFF);
 }
 
-// pass 2: bin size and boundary count per block
+// pass 2: bin size per block, group counters -> exclusive prefix
 __global__ void bin_assign_kernel(int32_t* __restrict__ cnt, const int32_t* __restrict__ nblk, int64_t max_blocks,
-                                  int32_t* __restrict__ blk_cnt, int32_t* __restrict__ blk_bnd) {
+                                  int32_t* __restrict__ blk_cnt) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= max_blocks || id >= *nblk) return;
   int32_t* c = cnt + id * (2 * kSub);
-  int bnd = 0, tot = 0;
+  int tot = 0;
 #pragma unroll
   for (int g = 0; g < 2 * kSub; ++g) {
     const int v = c[g];
-    c[g] = tot;  // exclusive prefix over the groups: bin_scatter adds it to the position inside the group
-    tot += v;
-    if (g < kSub) bnd += v;
+    c[g] = tot;  // exclusive prefix over the groups: bin_scatter adds it to the position inside the group, bin_neighbors
+    tot += v;    // reads the run of face groups a neighbour needs
   }
   blk_cnt[id] = tot;
-  blk_bnd[id] = bnd;
 }
 
 // single workgroup: exclusive scan of blk_cnt[0..nblk) -> blk_off[0..nblk]
@@ -216,7 +225,7 @@ __device__ unsigned long long g_bprof[4096 * 8];
 template <int LPR>
 __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* __restrict__ slots, uint32_t cmask,
                                                                     const int32_t* __restrict__ slot_id,
-                                                                    const int32_t* __restrict__ blk_bnd,
+                                                                    const int32_t* __restrict__ grp_pre,
                                                                     const int32_t* __restrict__ blk_slot,
                                                                     const int32_t* __restrict__ nblk,
                                                                     const int32_t* __restrict__ blk_off,
@@ -251,8 +260,19 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
         if (s >= 0) {
           const int nid = slot_id[s];
           beg = blk_off[nid];
-          // a neighbour block can only contribute its boundary voxels (stored first); the own block is read whole
-          cnt = (tid == 13) ? (blk_off[nid + 1] - beg) : blk_bnd[nid];
+          if (tid == 13) {
+            cnt = blk_off[nid + 1] - beg;  // the own block is read whole
+          } else {
+            // a neighbour contributes voxels near the face it shares with this block.  Boundary voxels are stored first,
+            // grouped by the first face they are near (bin_count), so the candidates are one contiguous run of groups:
+            //   +x neighbour: its x- group; -x: x+; same x, +y: x-, x+, y-; same x, -y: x- .. y+; same x and y: .. z-/z+
+            const int g0 = ddx > 0 ? 0 : (ddx < 0 ? 1 : 0);
+            const int g1 = ddx > 0 ? 0 : (ddx < 0 ? 1 : (ddy > 0 ? 2 : (ddy < 0 ? 3 : (ddz > 0 ? 4 : 5))));
+            const int32_t* pre = grp_pre + (int64_t)nid * (2 * kSub);  // exclusive prefix over the groups (bin_assign)
+            const int p0 = pre[g0];
+            beg += p0;
+            cnt = pre[g1 + 1] - p0;
+          }
         }
       }
       s_nb_beg[tid] = beg;
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_neighbors_kernel(const Slot* 
 static inline size_t align256b(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct BinWorkspace {
-  int32_t *vox_slot, *vox_pos, *blk_slot, *blk_cnt, *blk_bnd, *blk_off, *nblk, *slot_id, *cnt;
+  int32_t *vox_slot, *vox_pos, *blk_slot, *blk_cnt, *blk_off, *nblk, *slot_id, *cnt;
   int4* binned;
   size_t bytes;
 };
@@ -370,7 +390,6 @@ static BinWorkspace carve(void* ws, int64_t n, int64_t capacity) {
   w.vox_pos = (int32_t*)take((size_t)n * 4);
   w.blk_slot = (int32_t*)take((size_t)n * 4);
   w.blk_cnt = (int32_t*)take((size_t)n * 4);
-  w.blk_bnd = (int32_t*)take((size_t)n * 4);
   w.cnt = (int32_t*)take((size_t)n * 2 * kSub * 4);
   w.blk_off = (int32_t*)take((size_t)(n + 1) * 4);
   w.binned = (int4*)take((size_t)n * 16);
@@ -444,7 +463,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   hipLaunchKernelGGL(bin_count_kernel, dim3(gn), dim3(256), 0, s, (const int4*)coords, n, g.hx, g.hy, g.hz,
                      (const int32_t*)w.vox_slot, (const int32_t*)w.slot_id, w.cnt, w.vox_pos, status);
   hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, w.cnt, (const int32_t*)w.nblk, n,
-                     w.blk_cnt, w.blk_bnd);
+                     w.blk_cnt);
   hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)w.blk_cnt, (const int32_t*)w.nblk,
                      w.blk_off);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(gn), dim3(256), 0, s, (const int32_t*)w.slot_id, (const int32_t*)w.cnt,
@@ -455,7 +474,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   const dim3 grid((unsigned)(want < 4096 ? want : 4096)), block(kBinThreads);
 #define WCN_BIN_NB(L)                                                                                                  \
   hipLaunchKernelGGL(bin_neighbors_kernel<L>, grid, block, shm, s, (const Slot*)slots, cmask,                            \
-                     (const int32_t*)w.slot_id, (const int32_t*)w.blk_bnd, (const int32_t*)w.blk_slot,                   \
+                     (const int32_t*)w.slot_id, (const int32_t*)w.cnt, (const int32_t*)w.blk_slot,                       \
                      (const int32_t*)w.nblk, (const int32_t*)w.blk_off, (const int4*)w.binned, g, K, kp, mw, nbr, mask,  \
                      status)
   switch (lanes_per_row_b(kp)) {
