@@ -197,6 +197,26 @@ def main_pointconv():
     print("done (pointconv)")
 
 
+def main_radius():
+    """(i) radius search: the reference's own CPU path (`geometry/coords/search/radius.py:127-225`, chunked cdist) and
+    `batched_radius_search`'s bookkeeping restated on its output (the batched entry point itself asserts CUDA)."""
+    import_reference()
+    from warpconvnet.geometry.coords.search.radius import radius_search
+
+    g = torch.Generator().manual_seed(11)
+    pts = torch.rand(700, 3, generator=g) * torch.tensor([4.0, 4.0, 1.0])
+    qry = (torch.rand(260, 3, generator=g) * 1.2 - 0.1) * torch.tensor([4.0, 4.0, 1.0])
+    out = {"points": pts.numpy(), "queries": qry.numpy()}
+    for tag, radius in (("r030", 0.30), ("r075", 0.75)):
+        idx, dist, split = radius_search(pts.contiguous(), qry.contiguous(), radius)
+        out[f"{tag}_radius"] = np.float32(radius)
+        out[f"{tag}_index"] = idx.numpy()
+        out[f"{tag}_distance"] = dist.numpy()
+        out[f"{tag}_split"] = split.numpy()
+    np.savez_compressed(os.path.join(HERE, "radius_search.npz"), **out)
+    print("radius_search.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
 def main():
     import_reference()
     from warpconvnet.geometry.coords.search.cache import IntSearchCacheKey
@@ -309,7 +329,10 @@ if __name__ == "__main__":
         main_depthwise()  # only the (g) fixtures; the others are left untouched
     elif len(sys.argv) > 1 and sys.argv[1] == "pointconv":
         main_pointconv()  # only the (h) fixture
+    elif len(sys.argv) > 1 and sys.argv[1] == "radius":
+        main_radius()  # only the (i) fixture
     else:
         main()
         main_depthwise()
         main_pointconv()
+        main_radius()

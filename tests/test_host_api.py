@@ -344,3 +344,18 @@ def test_radius_search_cpu_contract():
     assert (bi[: bs[10]] < 100).all() and (bi[bs[10] :] >= 100).all()
     r = neighbor_search(p, offs_p, q, offs_q, RealSearchConfig("radius", radius=0.25))
     assert torch.equal(r.neighbor_indices, bi) and torch.equal(r.neighbor_row_splits, bs)
+
+
+@pytest.mark.parametrize("tag", ["r030", "r075"])
+def test_radius_search_cpu_matches_reference_golden(golden_dir, tag):
+    """CPU path == the reference's own CPU radius search (tests/golden/radius_search.npz, generated by running
+    warpconvnet/geometry/coords/search/radius.py:127-225): same neighbours in the same (ascending index) order."""
+    import os
+
+    from warpconvnet_amd.geometry.coords.search.radius import radius_search
+
+    gz = np.load(os.path.join(golden_dir, "radius_search.npz"))
+    idx, dist, split = radius_search(torch.from_numpy(gz["points"]), torch.from_numpy(gz["queries"]), float(gz[f"{tag}_radius"]))
+    np.testing.assert_array_equal(split.numpy(), gz[f"{tag}_split"])
+    np.testing.assert_array_equal(idx.numpy(), gz[f"{tag}_index"])
+    np.testing.assert_allclose(dist.numpy(), gz[f"{tag}_distance"], rtol=1e-6, atol=1e-7)
