@@ -85,7 +85,8 @@ int wcn_hash_search(const void* slots, int64_t capacity, const int32_t* queries,
  */
 int32_t wcn_kmap_row_pitch(int32_t num_offsets);
 int32_t wcn_kmap_mask_words(int32_t num_offsets);
-/* number of 64-row count blocks for m query rows; the counts buffer holds K * (num_blocks + 1) int32 */
+/* number of 64-row count blocks for m query rows, rounded up to a multiple of 4 (rows of the counts array stay 16-B
+ * aligned); the counts buffer holds K * (num_blocks + 1) int32 */
 int64_t wcn_kmap_num_blocks(int64_t m);
 
 /* reference: _C.cuhash.packed_kernel_map_size + packed_kernel_map_offset (cuhash_kernel_map.cu:68-134)

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ c
                                                          int32_t* __restrict__ totals) {
   // one workgroup per offset; kPer consecutive counts per thread and trip (the wave still reads one contiguous span),
   // wave scan of the thread sums by shuffles, wave totals combined through LDS, running carry in a register
-  constexpr int kPer = 8;
+  constexpr int kPer = 16;  // 16 K counts per trip: the 15 625 blocks of a 1 M-row map are one trip (one memory round trip)
   __shared__ int s_wave[16];
   int32_t* c = counts + (int64_t)blockIdx.x * nwb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,10 +151,14 @@ __global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ c
     const int64_t i0 = base + (int64_t)tid * kPer;
     int v[kPer];
     int sum = 0;
+    // 16-B pieces per lane (nwb is a multiple of 4, rows are 16-B aligned): a lane-strided 4-B access costs one
+    // texture-addresser slot per lane and element - 16 of them made this kernel 16 us instead of 6
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      v[j] = (i0 + j < nwb) ? c[i0 + j] : 0;
-      sum += v[j];
+    for (int j = 0; j < kPer; j += 4) {
+      int4 t = make_int4(0, 0, 0, 0);
+      if (i0 + j < nwb) t = *reinterpret_cast<const int4*>(c + i0 + j);
+      v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+      sum += t.x + t.y + t.z + t.w;
     }
     int incl = sum;
 #pragma unroll
@@ -173,9 +177,13 @@ __global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ c
     }
     int run = carry + wave_base + incl - sum;  // exclusive prefix of this thread's first element
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      if (i0 + j < nwb) c[i0 + j] = run;
-      run += v[j];
+    for (int j = 0; j < kPer; j += 4) {
+      int4 t;
+      t.x = run; run += v[j];
+      t.y = run; run += v[j + 1];
+      t.z = run; run += v[j + 2];
+      t.w = run; run += v[j + 3];
+      if (i0 + j < nwb) *reinterpret_cast<int4*>(c + i0 + j) = t;
     }
     carry += trip_total;
     __syncthreads();  // s_wave is rewritten by the next trip
@@ -417,7 +425,8 @@ int wcn_hash_search(const void* slots, int64_t capacity, const int32_t* queries,
 
 int32_t wcn_kmap_row_pitch(int32_t num_offsets) { return (num_offsets + 7) & ~7; }
 int32_t wcn_kmap_mask_words(int32_t num_offsets) { return (num_offsets + 31) / 32; }
-int64_t wcn_kmap_num_blocks(int64_t m) { return ceil_div(m, kCountRows); }
+// rounded up to a multiple of 4 so that every offset's row of the counts array is 16-B aligned (vector access in the scan)
+int64_t wcn_kmap_num_blocks(int64_t m) { return (ceil_div(m, kCountRows) + 3) & ~(int64_t)3; }
 
 int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, int64_t m, const int32_t ksize[3],
                    const int32_t stride[3], const int32_t dilation[3], int32_t* nbr, uint32_t* mask,

@@ -62,6 +62,7 @@ __device__ __forceinline__ int block_find(const Slot* __restrict__ slots, uint32
 // voxels spread over kSub sub-counters chosen by the row index.  Same-address atomics serialise (~280 ns each,
 // ~455 voxels per 16^3 block on the uniform scene: ~25 per face group, ~38 per interior sub-counter).
 constexpr int kSub = 8;
+constexpr int kInsertSample = 16;  // bin_insert: 1 voxel in 16 goes first (see the kernel)
 
 // clears the block table and - in the same launch - the block counter and the caller's status word (every extra
 // memset / fill is a ~5 us launch on this pipeline of ~20 short kernels)
@@ -78,8 +79,13 @@ __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, cons
                                   int32_t* __restrict__ vox_slot, int32_t* __restrict__ blk_slot,
                                   int32_t* __restrict__ slot_id, int32_t* __restrict__ nblk, int32_t* __restrict__ cnt,
                                   int32_t* __restrict__ status, int kp, int mw, int32_t* __restrict__ nbr,
-                                  uint32_t* __restrict__ mask) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                  uint32_t* __restrict__ mask, int phase) {
+  // Two launches: phase 0 inserts every kInsertSample-th voxel, phase 1 the rest.  With ONE launch half a million
+  // resident threads meet an empty table at the same instant and all of them CAS the ~2 200 block keys (~240 same-address
+  // atomics per key, serialised: 36 us); after the sampled pass nearly every block exists, and the rest of the voxels
+  // only read (a block that the sample missed is simply created in phase 1).
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = phase == 0 ? t * kInsertSample : t + t / (kInsertSample - 1) + 1;
   if (i >= n) return;
   const int4 c = coords[i];
   if (!coord_in_range(c.x, c.y, c.z, c.w)) {
@@ -94,30 +100,46 @@ __global__ void bin_insert_kernel(Slot* __restrict__ slots, uint32_t cmask, cons
   const uint64_t key = block_key(c.x, c.y >> kBlkShift, c.z >> kBlkShift, c.w >> kBlkShift);
   uint32_t s = hash_slot(key, cmask);
   int found = -1;
+  bool created = false;
   for (uint32_t a = 0; a <= cmask; ++a) {
     unsigned long long* kp = reinterpret_cast<unsigned long long*>(&slots[s].key);
     // optimistic cached read first: a key, once written, never changes, so a matching value is final; an empty or
     // stale value falls through to the coherent read below
-    unsigned long long cur = *reinterpret_cast<const volatile unsigned long long*>(kp);
+    // (wavefront-scope relaxed load = an ordinary cached load the compiler must still perform; a `volatile` access is
+    // emitted as a system-coherent `sc0 sc1` load that misses every cache - 36 us instead of 10 for this kernel)
+    unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (cur == key) { found = (int)s; break; }
     cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == 0ull) {
       cur = atomicCAS(kp, 0ull, (unsigned long long)key);
-      if (cur == 0ull) {  // this thread created the block: give it a dense id
-        const int id = atomicAdd(nblk, 1);
-        blk_slot[id] = (int)s;
-        slot_id[s] = id;  // read by the NEXT kernels only
-        // the block's position counters, used by bin_count (next kernel): cleared here by the one thread that created
-        // the block instead of a worst-case 32 MB memset (the block count is only known on the device)
-#pragma unroll
-        for (int q = 0; q < (2 * kSub) / 4; ++q)
-          reinterpret_cast<int4*>(cnt + (int64_t)id * (2 * kSub))[q] = make_int4(0, 0, 0, 0);
+      if (cur == 0ull) {  // this thread created the block (its dense id is handed out below, once per wave)
+        created = true;
         found = (int)s;
         break;
       }
     }
     if (cur == key) { found = (int)s; break; }
     s = (s + 1) & cmask;
+  }
+  // dense block ids: ONE counter update per wave for all the blocks its lanes created (every creator doing its own
+  // atomicAdd on the same address serialises ~2 200 round trips on the uniform scene - most of this kernel's time)
+  const unsigned long long makers = __ballot(created);
+  if (makers != 0ull) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)makers) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(nblk, __popcll(makers));
+    base = __shfl(base, leader);
+    if (created) {
+      const int id = base + __popcll(makers & ((1ull << lane) - 1ull));
+      blk_slot[id] = found;
+      slot_id[found] = id;  // read by the NEXT kernels only
+      // the block's position counters, used by bin_count (next kernel): cleared here by the one thread that created
+      // the block instead of a worst-case 32 MB memset (the block count is only known on the device)
+#pragma unroll
+      for (int q = 0; q < (2 * kSub) / 4; ++q)
+        reinterpret_cast<int4*>(cnt + (int64_t)id * (2 * kSub))[q] = make_int4(0, 0, 0, 0);
+    }
   }
   if (found < 0) atomicOr(status, (int)WCN_FLAG_TABLE_FULL);
   vox_slot[i] = found;
@@ -458,8 +480,13 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
                      w.nblk, status);
   const uint32_t cmask = (uint32_t)(capacity - 1);
   const unsigned gn = (unsigned)ceil_div(n, 256);
-  hipLaunchKernelGGL(bin_insert_kernel, dim3(gn), dim3(256), 0, s, (Slot*)slots, cmask, (const int4*)coords, n, w.vox_slot,
-                     w.blk_slot, w.slot_id, w.nblk, w.cnt, status, kp, mw, nbr, mask);
+  const int64_t n_first = ceil_div(n, kInsertSample), n_rest = n - n_first;
+  hipLaunchKernelGGL(bin_insert_kernel, dim3((unsigned)ceil_div(n_first, 256)), dim3(256), 0, s, (Slot*)slots, cmask,
+                     (const int4*)coords, n, w.vox_slot, w.blk_slot, w.slot_id, w.nblk, w.cnt, status, kp, mw, nbr, mask, 0);
+  if (n_rest > 0)
+    hipLaunchKernelGGL(bin_insert_kernel, dim3((unsigned)ceil_div(n_rest, 256)), dim3(256), 0, s, (Slot*)slots, cmask,
+                       (const int4*)coords, n, w.vox_slot, w.blk_slot, w.slot_id, w.nblk, w.cnt, status, kp, mw, nbr, mask,
+                       1);
   hipLaunchKernelGGL(bin_count_kernel, dim3(gn), dim3(256), 0, s, (const int4*)coords, n, g.hx, g.hy, g.hz,
                      (const int32_t*)w.vox_slot, (const int32_t*)w.slot_id, w.cnt, w.vox_pos, status);
   hipLaunchKernelGGL(bin_assign_kernel, dim3(gn), dim3(256), 0, s, w.cnt, (const int32_t*)w.nblk, n,

@@ -33,10 +33,18 @@ __global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __r
   for (int i = threadIdx.x; i < kRsBins; i += kRsThreads) s_hist[i] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kRsTile;
-  for (int i = threadIdx.x; i < kRsTile; i += kRsThreads) {
-    const int64_t idx = base + i;
-    if (idx < n) atomicAdd(&s_hist[rs_digit(keys[idx * key_stride], shift)], 1);
+  // all of a thread's keys are requested before the first one is used: predicated loads inside the loop are waited for
+  // one at a time (8 memory round trips instead of 1)
+  constexpr int kPer = kRsTile / kRsThreads;
+  uint32_t k[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const int64_t idx = base + threadIdx.x + j * kRsThreads;
+    k[j] = keys[(idx < n ? idx : n - 1) * key_stride];
   }
+#pragma unroll
+  for (int j = 0; j < kPer; ++j)
+    if (base + threadIdx.x + j * kRsThreads < n) atomicAdd(&s_hist[rs_digit(k[j], shift)], 1);
   __syncthreads();
   for (int i = threadIdx.x; i < kRsBins; i += kRsThreads) counts[(int64_t)i * nblk + blockIdx.x] = s_hist[i];
 }
@@ -80,8 +88,26 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
   __shared__ int s_dstart[kRsBins];          // first output position of every digit (scan of the digit totals)
   __shared__ int s_wsum[kRsWaves];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t wave_begin = (int64_t)blockIdx.x * kRsTile + (int64_t)wave * kRsPerWave;
+  // the wave's 8 x 64 keys (and carried values) are requested up front and kept in registers: the ranking loop below is a
+  // serial chain through LDS, and a global load inside it costs one memory round trip per 64 keys
+  constexpr int kBatches = kRsPerWave / 64;
+  uint32_t kreg[kBatches];
+  int32_t vreg[kBatches];
+#pragma unroll
+  for (int j = 0; j < kBatches; ++j) {
+    const int64_t idx = wave_begin + j * 64 + lane;
+    const int64_t at = idx < n ? idx : n - 1;
+    kreg[j] = keys_in[at * key_stride];
+    vreg[j] = vals_in ? vals_in[at] : (int32_t)at;
+  }
+  // ... and so are the digit totals and this block's (digit, block) bases: everything the kernel reads from global memory
+  // is in flight at once (three dependent round trips were most of its 15 us)
+  const int t0 = totals[2 * tid], t1 = totals[2 * tid + 1];
+  int blk_base[kRsBins / kRsThreads];
+#pragma unroll
+  for (int j = 0; j < kRsBins / kRsThreads; ++j) blk_base[j] = counts[(int64_t)(tid + j * kRsThreads) * nblk + blockIdx.x];
   {  // exclusive scan of the 512 digit totals: 2 per thread, wave scan, 4 wave partials
-    const int t0 = totals[2 * tid], t1 = totals[2 * tid + 1];
     int incl = t0 + t1;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -97,16 +123,16 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
   }
   for (int i = tid; i < kRsWaves * kRsBins; i += kRsThreads) (&s_base[0][0])[i] = 0;
   __syncthreads();
-  const int64_t wave_begin = (int64_t)blockIdx.x * kRsTile + (int64_t)wave * kRsPerWave;
   // phase 1: digit counts of this wave's sub-tile
-  for (int i = lane; i < kRsPerWave; i += 64) {
-    const int64_t idx = wave_begin + i;
-    if (idx < n) atomicAdd(&s_base[wave][rs_digit(keys_in[idx * key_stride], shift)], 1);
-  }
+#pragma unroll
+  for (int j = 0; j < kBatches; ++j)
+    if (wave_begin + j * 64 + lane < n) atomicAdd(&s_base[wave][rs_digit(kreg[j], shift)], 1);
   __syncthreads();
   // phase 2: counts -> starting positions (global base of (digit, block) + waves before this one)
-  for (int d = tid; d < kRsBins; d += kRsThreads) {
-    int run = s_dstart[d] + counts[(int64_t)d * nblk + blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kRsBins / kRsThreads; ++j) {
+    const int d = tid + j * kRsThreads;
+    int run = s_dstart[d] + blk_base[j];
 #pragma unroll
     for (int w = 0; w < kRsWaves; ++w) {
       const int c = s_base[w][d];
@@ -118,11 +144,11 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
   // phase 3: rank 64 keys at a time, in order
   volatile int* my_base = &s_base[wave][0];
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int i0 = 0; i0 < kRsPerWave; i0 += 64) {
-    const int64_t idx = wave_begin + i0 + lane;
+#pragma unroll
+  for (int j = 0; j < kBatches; ++j) {
+    const int64_t idx = wave_begin + j * 64 + lane;
     const bool live = idx < n;
-    uint32_t key = 0;
-    if (live) key = keys_in[idx * key_stride];
+    const uint32_t key = kreg[j];
     const uint32_t d = live ? rs_digit(key, shift) : 0u;
     unsigned long long peers = __ballot(live);
 #pragma unroll
@@ -135,7 +161,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
       const int rank = __popcll(peers & lt);
       const int pos = my_base[d] + rank;
       keys_out[pos] = key;
-      vals_out[pos] = vals_in ? vals_in[idx] : (int32_t)idx;
+      vals_out[pos] = vreg[j];
       // the last peer advances the running base after every peer has read it (same wave, LDS ops are in order)
       if ((peers >> lane) == 1ull) my_base[d] = pos + 1;
     }
