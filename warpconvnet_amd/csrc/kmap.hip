@@ -230,11 +230,22 @@ __global__ __launch_bounds__(kThreads) void kmap_scatter_kernel(const int32_t* _
   for (int w = 0; w < mw; ++w) {
     const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;      // offsets in this mask word
     const int cols4 = ((kp - w * 32) < 32 ? (kp - w * 32) : 32) >> 2;  // 16-B chunks per row in this word
-    for (int e = lane; e < 64 * cols4; e += 64) {
+    // cols4 (<= 8) 16-B pieces per lane, all requested before the first one is stored: a predicated load inside the loop
+    // is waited for before the next one is issued (8 memory round trips per wave instead of 1)
+    int4 piece[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = lane + 64 * j;
       const int r = e / cols4, c = e - r * cols4;
-      int4 v = make_int4(-1, -1, -1, -1);
-      if (row0 + r < m) v = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kp + w * 32 + c * 4);
-      *reinterpret_cast<int4*>(tile + r * 32 + ((c ^ (r & 7)) << 2)) = v;
+      const int64_t rr = row0 + r < m ? row0 + r : m - 1;  // clamped: always a valid address
+      if (j < cols4) piece[j] = *reinterpret_cast<const int4*>(nbr + rr * kp + w * 32 + c * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = lane + 64 * j;
+      const int r = e / cols4, c = e - r * cols4;
+      if (j < cols4)
+        *reinterpret_cast<int4*>(tile + r * 32 + ((c ^ (r & 7)) << 2)) = row0 + r < m ? piece[j] : make_int4(-1, -1, -1, -1);
     }
     // bucket write positions of this wave for the word's offsets: lane b holds the base of offset w*32+b
     int64_t base = 0;
