@@ -132,6 +132,11 @@ int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t
  * reference: host torch.cumsum in torch_discrete.py:268-272. */
 int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
                   wcn_stream_t stream);
+/* the same, and in the same launch offsets[0..K] ++ [*status] are also written to `host_mirror` - K + 2 int32 of pinned
+ * (device-accessible) HOST memory: the one host read of a build (torch_discrete.py:268-272 does `.item()` per value)
+ * becomes an event wait behind this kernel, no copy command. */
+int wcn_kmap_scan_to_host(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, const int32_t* status,
+                          int32_t* host_mirror, wcn_stream_t stream);
 /* deterministic compaction (pairs of one offset ordered by output row).
  * reference: _C.cuhash.postprocess_scatter (cuhash_kernel_map.cu:546-599, order there is racy).
  * pair_capacity = length of in_maps/out_maps; sets WCN_FLAG_PAIR_OVERFLOW in *status if too small. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     ),
     "wcn_kmap_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "wcn_kmap_scan_to_host": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wcn_kmap_scatter": (
         c_int,
         [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],

@@ -190,14 +190,21 @@ __global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ c
   }
   if (tid == 0) totals[blockIdx.x] = carry;
 }
-__global__ void kmap_offsets_kernel(const int32_t* __restrict__ totals, int K, int32_t* __restrict__ offsets) {
+// `mirror` (may be null): device-accessible pinned HOST buffer [K+2] that receives the offsets and the status word in the
+// same kernel - the host waits for an event behind this launch instead of queueing a separate D2H copy (a ~4 us copy
+// command plus the engine switch around it, on a pipeline of ~5 us kernels)
+__global__ void kmap_offsets_kernel(const int32_t* __restrict__ totals, int K, int32_t* __restrict__ offsets,
+                                    const int32_t* __restrict__ status, int32_t* __restrict__ mirror) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int acc = 0;
     offsets[0] = 0;
+    if (mirror) mirror[0] = 0;
     for (int k = 0; k < K; ++k) {
       acc += totals[k];
       offsets[k + 1] = acc;
+      if (mirror) mirror[k + 1] = acc;
     }
+    if (mirror) mirror[K + 1] = status ? *status : 0;
   }
 }
 
@@ -490,14 +497,28 @@ int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t
   return launch_status();
 }
 
+static int kmap_scan_impl(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
+                          const int32_t* status, int32_t* mirror, wcn_stream_t stream);
+
 int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, wcn_stream_t stream) {
+  return kmap_scan_impl(counts, num_blocks, num_offsets, offsets, nullptr, nullptr, stream);
+}
+
+int wcn_kmap_scan_to_host(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, const int32_t* status,
+                          int32_t* host_mirror, wcn_stream_t stream) {
+  if (!host_mirror) return WCN_ERROR_INVALID_PARAMETERS;
+  return kmap_scan_impl(counts, num_blocks, num_offsets, offsets, status, host_mirror, stream);
+}
+
+static int kmap_scan_impl(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
+                          const int32_t* status, int32_t* mirror, wcn_stream_t stream) {
   if (num_blocks < 0 || num_offsets < 1 || num_offsets > 4096 || !offsets || !counts) return WCN_ERROR_INVALID_PARAMETERS;
   // totals live in the last K ints of the counts buffer (the caller allocates K * (num_blocks + 1) ints)
   int32_t* totals = counts + (int64_t)num_offsets * num_blocks;
   hipLaunchKernelGGL(kmap_scan_kernel, dim3((unsigned)num_offsets), dim3(1024), 0, (hipStream_t)stream, counts,
                      num_blocks, (int)num_offsets, totals);
   hipLaunchKernelGGL(kmap_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int32_t*)totals,
-                     (int)num_offsets, offsets);
+                     (int)num_offsets, offsets, status, mirror);
   return launch_status();
 }
 

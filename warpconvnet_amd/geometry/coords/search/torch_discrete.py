@@ -5,6 +5,7 @@ Mirrors `warpconvnet/geometry/coords/search/torch_discrete.py:24-56, 296-432` (`
 scan + deterministic per-offset compaction + mask argsort, all on the current HIP stream through the
 C-ABI, with ONE host read (offsets + status flags) where the reference does six.
 """
+import ctypes
 import os
 from typing import Literal, Optional, Sequence, Tuple
 
@@ -211,12 +212,12 @@ def generate_kernel_map(
             "wcn_kmap_probe",
         )
     _lib.check(L.wcn_kmap_count(_lib.ptr(mask), M, K, _lib.ptr(block_counts), stream), "wcn_kmap_count")
-    _lib.check(L.wcn_kmap_scan(_lib.ptr(block_counts), nblk, K, _lib.ptr(meta), stream), "wcn_kmap_scan")
-    table_capacity = _next_power_of_2(max(16, 2 * N))
-    # offsets + status flags start travelling to pinned host memory now; the mask argsort does not depend on the pair
-    # count and keeps the GPU busy during the host round trip
+    # offsets + status flags are written to pinned host memory by the scan's last kernel itself (no copy command); the
+    # mask argsort does not depend on the pair count and keeps the GPU busy during the host round trip
     meta_host = torch.empty(K + 2, dtype=torch.int32, pin_memory=True)
-    meta_host.copy_(meta, non_blocking=True)
+    _lib.check(L.wcn_kmap_scan_to_host(_lib.ptr(block_counts), nblk, K, _lib.ptr(meta), _lib.ptr(meta[K + 1 :]),
+                                       ctypes.c_void_p(meta_host.data_ptr()), stream), "wcn_kmap_scan_to_host")
+    table_capacity = _next_power_of_2(max(16, 2 * N))
     event = torch.cuda.Event()
     event.record(torch.cuda.current_stream(dev))
     perm = mask_argsort(mask, K)
