@@ -38,6 +38,24 @@ def scene_u(n, seed):
     return c[np.sort(first)][:n].astype(np.int32)
 
 
+def scene_surface(n, seed):
+    """Surface-like scene (SURVEY.md §8d generator S): two height-field sheets over a side x side grid,
+    side chosen so that ~n voxels come out (L/N ~ 9).  Secondary workload (`--scene surface`), never the headline."""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(n / 2.0)))
+    xs, ys = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    sheets = []
+    for l in range(2):
+        a1, a2 = rng.uniform(3, 9), rng.uniform(1, 4)
+        f = rng.uniform(0.02, 0.15, size=4)
+        ph = rng.uniform(0, 6.28, size=3)
+        z = np.round(40 * l + a1 * np.sin(f[0] * xs + ph[0]) * np.cos(f[1] * ys + ph[1]) + a2 * np.sin(f[2] * xs + f[3] * ys + ph[2]))
+        sheets.append(np.stack([xs.ravel(), ys.ravel(), z.ravel().astype(np.int64)], 1))
+    c = np.unique(np.concatenate(sheets, 0), axis=0).astype(np.int32)
+    rng.shuffle(c)
+    return c[:n]
+
+
 def algorithmic_bytes(N, L, cin=CIN, cout=COUT, K=KVOL, e=2):
     """SURVEY.md §8(d) per-iteration algorithmic bytes (N_in = N_out = N)."""
     cap = 1 << int(np.ceil(np.log2(max(16, 2 * N))))
@@ -100,6 +118,9 @@ def main():
                     help="generator: rows in the order the reference's generator emits them (the headline workload); "
                          "block: the same scene with rows sorted by 16^3 block then x,y,z (what a voxelised scan looks like) - "
                          "a locality study, never the headline")
+    ap.add_argument("--scene", choices=["uniform", "surface"], default="uniform",
+                    help="uniform: the reference-style generator U the metric is quoted on; surface: generator S of "
+                         "SURVEY.md §8d (ScanNet-like sheets, ~2x the pairs per voxel) - a secondary workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,7 +142,7 @@ def main():
     _lib.lib()  # fail loudly if the HIP extension is missing
 
     # ---- resident inputs: one scene per GPU (weak scaling), identical weights on every rank ----
-    c_np = scene_u(args.voxels, seed=1000 + rank)
+    c_np = (scene_u if args.scene == "uniform" else scene_surface)(args.voxels, seed=1000 + rank)
     if args.coord_order == "block":
         key = (((c_np[:, 0] >> 4) * 4096 + (c_np[:, 1] >> 4)) * 4096 + (c_np[:, 2] >> 4)).astype(np.int64)
         c_np = c_np[np.lexsort((c_np[:, 2], c_np[:, 1], c_np[:, 0], key))]
@@ -245,7 +266,7 @@ def main():
                       + (N * (CIN + COUT) * e + 4 * KVOL * CIN * COUT + 4 * KVOL * N))
         traffic, traffic_src = None, None
         pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if N == 1_000_000 and os.path.exists(pmc_file):
+        if N == 1_000_000 and args.scene == "uniform" and os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 pmc = json.load(f)
             key = "fwd" if "(fwd)" in dom else ("dgrad" if "(dgrad)" in dom else "wgrad")
@@ -266,7 +287,7 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[1]: one {N}-voxel uniform (U) scene per GPU, SparseConv3d 64->128 k=3, bf16 autocast, "
+                "workload": f"configs[1]: one {N}-voxel {'uniform (U)' if args.scene == 'uniform' else 'surface-like (S, secondary)'} scene per GPU, SparseConv3d 64->128 k=3, bf16 autocast, "
                             "kernel-map build + AB fwd + ABt dgrad + AtB wgrad per step",
                 "voxels_per_gpu": N, "pairs_per_scene": L, "coord_order": args.coord_order, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)",
             },

@@ -189,12 +189,21 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
     }
   }
   // OR-reduce masks: rows of wave w are [w*RPW, (w+1)*RPW)
-  if (tid < kWaves) s_wmask[tid] = 0;
+  // (one word per 32-row block: a wave also skips the MFMAs of a row block that has no row with the offset)
+  if (tid < kWaves * RB) s_wmask[tid] = 0;
   __syncthreads();
-  if (tid < TILE && my_mask) atomicOr(&s_wmask[tid / RPW], my_mask);
+  if (tid < TILE && my_mask) atomicOr(&s_wmask[tid / 32], my_mask);
   __syncthreads();
-  const uint32_t wave_mask = s_wmask[wave];
-  const uint32_t block_mask = s_wmask[0] | s_wmask[1] | s_wmask[2] | s_wmask[3];
+  uint32_t rb_mask[RB];
+  uint32_t wave_mask = 0u, block_mask = 0u;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    rb_mask[rb] = __builtin_amdgcn_readfirstlane(s_wmask[wave * RB + rb]);  // wave-uniform: keep it in an SGPR
+    wave_mask |= rb_mask[rb];
+  }
+#pragma unroll
+  for (int q = 0; q < kWaves * RB; ++q) block_mask |= s_wmask[q];
+  block_mask = __builtin_amdgcn_readfirstlane(block_mask);
   WCN_STAMP(2);
   WCN_STAMPV(5, (unsigned long long)__builtin_popcount(block_mask));
 
@@ -250,9 +259,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
           for (int b = 0; b < NB; ++b) a_nxt[b] = wl[(b * NS + s + 1) * 64 + lane];
         }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int rb = 0; rb < RB; ++rb) {
+          if (RB > 1 && !((rb_mask[rb] >> k) & 1u)) continue;  // wave-uniform: no row of this block has offset k
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) acc[b][rb] = Frag<T>::mfma(a_cur[b], bf[rb][s], acc[b][rb]);
+          for (int b = 0; b < NB; ++b) acc[b][rb] = Frag<T>::mfma(a_cur[b], bf[rb][s], acc[b][rb]);
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) a_cur[b] = a_nxt[b];
