@@ -311,6 +311,39 @@ int wcn_pool_gather(const void* in, const int32_t* tbl, int64_t n_in, int64_t n_
 int wcn_pool_select(const void* dy, const int32_t* arg, const int32_t* tbl, int64_t n_in, int64_t n_out, int32_t channels,
                     int32_t num_offsets, int32_t dtype, void* dx, wcn_stream_t stream);
 
+/* ---- BatchNorm over sparse feature tensors [n, channels] (f32 / f16 / bf16 storage, fp32 statistics) --------------------
+ * The elementwise chain behind every sparse convolution (reference models/mink_unet.py:31-53: SparseConv3d ->
+ * nn.BatchNorm1d -> ReLU, the framework's stock BatchNorm kernels).  All passes stream the tensor once; the two
+ * reductions are fixed-order two-level sums (deterministic).  `workspace` >= wcn_bn_workspace(channels) bytes.
+ *   wcn_bn_stats            mean[c], var[c] (biased, /n) in one pass (sums around the pivot x[0][c]).
+ *   wcn_bn_apply            y = x * scale[c] + shift[c]; relu != 0: max(., 0).  (training: scale = gamma * rstd,
+ *                           shift = beta - mean * scale; inference: the same from the running statistics.)
+ *   wcn_bn_backward_reduce  sum_dy[c] = sum_r g, sum_dy_xhat[c] = sum_r g * (x - mean) * rstd, where g = dy, or 0 where
+ *                           y <= 0 when `y` (the forward output of a fused ReLU) is given; `y` may be NULL.
+ *   wcn_bn_backward_apply   dx = gamma * rstd * (g - sum_dy / n - xhat * sum_dy_xhat / n); gamma may be NULL (= 1). */
+size_t wcn_bn_workspace(int32_t channels);
+/*   wcn_bn_stats_fold       wcn_bn_stats plus, in the same launches, everything a training step derives from the
+ *                           statistics: rstd = 1/sqrt(var + eps), scale = gamma * rstd, shift = beta - mean * scale (gamma /
+ *                           beta may be NULL) and the in-place update of the fp32 running statistics (NULL: none) with
+ *                           `momentum` and the unbiased variance - the ~10 tiny framework kernels of a BatchNorm step.
+ *   wcn_bn_fold             inference: mean / rstd / scale / shift from the running statistics, one launch. */
+int wcn_bn_stats_fold(const void* x, int64_t n, int32_t channels, int32_t dtype, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* mean, float* var,
+                      float* rstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                      wcn_stream_t stream);
+int wcn_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
+                int32_t channels, float* mean, float* rstd, float* scale, float* shift, wcn_stream_t stream);
+int wcn_bn_stats(const void* x, int64_t n, int32_t channels, int32_t dtype, float* mean, float* var, void* workspace,
+                 size_t workspace_bytes, wcn_stream_t stream);
+int wcn_bn_apply(const void* x, int64_t n, int32_t channels, int32_t dtype, const float* scale, const float* shift,
+                 int32_t relu, void* y, wcn_stream_t stream);
+int wcn_bn_backward_reduce(const void* dy, const void* x, const void* y, int64_t n, int32_t channels, int32_t dtype,
+                           const float* mean, const float* rstd, float* sum_dy, float* sum_dy_xhat, void* workspace,
+                           size_t workspace_bytes, wcn_stream_t stream);
+int wcn_bn_backward_apply(const void* dy, const void* x, const void* y, int64_t n, int32_t channels, int32_t dtype,
+                          const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
+                          const float* sum_dy_xhat, void* dx, wcn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

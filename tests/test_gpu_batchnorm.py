@@ -1,0 +1,111 @@
+"""GPU: HIP BatchNorm over sparse feature tensors vs torch.nn.BatchNorm1d evaluated in fp64 on the CPU (same parameters,
+same inputs): forward, input / weight / bias gradients, running statistics, fused ReLU, eval mode, the Sequential
+fast path."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+from tests.util import rel_max_err, scene_u
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(bn: nn.BatchNorm1d, x: torch.Tensor, g: torch.Tensor, relu: bool):
+    """fp64 reference on the values the kernel saw (x, g already rounded to the storage dtype)."""
+    ref = copy.deepcopy(bn).double().cpu()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    y = ref(xr)
+    if relu:
+        y = torch.relu(y)
+    y.backward(g.double().cpu())
+    return ref, y.detach(), xr.grad
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,c", [(5000, 96), (20000, 13), (257, 256), (7, 32), (1, 8)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_training_forward_backward(n, c, dtype, relu):
+    from warpconvnet_amd.nn.functional.normalizations import batch_norm_module_forward
+
+    torch.manual_seed(n + c)
+    bn = nn.BatchNorm1d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.normal_(1.0, 0.3)
+        bn.bias.normal_(0.0, 0.3)
+    x = (torch.randn(n, c, device=DEV) * 2.0 + 0.7).to(dtype).requires_grad_(True)
+    g = torch.randn(n, c, device=DEV).to(dtype)
+    if n == 1:  # torch refuses a single value per channel in training mode; the kernels give var = 0
+        return
+    ref, y_ref, dx_ref = _ref(bn, x, g, relu)
+    y = batch_norm_module_forward(bn, x, relu=relu)
+    y.backward(g)
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    assert y.dtype == dtype and rel_max_err(y.detach(), y_ref) < tol
+    assert rel_max_err(x.grad, dx_ref) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert rel_max_err(bn.weight.grad, ref.weight.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_max_err(bn.bias.grad, ref.bias.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    # running statistics (unbiased variance, momentum 0.1) and the step counter
+    assert rel_max_err(bn.running_mean, ref.running_mean) < 1e-4 and rel_max_err(bn.running_var, ref.running_var) < 1e-4
+    assert int(bn.num_batches_tracked) == 1 == int(ref.num_batches_tracked)
+
+
+def test_statistics_are_robust_and_deterministic():
+    """A large common offset must not cancel the variance (sums are taken around a pivot row); bitwise repeatable."""
+    from warpconvnet_amd.nn.functional.normalizations import hip_batch_norm
+
+    torch.manual_seed(0)
+    x = (torch.randn(100_000, 64, device=DEV) + 1000.0)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    y1 = hip_batch_norm(x, rm.clone(), rv.clone(), training=True)
+    y2 = hip_batch_norm(x, rm.clone(), rv.clone(), training=True)
+    assert torch.equal(y1, y2)
+    want = (x.double() - x.double().mean(0)) / x.double().var(0, unbiased=False).add(1e-5).sqrt()
+    assert rel_max_err(y1, want) < 1e-3  # fp32 storage of x at 1000 +- 1 limits this, not the reduction
+
+
+def test_eval_mode_cumulative_momentum_and_sequential():
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.functional.normalizations import batch_norm_module_forward
+    from warpconvnet_amd.nn.modules import BatchNorm, Sequential
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    torch.manual_seed(1)
+    # momentum=None: cumulative moving average over the batches seen
+    bn = nn.BatchNorm1d(24, momentum=None).to(DEV)
+    ref = copy.deepcopy(bn).double().cpu()
+    for step in range(3):
+        x = torch.randn(3000, 24, device=DEV) * (step + 1)
+        batch_norm_module_forward(bn, x)
+        ref(x.double().cpu())
+    assert int(bn.num_batches_tracked) == 3
+    assert rel_max_err(bn.running_mean, ref.running_mean) < 1e-4 and rel_max_err(bn.running_var, ref.running_var) < 1e-4
+    # eval: running statistics, gradients flow with constant statistics
+    bn.eval(); ref.eval()
+    x = torch.randn(1000, 24, device=DEV, requires_grad=True)
+    g = torch.randn(1000, 24, device=DEV)
+    _, y_ref, dx_ref = _ref(bn, x, g, True)
+    y = batch_norm_module_forward(bn, x, relu=True)
+    y.backward(g)
+    assert rel_max_err(y.detach(), y_ref) < 1e-5 and rel_max_err(x.grad, dx_ref) < 1e-5
+    # Sequential(conv, BatchNorm1d, ReLU) == the same chain with the stock BatchNorm module (fast path switched off)
+    p = torch.from_numpy(scene_u(4000, 3)[:, 1:])
+    vox = Voxels([p], [torch.randn(len(p), 16)], device=torch.device(DEV))
+    net = Sequential(SparseConv3d(16, 32, 3, bias=False), nn.BatchNorm1d(32), nn.ReLU(inplace=True)).to(DEV)
+    net2 = copy.deepcopy(net)
+    import os
+
+    y_fast = net(vox).feature_tensor
+    os.environ["WARPCONVNET_AMD_HIP_BATCHNORM"] = "0"
+    try:
+        y_stock = net2(vox).feature_tensor
+    finally:
+        del os.environ["WARPCONVNET_AMD_HIP_BATCHNORM"]
+    assert rel_max_err(y_fast, y_stock) < 1e-4 and (y_fast >= 0).all()
+    assert rel_max_err(net[1].running_var, net2[1].running_var) < 1e-4
+    # the reference-style wrapper module
+    wrap = BatchNorm(32).to(DEV)
+    out = wrap(net(vox))
+    assert out.feature_tensor.shape == (len(p), 32) and int(wrap.norm.num_batches_tracked) == 1

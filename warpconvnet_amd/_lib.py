@@ -38,6 +38,18 @@ SIGNATURES = {
         [c_void_p, c_int64, c_void_p, c_int64, _3I, _3I, _3I, c_void_p, c_void_p, c_void_p],
     ),
     "wcn_batch_indexed_coords": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "wcn_bn_workspace": (c_size_t, [c_int32]),
+    "wcn_bn_stats": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_bn_stats_fold": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float,
+                                  ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
+    "wcn_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int32, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p]),
+    "wcn_bn_apply": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "wcn_bn_backward_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_bn_backward_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "wcn_pool_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     "wcn_pool_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

@@ -11,7 +11,7 @@ import torch
 from torch import Tensor
 
 from warpconvnet_amd.geometry.coords.ops.batch_index import offsets_from_batch_index
-from warpconvnet_amd.utils.ntuple import ntuple
+from warpconvnet_amd.utils.ntuple import device_const_i32, ntuple
 from warpconvnet_amd.utils.unique import unique_first_indices
 
 
@@ -22,7 +22,7 @@ def stride_coords(batch_indexed_coords: Tensor, stride: Tuple[int, ...], order=N
     stride = ntuple(stride, nd)
     if all(s == 1 for s in stride):
         return batch_indexed_coords, offsets_from_batch_index(batch_indexed_coords[:, 0])
-    div = torch.tensor([1, *stride], dtype=torch.int32, device=batch_indexed_coords.device)
+    div = device_const_i32([1, *stride], batch_indexed_coords.device)
     coarse = torch.div(batch_indexed_coords, div, rounding_mode="floor").to(torch.int32)
     idx = unique_first_indices(coarse)
     out = coarse[idx].contiguous()

@@ -19,7 +19,7 @@ from warpconvnet_amd.geometry.coords.search.cache import IntSearchCache, IntSear
 from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
 from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
 from warpconvnet_amd.geometry.types.voxels import Voxels
-from warpconvnet_amd.utils.ntuple import ntuple
+from warpconvnet_amd.utils.ntuple import device_const_i32, ntuple
 
 from .detail.unified import (
     SPARSE_CONV_AB_ALGO_MODE,
@@ -79,7 +79,7 @@ def generate_output_coords_and_kernel_map(
         if all(s == 1 for s in stride):
             base = bcoords_in
         elif transposed:  # up-sampling + densification: scale the coordinates, then expand; map built at stride 1
-            scale = torch.tensor([1, *stride], dtype=torch.int32, device=bcoords_in.device)
+            scale = device_const_i32([1, *stride], bcoords_in.device)
             base = bcoords_in * scale
             bcoords_in = base
         else:             # stride first, then expand; the map still pairs the original inputs with the outputs

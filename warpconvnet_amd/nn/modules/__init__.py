@@ -1,6 +1,7 @@
 from .base_module import BaseSpatialModel, BaseSpatialModule
 from .fused_block import FusedSparseConvBlock
 from .mlp import MLPBlock
+from .normalizations import BatchNorm, NormalizationBase
 from .point_conv import PointConv
 from .sequential import Sequential
 from .sparse_conv import SparseConv2d, SparseConv3d, SpatiallySparseConv
@@ -9,4 +10,4 @@ from .sparse_conv_depth import SparseDepthwiseConv2d, SparseDepthwiseConv3d, Spa
 
 __all__ = ["BaseSpatialModel", "BaseSpatialModule", "MLPBlock", "PointConv", "Sequential", "SparseConv2d", "SparseConv3d", "SpatiallySparseConv",
            "SparseDepthwiseConv2d", "SparseDepthwiseConv3d", "SpatiallySparseDepthwiseConv",
-           "FusedSparseConvBlock", "GlobalPool", "SparseMaxPool", "SparseMinPool", "SparsePool", "SparseUnpool"]
+           "BatchNorm", "NormalizationBase", "FusedSparseConvBlock", "GlobalPool", "SparseMaxPool", "SparseMinPool", "SparsePool", "SparseUnpool"]

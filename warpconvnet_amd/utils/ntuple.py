@@ -23,3 +23,16 @@ def _pad_values(number_of_outputs: int, *values: Any) -> Tuple[Any, ...]:
 
 def _pad_tuple(x: Any, y: Any, number_of_outputs: int) -> Tuple[Any, ...]:
     return _pad_values(number_of_outputs, x, y)
+
+
+_DEVICE_CONSTS = {}
+
+
+def device_const_i32(values: Sequence[int], device: torch.device) -> torch.Tensor:
+    """Small int32 constant vector on ``device``, built once per (values, device): ``torch.tensor(list, device=gpu)`` is a
+    synchronous pageable host-to-device copy (~0.3 ms) - five of them per MinkUNet forward before this cache."""
+    key = (tuple(int(v) for v in values), str(device))
+    t = _DEVICE_CONSTS.get(key)
+    if t is None:
+        t = _DEVICE_CONSTS[key] = torch.tensor(key[0], dtype=torch.int32, device=device)
+    return t
