@@ -191,6 +191,10 @@ int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype);
 size_t wcn_packed_weight_bytes(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose);
 int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype,
                     int32_t transpose, int32_t flip, void* packed, wcn_stream_t stream);
+/* the same packed image (`dtype` = WCN_F16 / WCN_BF16) straight from fp32 master weights, rounded to nearest even like the
+ * framework's cast: one launch instead of cast + pack per convolution and direction. */
+int wcn_pack_weight_f32(const float* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose,
+                        int32_t flip, void* packed, wcn_stream_t stream);
 
 /* y = gather-GEMM over a neighbour table.  Serves forward (x, packed w) and dgrad (dy, packed w^T).
  *   in   [n_in, cin]   out [n_out, cout]   nbr [n_out, kp]   mask [n_out, mw]   perm [n_out] or NULL

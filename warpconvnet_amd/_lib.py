@@ -85,6 +85,10 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
     ),
+    "wcn_pack_weight_f32": (
+        c_int,
+        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
+    ),
     "wcn_conv_gather_gemm": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,

@@ -16,6 +16,8 @@ int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32
                           float* out32, hipStream_t s);
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s);
+int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
+                         hipStream_t s);
 // wgrad_mfma.hip
 bool mfma_wgrad_supported(int cin, int cout, int dtype);
 size_t wgrad_mfma_workspace(int K, int cin, int cout);
@@ -65,6 +67,12 @@ int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cou
                     int32_t flip, void* packed, wcn_stream_t stream) {
   if (!w || !packed || num_offsets < 1 || cin < 1 || cout < 1) return WCN_ERROR_INVALID_PARAMETERS;
   return pack_weight_mfma(w, num_offsets, cin, cout, dtype, transpose, flip, packed, (hipStream_t)stream);
+}
+
+int wcn_pack_weight_f32(const float* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose,
+                        int32_t flip, void* packed, wcn_stream_t stream) {
+  if (!w || !packed || num_offsets < 1 || cin < 1 || cout < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  return pack_weight_mfma_f32(w, num_offsets, cin, cout, dtype, transpose, flip, packed, (hipStream_t)stream);
 }
 
 int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t* nbr, const uint32_t* mask,

@@ -91,6 +91,30 @@ __global__ void pack_weight_kernel(const T* __restrict__ w, T* __restrict__ pack
   packed[e] = w[src];
 }
 
+// the same image straight from the fp32 master weights (round to nearest even, what `.to(bf16 / f16)` does): one launch
+// instead of a cast kernel plus a pack kernel per convolution and direction
+template <typename TD>
+__global__ void pack_weight_cast_kernel(const float* __restrict__ w, TD* __restrict__ packed, int K, int cin, int cout,
+                                        int cic, int transpose, int flip) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * cin * cout;
+  if (e >= total) return;
+  const int NS = cic / 16, NB = cout / 32, nchunk = cin / cic;
+  int64_t t = e;
+  const int j = (int)(t % 8); t /= 8;
+  const int lane = (int)(t % 64); t /= 64;
+  const int s = (int)(t % NS); t /= NS;
+  const int b = (int)(t % NB); t /= NB;
+  const int chunk = (int)(t % nchunk); t /= nchunk;
+  const int k = (int)t;
+  const int h = lane >> 5, m = lane & 31;
+  const int ci = chunk * cic + h * (cic / 2) + 8 * s + j;
+  const int co = ((m >> 2) & 1) * (cout / 2) + 16 * b + 4 * (m >> 3) + (m & 3);
+  const int kw = flip ? (K - 1 - k) : k;
+  const int64_t src = transpose ? (((int64_t)kw * cout + co) * cin + ci) : (((int64_t)kw * cin + ci) * cout + co);
+  packed[e] = (TD)w[src];
+}
+
 // ---- main kernel -------------------------------------------------------------------------------------
 template <typename T, int CIC, int CO, int RB>
 struct GatherGemm {
@@ -522,6 +546,20 @@ int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32
   if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, out32, s);
   return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, out32, s);
+}
+
+int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
+                         hipStream_t s) {
+  const int cic = mfma_chunk_for(cin);
+  if (cic == 0 || cout % 32 != 0 || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  const int64_t total = (int64_t)K * cin * cout;
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (dtype == WCN_BF16)
+    hipLaunchKernelGGL(pack_weight_cast_kernel<__bf16>, grid, block, 0, s, w, (__bf16*)packed, K, cin, cout, cic, transpose, flip);
+  else
+    hipLaunchKernelGGL(pack_weight_cast_kernel<_Float16>, grid, block, 0, s, w, (_Float16*)packed, K, cin, cout, cic,
+                       transpose, flip);
+  return launch_status();
 }
 
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,

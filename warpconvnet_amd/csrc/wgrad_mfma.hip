@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const T* __restrict_
 // order => deterministic.  (ce is a multiple of 64: channel counts are multiples of 32.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs,
                                                            const int32_t* __restrict__ offsets, int K, int64_t ce, int G,
-                                                           float* __restrict__ dw) {
+                                                           float* __restrict__ dw, const float* __restrict__ cs_slabs,
+                                                           int cs_k, int cout, float* __restrict__ bias_grad) {
   __shared__ float4 s_part[16][16];
   const int part = threadIdx.x >> 4, el = threadIdx.x & 15;
   const int64_t e = (int64_t)blockIdx.x * 64 + el * 4;
@@ -316,6 +317,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int64_t L = offsets[K];
   int64_t Q = (L + G - 1) / G;
   Q = ((Q + kPairs - 1) / kPairs) * kPairs;
+  if (k == K) {
+    // extra grid row (bias-gradient launches only): bias_grad[co] = sum over the ranges g that intersect bucket cs_k
+    // (ascending) of cs_slabs[g][co]; one wavefront per channel - same launch instead of a ~5 us kernel of its own
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (co >= cout) return;
+    const int64_t b = offsets[cs_k], en = offsets[cs_k + 1];
+    float s = 0.f;
+    if (en > b && Q > 0) {
+      const int g_lo = (int)(b / Q), g_hi = (int)((en - 1) / Q);
+      for (int g = g_lo + lane; g <= g_hi; g += 64) s += cs_slabs[(int64_t)g * cout + co];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) bias_grad[co] = s;
+    return;
+  }
   const int64_t b = offsets[k], en = offsets[k + 1];
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < ce && en > b && Q > 0) {
@@ -336,26 +353,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     *reinterpret_cast<float4*>(dw + (int64_t)k * ce + e) = t;
   }
-}
-
-// bias_grad[co] = sum over the ranges g that intersect bucket cs_k (ascending) of cs_slabs[g][co]; one wavefront per
-// channel, lane l adds ranges g_lo + l, + 64, ... then a fixed butterfly => deterministic.
-__global__ __launch_bounds__(64) void wgrad_colsum_reduce_kernel(const float* __restrict__ cs_slabs,
-                                                                 const int32_t* __restrict__ offsets, int K, int cs_k,
-                                                                 int cout, int G, float* __restrict__ out) {
-  const int co = blockIdx.x, lane = threadIdx.x;
-  const int64_t L = offsets[K];
-  int64_t Q = (L + G - 1) / G;
-  Q = ((Q + kPairs - 1) / kPairs) * kPairs;
-  const int64_t b = offsets[cs_k], en = offsets[cs_k + 1];
-  float s = 0.f;
-  if (en > b && Q > 0) {
-    const int g_lo = (int)(b / Q), g_hi = (int)((en - 1) / Q);
-    for (int g = g_lo + lane; g <= g_hi; g += 64) s += cs_slabs[(int64_t)g * cout + co];
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-  if (lane == 0) out[co] = s;
 }
 
 static int wgrad_tile(int c) {  // largest supported tile dividing the channel count
@@ -408,8 +405,6 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
       hipLaunchKernelGGL((wgrad_mfma_kernel<T, CIT, COT, true>), grid, dim3(256), W::LDS_BYTES, s, (const T*)x,
                          (const T*)dy, in_maps, out_maps, offsets, K, cin, cout, (const char*)zero_page, slabs, cs_slabs,
                          cs_k);
-      hipLaunchKernelGGL(wgrad_colsum_reduce_kernel, dim3((unsigned)cout), dim3(64), 0, s, (const float*)cs_slabs, offsets,
-                         K, cs_k, cout, kWgradGrid, bias_grad);
     } else {
       return WCN_ERROR_UNSUPPORTED_CONFIG;
     }
@@ -418,8 +413,11 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
                        (const T*)dy, in_maps, out_maps, offsets, K, cin, cout, (const char*)zero_page, slabs, nullptr, -1);
   }
   const int64_t ce = (int64_t)cin * cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ce, 64), K), dim3(256), 0, s, (const float*)slabs,
-                     offsets, K, ce, kWgradGrid, dw);
+  // (the row K of the grid, present with a bias gradient, reduces the column-sum partials: 4 channels per workgroup)
+  const unsigned gx = (unsigned)ceil_div(ce, 64);
+  if (bias_grad && (int64_t)gx * 4 < cout) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, bias_grad ? K + 1 : K), dim3(256), 0, s, (const float*)slabs, offsets, K, ce,
+                     kWgradGrid, dw, (const float*)cs_slabs, cs_k, cout, bias_grad);
   return launch_status();
 }
 

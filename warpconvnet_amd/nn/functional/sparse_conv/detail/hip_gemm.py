@@ -74,17 +74,38 @@ def resolve_wgrad_algo(algo: str, cin: int, cout: int, dtype: torch.dtype) -> in
     return _lib.WCN_ALGO_MFMA if ok else _lib.WCN_ALGO_REF
 
 
-def pack_weight(weight: Tensor, transpose: bool, flip: bool) -> Tensor:
-    """Fragment-ordered weight image for the MFMA gather-GEMM.  ``weight`` is the forward [K, Cin, Cout]."""
+def pack_weight(weight: Tensor, transpose: bool, flip: bool, dtype: Optional[torch.dtype] = None) -> Tensor:
+    """Fragment-ordered weight image for the MFMA gather-GEMM.  ``weight`` is the forward [K, Cin, Cout]; an fp32 master
+    weight with a 16-bit ``dtype`` is rounded while it is packed (one launch instead of cast + pack)."""
     K, c_in, c_out = weight.shape
     kin, kout = (c_out, c_in) if transpose else (c_in, c_out)  # kernel-side channel roles
-    packed = torch.empty(weight.numel(), dtype=weight.dtype, device=weight.device)
+    dtype = dtype or weight.dtype
+    packed = torch.empty(weight.numel(), dtype=dtype, device=weight.device)
+    if weight.dtype == torch.float32 and dtype != torch.float32:
+        _lib.check(
+            _lib.lib().wcn_pack_weight_f32(_lib.ptr(weight), K, kin, kout, _lib.dtype_code(dtype), int(transpose), int(flip),
+                                           _lib.ptr(packed), _lib.stream_handle(weight.device)),
+            "wcn_pack_weight_f32",
+        )
+        return packed
     _lib.check(
         _lib.lib().wcn_pack_weight(_lib.ptr(weight), K, kin, kout, _lib.dtype_code(weight.dtype), int(transpose),
                                    int(flip), _lib.ptr(packed), _lib.stream_handle(weight.device)),
         "wcn_pack_weight",
     )
     return packed
+
+
+def master_weight_ok(x_dtype: torch.dtype, weight: Tensor, algo: str, transposed: bool) -> bool:
+    """May ``weight`` stay an fp32 master for 16-bit features?  Only when the MFMA kernel takes the shape: the packed
+    image is then produced from fp32 directly; every other path multiplies in the storage dtype and needs the cast."""
+    if weight.dtype != torch.float32 or x_dtype not in (torch.float16, torch.bfloat16) or weight.ndim != 3 or not weight.is_cuda:
+        return False
+    if algo not in ("auto", "hip_mfma"):
+        return False
+    K, cin, cout = weight.shape
+    kin, kout = (cout, cin) if transposed else (cin, cout)
+    return bool(_lib.lib().wcn_mfma_gather_supported(kin, kout, K, _lib.dtype_code(x_dtype)))
 
 
 def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: Optional[Tensor], n_out: int,
@@ -94,7 +115,7 @@ def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: O
     if n_out == 0:
         return out
     if algo_code == _lib.WCN_ALGO_MFMA:
-        w_arg = pack_weight(weight, transposed, flip)
+        w_arg = pack_weight(weight, transposed, flip, dtype=inp.dtype)
     else:
         w_arg = weight
     if f32_out:
@@ -124,7 +145,7 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
             bias = bias.float()
         bias = _prep(bias, "bias")
     x, w = _prep(in_features, "in_features"), _prep(weight, "weight")
-    if x.dtype != w.dtype:
+    if x.dtype != w.dtype and not master_weight_ok(x.dtype, w, algo, False):
         raise RuntimeError(f"hip forward error: {_lib.status_string(-6)} ({x.dtype} vs {w.dtype})")
     K, cin, cout = w.shape
     assert K == len(kernel_map) and cin == x.shape[1]
@@ -162,7 +183,7 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
               algo: str = "auto") -> Tensor:
     """dx[n] = sum_k dy[rev[n][k]] @ w[k]^T; a submanifold map reuses the forward table with k reversed."""
     dy, w = _prep(grad_output, "grad_output"), _prep(weight, "weight")
-    if dy.dtype != w.dtype:
+    if dy.dtype != w.dtype and not master_weight_ok(dy.dtype, w, algo, True):
         raise RuntimeError(f"hip dgrad error: {_lib.status_string(-6)} ({dy.dtype} vs {w.dtype})")
     K, cin, cout = w.shape
     kernel_map.poll()

@@ -77,7 +77,15 @@ class UnifiedSpatiallySparseConvFunction(Function):
         ctx.wgrad_algo = _algo_name(wgrad_algo, on_gpu)
         ctx.weight_dtype = weight.dtype
         if compute_dtype is not None and weight.dtype != compute_dtype and weight.is_floating_point():
-            weight = weight.to(compute_dtype)  # saved in compute precision (reference helper.py:256-262 casts before apply)
+            from .hip_gemm import master_weight_ok
+
+            fa, da = _algo_name(fwd_algo, on_gpu), ctx.dgrad_algo
+            keep_master = (on_gpu and groups == 1 and master_weight_ok(compute_dtype, weight, fa, False)
+                           and master_weight_ok(compute_dtype, weight, da, True))
+            if not keep_master:  # saved in compute precision (reference helper.py:256-262 casts before apply)
+                weight = weight.to(compute_dtype)
+            # else: the MFMA kernels' packed weight image is rounded from the fp32 master directly (same values, one launch
+            # less per direction) and the parameter itself is what is saved for the backward pass
         ctx.save_for_backward(in_features, weight)
         ctx.has_bias = bias is not None
         cout = weight.shape[-1] * (groups if weight.ndim == 4 else 1)
