@@ -70,8 +70,9 @@ def _bwd_explicit(ctx: BwdCtx):
 def _make_hip_fwd(algo: str) -> FwdFn:
     def fn(ctx: FwdCtx):
         dt = ctx.compute_dtype or ctx.in_features.dtype
-        out = hip_gemm.hip_forward(ctx.in_features.to(dt), ctx.weight.to(dt), ctx.kernel_map, ctx.num_out_coords, algo,
-                                   bias=ctx.bias)
+        # (an fp32 master weight stays as it is when the MFMA kernel takes the shape: its packed image is rounded from it)
+        w = ctx.weight if hip_gemm.master_weight_ok(dt, ctx.weight, algo, False) else ctx.weight.to(dt)
+        out = hip_gemm.hip_forward(ctx.in_features.to(dt), w, ctx.kernel_map, ctx.num_out_coords, algo, bias=ctx.bias)
         return out.to(ctx.in_features.dtype) if ctx.compute_dtype is not None else out
 
     return fn
@@ -84,7 +85,8 @@ def _make_hip_bwd(algo: str) -> BwdFn:
         dy = ctx.grad_output.to(dt)
         dx = dw = None
         if need_dx:
-            dx = hip_gemm.hip_dgrad(dy, ctx.weight.to(dt), ctx.kernel_map, ctx.in_features.shape[0], algo)
+            w = ctx.weight if hip_gemm.master_weight_ok(dt, ctx.weight, algo, True) else ctx.weight.to(dt)
+            dx = hip_gemm.hip_dgrad(dy, w, ctx.kernel_map, ctx.in_features.shape[0], algo)
             dx = dx.to(ctx.in_features.dtype)
         if need_dw:
             # the bias gradient rides along only if it is the column sum of the very tensor autograd handed us
