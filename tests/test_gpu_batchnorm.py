@@ -37,7 +37,9 @@ def test_training_forward_backward(n, c, dtype, relu):
         bn.bias.normal_(0.0, 0.3)
     x = (torch.randn(n, c, device=DEV) * 2.0 + 0.7).to(dtype).requires_grad_(True)
     g = torch.randn(n, c, device=DEV).to(dtype)
-    if n == 1:  # torch refuses a single value per channel in training mode; the kernels give var = 0
+    if n == 1:  # a single value per channel has no variance: refused in training mode, like torch
+        with pytest.raises(ValueError):
+            batch_norm_module_forward(bn, x, relu=relu)
         return
     ref, y_ref, dx_ref = _ref(bn, x, g, relu)
     y = batch_norm_module_forward(bn, x, relu=relu)

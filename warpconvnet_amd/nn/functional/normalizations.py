@@ -131,6 +131,8 @@ def hip_batch_norm(x: Tensor, running_mean: Optional[Tensor], running_var: Optio
         raise RuntimeError(f"hip_batch_norm needs a non-empty 2-D f32/f16/bf16 GPU tensor, got {tuple(x.shape)} {x.dtype} {x.device}")
     if not training and (running_mean is None or running_var is None):
         raise ValueError("hip_batch_norm in eval mode needs running statistics")
+    if training and x.shape[0] == 1:  # same refusal as F.batch_norm: a single row has no variance
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
     return _HipBatchNorm.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), bool(relu))
 
 
