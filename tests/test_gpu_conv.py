@@ -489,3 +489,35 @@ def test_generative_convolution_module(transposed, ksize, stride):
     dXr, dWr = oconv.backward(dY.double().cpu(), Xd, Wd, in_maps, out_maps, r["offsets"])
     assert rel_max_err(y.feature_tensor.detach(), Yr) < 1e-3
     assert rel_max_err(X.grad, dXr) < 1e-3 and rel_max_err(conv.weight.grad, dWr) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("cin,cout", [(96, 20), (32, 64), (3, 16), (256, 256)])
+def test_pointwise_conv_gradients(cin, cout, dtype):
+    """kernel_size = 1: forward / dX dense products, dW through the sparse AtB kernel with the identity pair list
+    (channel counts outside the MFMA tiles zero-padded), bias gradient by column sum - vs fp64 on the same values."""
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    p = scene_u(20000, 12)[:, 1:]
+    torch.manual_seed(cin * 7 + cout)
+    conv = SparseConv3d(cin, cout, 1, bias=True).to(dev)
+    x = torch.randn(len(p), cin, device=dev).to(dtype).requires_grad_(True)
+    vox = Voxels([torch.from_numpy(p)], [x.detach().cpu().float()], device=dev).replace(batched_features=x)
+    g = torch.randn(len(p), cout, device=dev).to(dtype)
+    with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+        y = conv(vox)
+    assert y.feature_tensor.dtype == dtype and torch.equal(y.coordinate_tensor, vox.coordinate_tensor)
+    y.feature_tensor.backward(g)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    wq = conv.weight.detach()[0].to(dtype).double().cpu().requires_grad_(True)
+    br = conv.bias.detach().double().cpu().requires_grad_(True)
+    yr = xr @ wq + br
+    yr.backward(g.double().cpu())
+    tol = 1e-4 if dtype == torch.float32 else 1.5e-2
+    assert rel_max_err(y.feature_tensor.detach(), yr.detach()) < tol
+    assert rel_max_err(x.grad, xr.grad) < tol
+    assert rel_max_err(conv.weight.grad[0], wq.grad) < tol
+    assert rel_max_err(conv.bias.grad, br.grad) < tol
+    assert conv.weight.grad.dtype == torch.float32 and conv.weight.grad.shape == (1, cin, cout)

@@ -167,10 +167,15 @@ def spatially_sparse_conv(
 
     # 1x1 kernel, stride 1: a plain matmul on the features (reference helper.py:206-213)
     if int(np.prod(_kernel_size)) == 1 and int(np.prod(_stride)) == 1:
+        from warpconvnet_amd.nn.functional.sparse_conv.pointwise import pointwise_conv
+
         feats = input_sparse_tensor.feature_tensor
-        out = feats @ weight[0].to(feats.dtype)
-        if bias is not None:
-            out = out + bias.to(out.dtype)
+        if weight.ndim == 3:  # forward / dX: dense products; dW through the sparse AtB kernel (pointwise.py)
+            out = pointwise_conv(feats, weight[0], bias)
+        else:
+            out = feats @ weight[0].to(feats.dtype)
+            if bias is not None:
+                out = out + bias.to(out.dtype)
         return input_sparse_tensor.replace(batched_features=out)
 
     in_tensor_stride = input_sparse_tensor.tensor_stride or ntuple(1, ndim=nd)

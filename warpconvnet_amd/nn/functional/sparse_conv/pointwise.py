@@ -1,0 +1,91 @@
+"""1x1 (kernel volume 1, stride 1) sparse convolution: a dense ``[N, Cin] x [Cin, Cout]`` product on the feature tensor.
+
+The reference's shortcut is a plain ``feats @ weight[0]`` (`helper.py:206-213`) and leaves the backward to the
+framework.  Forward and input gradient are fine that way; the WEIGHT gradient ``X^T dY`` has a tiny output
+(``Cin x Cout``) and a reduction over all N rows, a shape the vendor GEMM serves with a non-split kernel (measured
+300-600 us at N = 200 k for 32->64 ... 96->20, the largest single kernels of a MinkUNet backward).  It is exactly
+the AtB problem of the sparse path with the identity pair list, so it goes through `wcn_conv_wgrad` (fixed grid of pair
+ranges + ordered slab reduction, deterministic): ~15 us.  Channel counts outside the MFMA tiles are zero-padded to the
+next multiple of 32 for that one product.
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from warpconvnet_amd import _lib
+from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+
+_IDENTITY_MAPS = {}
+
+
+def _identity_map(n: int, dev: torch.device) -> IntSearchResult:
+    """Pair list (r, r), r = 0..n-1, as a one-offset kernel map; cached per (n, device) (8 bytes per row)."""
+    key = (n, str(dev))
+    km = _IDENTITY_MAPS.get(key)
+    if km is None:
+        if len(_IDENTITY_MAPS) > 16:
+            _IDENTITY_MAPS.clear()
+        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        km = IntSearchResult(rows, rows, torch.tensor([0, n], dtype=torch.int32))
+        km._offsets_dev = torch.tensor([0, n], dtype=torch.int32, device=dev)
+        _IDENTITY_MAPS[key] = km
+    return km
+
+
+def _pad_channels(t: Tensor, mult: int = 32) -> Tensor:
+    c = t.shape[1]
+    cp = (c + mult - 1) // mult * mult
+    if cp == c:
+        return t.contiguous()
+    out = torch.zeros((t.shape[0], cp), dtype=t.dtype, device=t.device)
+    out[:, :c] = t
+    return out
+
+
+def dense_wgrad(x: Tensor, dy: Tensor) -> Tensor:
+    """fp32 ``x^T @ dy`` ([Cin, Cout]) of two 16-bit ``[N, C]`` GPU tensors through the sparse wgrad kernel."""
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    n, cin, cout = x.shape[0], x.shape[1], dy.shape[1]
+    xp, gp = _pad_channels(x), _pad_channels(dy)
+    dw = hip_gemm.hip_wgrad(xp, gp, _identity_map(n, x.device), (1, xp.shape[1], gp.shape[1]), "hip_mfma")
+    return dw[0, :cin, :cout]
+
+
+class _PointwiseConv(Function):
+    @staticmethod
+    def forward(ctx, feats: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+        w = weight if weight.dtype == feats.dtype else weight.to(feats.dtype)
+        ctx.save_for_backward(feats, w)
+        ctx.weight_dtype, ctx.has_bias = weight.dtype, bias is not None
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        out = feats @ w
+        return out if bias is None else out + bias.to(out.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        feats, w = ctx.saved_tensors
+        dy = grad_out.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ w.t()
+        if ctx.needs_input_grad[1]:
+            if (dy.is_cuda and dy.dtype in (torch.float16, torch.bfloat16) and feats.dtype == dy.dtype and feats.shape[0] > 0):
+                dw = dense_wgrad(feats.contiguous(), dy).to(ctx.weight_dtype)
+            else:
+                dw = (feats.t() @ dy).to(ctx.weight_dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if dy.is_cuda and dy.shape[0] > 0 and dy.dtype in (torch.float32, torch.float16, torch.bfloat16):
+                from warpconvnet_amd.nn.functional.sparse_conv.detail.hip_gemm import hip_colsum
+
+                db = hip_colsum(dy).to(ctx.bias_dtype)
+            else:
+                db = dy.sum(0).to(ctx.bias_dtype)
+        return dx, dw, db
+
+
+def pointwise_conv(feats: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """``feats [N, Cin] @ weight [Cin, Cout] (+ bias)`` with the weight gradient through the sparse wgrad kernel."""
+    return _PointwiseConv.apply(feats, weight, bias)
