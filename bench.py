@@ -274,7 +274,7 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         total_bytes = sum(ab.values())
         result = {
-            "metric": "M active voxels/sec fwd+bwd, SparseConv3d 64->128 k=3",
+            "metric": "M active voxels/sec fwd+bwd, SparseConv3d 64\u2192128 k=3, 1/2/4/8 MI355X",  # = BASELINE.json:metric
             "value": round(value, 3),
             "unit": "M voxels/s",
             "n_gpus": world,
