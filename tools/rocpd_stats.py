@@ -83,7 +83,32 @@ def traffic(fetch_db, write_db):
     print(json.dumps(out, indent=1))
 
 
+def mfma(db):
+    """Matrix-core utilisation per kernel from a `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES` pass:
+    MFMA busy cycles (summed over SIMDs) / (4 SIMDs x CU busy cycles)."""
+    rows = sqlite3.connect(db).execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+    agg = {}
+    for k, c, v in rows:
+        a = agg.setdefault((k, c), [0, 0.0])
+        a[0] += 1
+        a[1] += v
+    avg = {kc: t / n for kc, (n, t) in agg.items()}
+    names = sorted({k for k, _ in avg}, key=lambda k: -avg.get((k, "SQ_BUSY_CU_CYCLES"), 0))
+    print(f"# rocprofv3 PMC summary: matrix-core utilisation ({db})\n")
+    print("`SQ_VALU_MFMA_BUSY_CYCLES` is summed over the SIMDs (32 cycles per `v_mfma_f32_32x32x16_bf16`), `SQ_BUSY_CU_CYCLES` over")
+    print("the CUs; MFMA utilisation = MFMA busy cycles / (4 SIMDs x CU busy cycles).\n")
+    print("| kernel | dispatches | MFMA busy cycles (avg) | CU busy cycles (avg) | MFMA utilisation |\n|---|---:|---:|---:|---:|")
+    for k in names[:14]:
+        m, b = avg.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), 0.0), avg.get((k, "SQ_BUSY_CU_CYCLES"), 0.0)
+        if b > 0:
+            name = k if len(k) < 110 else k[:107] + "..."
+            print(f"| `{name}` | {agg[(k, 'SQ_BUSY_CU_CYCLES')][0]} | {m:,.0f} | {b:,.0f} | {m / (4 * b):.3f} |")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "mfma":
+        mfma(sys.argv[1])
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3])
         sys.exit(0)
