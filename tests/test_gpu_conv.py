@@ -521,3 +521,41 @@ def test_pointwise_conv_gradients(cin, cout, dtype):
     assert rel_max_err(conv.weight.grad[0], wq.grad) < tol
     assert rel_max_err(conv.bias.grad, br.grad) < tol
     assert conv.weight.grad.dtype == torch.float32 and conv.weight.grad.shape == (1, cin, cout)
+
+
+def test_config4_batch_of_lidar_scale_scenes():
+    """BASELINE config 4 shape per GPU: 8 scenes x ~35 k voxels with anisotropic extent (wide in x / y, shallow in z) in one
+    batch - kernel map bit-exact (no pair crosses scenes), SparseConv3d forward / backward vs the oracle."""
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    rng = np.random.default_rng(44)
+    parts = []
+    for b in range(8):
+        n = int(rng.integers(30000, 40000))
+        c = np.stack([rng.integers(0, 400, size=2 * n), rng.integers(0, 400, size=2 * n), rng.integers(0, 12, size=2 * n)], 1)
+        _, first = np.unique(c, axis=0, return_index=True)
+        parts.append(c[np.sort(first)][:n].astype(np.int32))
+    feats = [torch.randn(len(p), 32) for p in parts]
+    vox = Voxels([torch.from_numpy(p) for p in parts], feats, device=dev)
+    torch.manual_seed(4)
+    conv = SparseConv3d(32, 64, 3).to(dev)
+    x = vox.replace(batched_features=vox.feature_tensor.detach().clone().requires_grad_(True))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(x)
+    g = torch.randn_like(y.feature_tensor)
+    y.feature_tensor.backward(g)
+    bc = vox.batch_indexed_coordinates.cpu().numpy().astype(np.int32)
+    r = okmap.kernel_map(bc, bc, (3, 3, 3))
+    km = next(iter(x.cache.values()))
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+    np.testing.assert_array_equal(km.out_maps.cpu().numpy(), r["out_maps"])
+    assert (bc[r["in_maps"], 0] == bc[r["out_maps"], 0]).all()  # every pair stays inside its scene
+    X = vox.feature_tensor.detach().to(torch.bfloat16).double().cpu()
+    Wd = conv.weight.detach().to(torch.bfloat16).double().cpu()
+    Yr = oconv.forward(X, Wd, r["in_maps"], r["out_maps"], r["offsets"], len(bc)) + conv.bias.detach().double().cpu()
+    assert rel_max_err(y.feature_tensor.detach(), Yr) < 2e-2
+    dXr, dWr = oconv.backward(g.double().cpu(), X, Wd, r["in_maps"], r["out_maps"], r["offsets"])
+    assert rel_max_err(x.feature_tensor.grad, dXr) < 2e-2 and rel_max_err(conv.weight.grad, dWr) < 2e-2
+    assert y.offsets.tolist() == vox.offsets.tolist() and len(vox.offsets) == 9
