@@ -195,7 +195,17 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_handle(device: torch.device) -> int:
+    """hipStream_t of the current PyTorch stream on ``device``.  Every C-ABI call needs it (~900 per MinkUNet iteration):
+    the raw accessor skips building a ``torch.cuda.Stream`` object (≈ 6 us -> 0.3 us per call)."""
+    if _RAW_STREAM is not None:
+        idx = device.index
+        if idx is None:
+            idx = torch.cuda.current_device()
+        return _RAW_STREAM(idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 
