@@ -14,6 +14,7 @@ fused kernels write fp32 results and the product of the operand scales is multip
 Role of the reference's `_mask_gemm_forward_logic` / `_mask_gemm_backward_logic`
 (`warpconvnet/nn/functional/sparse_conv/detail/mask_gemm.py:661-745, 818-963`).
 """
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -33,6 +34,27 @@ def _prep(t: Tensor, name: str) -> Tensor:
 _FP16_RESCALE_TARGET = 32768.0
 
 
+@functools.lru_cache(maxsize=None)
+def _gather_ok(cin: int, cout: int, K: int, code: int) -> bool:
+    """`wcn_mfma_gather_supported`, memoised: a pure function of the shape (asked several times per layer and step)."""
+    return bool(_lib.lib().wcn_mfma_gather_supported(cin, cout, K, code))
+
+
+@functools.lru_cache(maxsize=None)
+def _wgrad_ok(cin: int, cout: int, code: int) -> bool:
+    return bool(_lib.lib().wcn_mfma_wgrad_supported(cin, cout, code))
+
+
+@functools.lru_cache(maxsize=None)
+def _wgrad_bias_ok(cin: int, cout: int, code: int) -> bool:
+    return bool(_lib.lib().wcn_mfma_wgrad_bias_supported(cin, cout, code))
+
+
+@functools.lru_cache(maxsize=None)
+def _wgrad_workspace(K: int, cin: int, cout: int, code: int) -> int:
+    return int(_lib.lib().wcn_conv_wgrad_workspace(K, cin, cout, code))
+
+
 def fp16_safe_cast(t: Tensor) -> Tuple[Tensor, Tensor]:
     """``(t_fp16, scale)`` with ``t == t_fp16 * scale`` exact in the exponent; scale = 2^max(0, ceil(log2(absmax / 32768)))
     as a 0-dim device tensor (restates the reference's `_fp16_safe_cast`, mask_gemm.py:72-103)."""
@@ -47,12 +69,12 @@ def _fp32_via_fp16(algo: str, kin: int, kout: int, K: int, dtype: torch.dtype) -
     """fp32 features take the fp16-operand fused kernels when the algorithm allows and the shape is covered."""
     if dtype != torch.float32 or algo == "hip_ref":
         return False
-    return bool(_lib.lib().wcn_mfma_gather_supported(kin, kout, K, _lib.WCN_F16))
+    return _gather_ok(kin, kout, K, _lib.WCN_F16)
 
 
 def resolve_gather_algo(algo: str, cin: int, cout: int, K: int, dtype: torch.dtype) -> int:
     L = _lib.lib()
-    ok = bool(L.wcn_mfma_gather_supported(cin, cout, K, _lib.dtype_code(dtype)))
+    ok = _gather_ok(cin, cout, K, _lib.dtype_code(dtype))
     if algo == "hip_ref":
         return _lib.WCN_ALGO_REF
     if algo == "hip_mfma":
@@ -64,7 +86,7 @@ def resolve_gather_algo(algo: str, cin: int, cout: int, K: int, dtype: torch.dty
 
 def resolve_wgrad_algo(algo: str, cin: int, cout: int, dtype: torch.dtype) -> int:
     L = _lib.lib()
-    ok = bool(L.wcn_mfma_wgrad_supported(cin, cout, _lib.dtype_code(dtype)))
+    ok = _wgrad_ok(cin, cout, _lib.dtype_code(dtype))
     if algo == "hip_ref":
         return _lib.WCN_ALGO_REF
     if algo == "hip_mfma":
@@ -105,7 +127,7 @@ def master_weight_ok(x_dtype: torch.dtype, weight: Tensor, algo: str, transposed
         return False
     K, cin, cout = weight.shape
     kin, kout = (cout, cin) if transposed else (cin, cout)
-    return bool(_lib.lib().wcn_mfma_gather_supported(kin, kout, K, _lib.dtype_code(x_dtype)))
+    return _gather_ok(kin, kout, K, _lib.dtype_code(x_dtype))
 
 
 def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: Optional[Tensor], n_out: int,
@@ -218,7 +240,7 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
     dev = x.device
     kernel_map.poll()
     scale = None
-    if x.dtype == torch.float32 and algo != "hip_ref" and bool(_lib.lib().wcn_mfma_wgrad_supported(cin, cout, _lib.WCN_F16)):
+    if x.dtype == torch.float32 and algo != "hip_ref" and _wgrad_ok(cin, cout, _lib.WCN_F16):
         x, sx = fp16_safe_cast(x)      # fp16 operands, fp32 accumulate and output; scales multiplied back below
         dy, sg = fp16_safe_cast(dy)
         scale = sx * sg
@@ -227,12 +249,12 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
         kernel_map._offsets_dev = kernel_map.offsets.to(device=dev, dtype=torch.int32)
     L = _lib.lib()
     code = resolve_wgrad_algo(algo, cin, cout, x.dtype)
-    ws_bytes = L.wcn_conv_wgrad_workspace(K, cin, cout, code)
+    ws_bytes = _wgrad_workspace(K, cin, cout, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     # (not for fp32 features routed through fp16 operands: the bias gradient then stays an exact fp32 column sum)
     fuse = (want_bias_grad and scale is None and code == _lib.WCN_ALGO_MFMA and getattr(kernel_map, "_self_exact", False)
             and x.shape[0] == dy.shape[0] and dy.shape[0] > 0
-            and bool(L.wcn_mfma_wgrad_bias_supported(cin, cout, _lib.dtype_code(x.dtype))))
+            and _wgrad_bias_ok(cin, cout, _lib.dtype_code(x.dtype)))
     if fuse:
         db = torch.empty(cout, dtype=torch.float32, device=dev)
         _lib.check(
