@@ -35,3 +35,33 @@ def unique_hashmap(bcoords: Tensor, **kwargs) -> Tuple[Tensor, "PackedHashTable"
         bcoords = torch.nn.functional.pad(bcoords, (0, 1), value=0)
     table = PackedHashTable.from_coords(bcoords, device=bcoords.device)
     return table.unique_index, table
+
+
+@torch.no_grad()
+def unique_first_indices_with_offsets(bcoords: Tensor) -> Tuple[Tensor, Tensor]:
+    """GPU: ``(ascending int64 rows of the first occurrence of every distinct [b, x, y, z] row, CPU int32 offsets [B+1] of
+    the surviving rows per batch index)`` with ONE host read.
+
+    The generic route (`unique_hashmap` -> `PackedHashTable.insert` -> `unique_index` -> `offsets_from_batch_index`) reads
+    the status word, the number of survivors and the per-batch counts back separately - three queue-draining waits per
+    strided convolution; here the status word and a 512-bin per-batch histogram of the survivors travel together and the
+    index list is compacted with a known size (`nonzero_static`)."""
+    from warpconvnet_amd.geometry.coords.search.packed_hashmap import PackedHashTable
+
+    assert bcoords.is_cuda and bcoords.ndim == 2 and bcoords.shape[1] == 4
+    coords = bcoords.contiguous().to(torch.int32)
+    n, dev = coords.shape[0], coords.device
+    table = PackedHashTable(max(16, 2 * n), device=dev)
+    meta = torch.zeros(1 + PackedHashTable.BATCH_MAX + 1, dtype=torch.int32, device=dev)  # [status, counts[512]]
+    table._launch_insert(coords, meta[:1])
+    first = table.search(coords) == torch.arange(n, dtype=torch.int32, device=dev)
+    b = coords[:, 0].long().clamp_(0, PackedHashTable.BATCH_MAX)  # out-of-range batch ids are reported through the status
+    meta[1:].index_add_(0, b, first.to(torch.int32))
+    host = meta.cpu()  # the one host read
+    PackedHashTable.raise_for_flags(int(host[0]), n, table.capacity)
+    counts = host[1:]
+    nz = torch.nonzero(counts)
+    num_batches = int(nz[-1]) + 1 if len(nz) else 0
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), counts[:num_batches].to(torch.int64).cumsum(0)]).to(torch.int32)
+    idx = torch.nonzero_static(first, size=int(offsets[-1])).squeeze(1)
+    return idx, offsets
