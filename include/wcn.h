@@ -48,8 +48,10 @@ enum wcn_kmap_flag {
   WCN_FLAG_COORD_RANGE = 2,     /* batch not in [0,511] or coord not in [-131072,131071]
                                    (reference packed_hashmap.py:66-82 raises ValueError)            */
   WCN_FLAG_PAIR_OVERFLOW = 4,   /* in_maps/out_maps capacity smaller than the number of pairs       */
-  WCN_FLAG_DUPLICATE_COORD = 8  /* informational: the inserted coordinates are not all distinct (the smallest row wins,
+  WCN_FLAG_DUPLICATE_COORD = 8, /* informational: the inserted coordinates are not all distinct (the smallest row wins,
                                    so the centre neighbour of a later duplicate is not the row itself)          */
+  WCN_FLAG_NEED_STRICT = 16     /* binned builder, strict = 0: a duplicate coordinate kept a row that is not the smallest
+                                   one - the tables are NOT valid, rebuild with strict = 1                         */
 };
 
 /* ---- misc ------------------------------------------------------------------------------------ */
@@ -85,9 +87,10 @@ int wcn_hash_search(const void* slots, int64_t capacity, const int32_t* queries,
  */
 int32_t wcn_kmap_row_pitch(int32_t num_offsets);
 int32_t wcn_kmap_mask_words(int32_t num_offsets);
-/* number of 64-row count blocks for m query rows, rounded up to a multiple of 4 (rows of the counts array stay 16-B
- * aligned); the counts buffer holds K * (num_blocks + 1) int32 */
+/* number of 256-row bucket tiles for m query rows, rounded up to a multiple of 4 (rows of the counts array stay 16-B
+ * aligned); the counts buffer holds wcn_kmap_counts_bytes(m, K) bytes: K rows of tile counts, K totals, a ticket word */
 int64_t wcn_kmap_num_blocks(int64_t m);
+size_t wcn_kmap_counts_bytes(int64_t m, int32_t num_offsets);
 
 /* reference: _C.cuhash.packed_kernel_map_size + packed_kernel_map_offset (cuhash_kernel_map.cu:68-134)
  * fused with build_pair_mask (mask_data_kernels.cu:23-44).
@@ -113,22 +116,45 @@ int wcn_morton_code(const int32_t* coords, int64_t n, int32_t num_dims, const in
                     int64_t* codes, wcn_stream_t stream);
 
 /* LDS-binned neighbour search for SUBMANIFOLD maps (query coords == input coords, stride 1): replaces
- * wcn_hash_insert + wcn_kmap_probe.  Voxels are binned into 16^3 blocks through a block-level hash table
- * (`slots`, capacity >= 2n, power of two; prepared by the call), then every block and its halo are staged in an
- * LDS grid and all K probes are answered from LDS.  Same outputs as the hash path (bit-exact), incl. the
- * range flags in *status (the status word is CLEARED by this call, it need not be zeroed beforehand).  Returns WCN_ERROR_PROBLEM_NOT_SUPPORTED when the kernel halo exceeds 4 cells
+ * wcn_hash_insert + wcn_kmap_probe.  The hash table is BLOCK-level: voxels are binned into 8^3 blocks, every occupied
+ * block owns a dense 512-cell sub-grid of row ids (one plain 4-B store per voxel), and one wavefront per block stages
+ * its sub-grid and the halo of the 26 neighbouring sub-grids in an LDS grid and answers all K probes from LDS.  Same
+ * outputs as the hash path (bit-exact), incl. the range flags in *status (the status word is CLEARED by this call).
+ *   max_blocks  capacity of the block table (occupied 8^3 blocks); more blocks -> WCN_FLAG_TABLE_FULL, tables invalid,
+ *               the caller retries with max_blocks = n (always enough) - workspace = wcn_kmap_binned_workspace(n, max_blocks)
+ *   strict      0: cells are written with plain stores; rows of duplicate coordinates are repaired by
+ *               wcn_kmap_tally_sort, which raises WCN_FLAG_NEED_STRICT when a cell did not keep the smallest row
+ *               (the caller then rebuilds with strict = 1: atomicMin, ~2.5x the store cost)
+ *   mask        rows that no block has enumerated yet (duplicates) carry 0x80000000 in their LAST mask word until
+ *               wcn_kmap_tally_sort repairs them, which is why K % 32 == 0 is not supported here
+ * Returns WCN_ERROR_PROBLEM_NOT_SUPPORTED when the kernel halo exceeds 4 cells or K % 32 == 0
  * (wcn_kmap_binned_supported == 0): the caller then uses the hash path.
  * reference being replaced: cuhash_hash_table.cu:179-220 + cuhash_kernel_map.cu:93-134. */
-size_t wcn_kmap_binned_workspace(int64_t n);
+size_t wcn_kmap_binned_workspace(int64_t n, int64_t max_blocks);
 int wcn_kmap_binned_supported(const int32_t ksize[3], const int32_t dilation[3]);
 int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[3], const int32_t dilation[3],
-                          void* slots, int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* nbr,
+                          int64_t max_blocks, int32_t strict, void* workspace, size_t workspace_bytes, int32_t* nbr,
                           uint32_t* mask, int32_t* status, wcn_stream_t stream);
-/* counts[k][b] = pairs of offset k in the 64-row block b (k-major, from the masks).
+/* Everything between the neighbour table and the ONE host read of a build, three + (3 per further sort digit) launches:
+ *   tally  per-(offset, tile) pair counts from the masks, the first digit histogram of the mask sort, and - when
+ *          `binned_workspace` (the workspace of the wcn_kmap_build_binned call that produced nbr / mask, with its n and
+ *          max_blocks) is given - repair of the rows of duplicate coordinates
+ *   scan   offsets int32 [K+1] on the device and, if `host_mirror` (K + 2 int32 of pinned, device-accessible HOST
+ *          memory) is given, offsets ++ [*status] there in the same launch
+ *   sort   perm = rows by descending mask (wcn_mask_argsort), the first digit already counted
+ * counts: wcn_kmap_counts_bytes(m, K) bytes, consumed by wcn_kmap_scatter.  sort_workspace:
+ * wcn_kmap_tally_sort_workspace(m) bytes.  reference: postprocess_count + torch.cumsum + mask_argsort
+ * (cuhash_kernel_map.cu:508-544, torch_discrete.py:268-272, mask_data_kernels.cu:187-220). */
+size_t wcn_kmap_tally_sort_workspace(int64_t m);
+int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* counts, int32_t* offsets,
+                        int32_t* status, int32_t* host_mirror, int32_t* perm, void* sort_workspace,
+                        size_t sort_workspace_bytes, const int32_t* coords, void* binned_workspace, int64_t binned_n,
+                        int64_t max_blocks, wcn_stream_t stream);
+/* counts[k][b] = pairs of offset k in the 256-row tile b (k-major, from the masks); counts = wcn_kmap_counts_bytes bytes.
  * reference: _C.cuhash.postprocess_count (cuhash_kernel_map.cu:508-544). */
 int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream);
-/* exclusive scan of counts over blocks (in place, one workgroup per offset) and over offsets ->
- * offsets int32 [K+1].  counts must hold K * (num_blocks + 1) int32 (the tail receives the bucket totals).
+/* exclusive scan of counts over tiles (in place, one workgroup per offset) and over offsets ->
+ * offsets int32 [K+1].  `counts` as left by wcn_kmap_count (the tail receives the bucket totals).
  * reference: host torch.cumsum in torch_discrete.py:268-272. */
 int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
                   wcn_stream_t stream);

@@ -34,7 +34,8 @@ def test_pure_host_entry_points(hip_lib):
     assert _lib.status_string(-5) == "Invalid parameters" and _lib.status_string(-99) == "Unknown error"
     assert L.wcn_kmap_row_pitch(27) == 32 and L.wcn_kmap_row_pitch(8) == 8 and L.wcn_kmap_row_pitch(125) == 128
     assert L.wcn_kmap_mask_words(27) == 1 and L.wcn_kmap_mask_words(33) == 2
-    assert L.wcn_kmap_num_blocks(1000) == 16
+    assert L.wcn_kmap_num_blocks(1000) == 4 and L.wcn_kmap_num_blocks(1025) == 8
+    assert L.wcn_kmap_counts_bytes(1000, 27) >= (27 * 5 + 1) * 4
     assert L.wcn_mfma_gather_supported(64, 128, 27, _lib.WCN_BF16) == 1
     assert L.wcn_mfma_gather_supported(64, 128, 27, _lib.WCN_F32) == 0
     assert L.wcn_mfma_gather_supported(7, 13, 27, _lib.WCN_BF16) == 0
@@ -47,7 +48,9 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_kmap_binned_supported(_lib.i3((3, 3, 3)), _lib.i3((8, 8, 8))) == 0
     assert L.wcn_packed_weight_bytes(27, 64, 128, _lib.WCN_BF16, 0) == 27 * 64 * 128 * 2
     assert L.wcn_conv_wgrad_workspace(27, 64, 128, _lib.WCN_ALGO_MFMA) > 27 * 64 * 128 * 4
-    assert L.wcn_mask_argsort_workspace(1000) > 3 * 4000 and L.wcn_kmap_binned_workspace(1000) > 36 * 1000
+    assert L.wcn_mask_argsort_workspace(1000) > 3 * 4000 and L.wcn_kmap_binned_workspace(1000, 250) > 250 * 2048
+    assert L.wcn_kmap_binned_supported(_lib.i3((4, 4, 2)), _lib.i3((1, 1, 1))) == 0  # K % 32 == 0: hash path
+    assert L.wcn_kmap_tally_sort_workspace(1000) >= L.wcn_mask_argsort_workspace(1000)
     # parameter validation happens before any launch: bad arguments come back as status codes
     assert L.wcn_hash_prepare(None, 16, None) == -5
     assert L.wcn_hash_prepare(None, 17, None) == -5

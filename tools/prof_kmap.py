@@ -1,3 +1,4 @@
+"""Dev tool: per-wave phase times of cell_neighbors (needs kmap_binned.hip built with -DWCN_PROF)."""
 import ctypes, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -8,20 +9,18 @@ dev = torch.device("cuda:0")
 N = 1_000_000
 c = torch.from_numpy(scene_u(N, seed=1000)).to(dev)
 c = torch.cat([torch.zeros(len(c), 1, dtype=c.dtype, device=dev), c], 1).int().contiguous()
-lib = L.lib()
+lib = L.lib()._h if hasattr(L.lib(), "_h") else L.lib()
 lib.wcn_debug_read_bprof.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 for _ in range(3):
     km = generate_kernel_map(c, c, (1, 1, 1), (3, 3, 3))
 torch.cuda.synchronize()
 buf = np.zeros((4096, 8), dtype=np.uint64)
 assert lib.wcn_debug_read_bprof(buf.ctypes.data, buf.nbytes) == 0
-p = buf[buf[:, 3] > 0].astype(np.int64)
+p = buf[buf[:, 3] > 0].astype(np.int64)  # stamps of the LAST block every wave processed
 t0 = p[:, 0].min()
-print("WGs with work", len(p), "span us", (p[:, 3].max() - t0) / 100.0)
-for a, b, nm in ((0, 1, "bin lookup + grid clear"), (1, 2, "grid fill"), (2, 3, "probe")):
+print("waves sampled", len(p), "last-block span us", (p[:, 3].max() - t0) / 100.0)
+for a, b, nm in ((0, 1, "halo gather"), (1, 2, "own cells + enumerate + prefetch"), (2, 3, "probe")):
     d = (p[:, b] - p[:, a]) / 100.0
-    print(f"  {nm:26s} mean {d.mean():6.2f} p50 {np.median(d):6.2f} p95 {np.percentile(d,95):6.2f}")
+    print(f"  {nm:34s} mean {d.mean():6.2f} p50 {np.median(d):6.2f} p95 {np.percentile(d,95):6.2f}")
 life = (p[:, 3] - p[:, 0]) / 100.0
-print("  life mean", life.mean(), "concurrency", life.sum() / ((p[:, 3].max() - t0) / 100.0), "own_cnt mean", p[:, 4].mean(), "max", p[:, 4].max())
-st = (p[:, 0] - t0) / 100.0
-print("  start-time percentiles", np.percentile(st, [10, 50, 90, 99]))
+print("  block life mean", life.mean(), "own_cnt mean", p[:, 4].mean(), "max", p[:, 4].max())

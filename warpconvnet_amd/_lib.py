@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_CSRC, "libwcn_hip.so")
 WCN_F32, WCN_F16, WCN_BF16 = 0, 1, 2
 WCN_ALGO_AUTO, WCN_ALGO_REF, WCN_ALGO_MFMA = 0, 1, 2
 WCN_FLAG_TABLE_FULL, WCN_FLAG_COORD_RANGE, WCN_FLAG_PAIR_OVERFLOW, WCN_FLAG_DUPLICATE_COORD = 1, 2, 4, 8
+WCN_FLAG_NEED_STRICT = 16
 
 _I32P = c_void_p  # all pointers travel as void*
 _3I = c_int32 * 3
@@ -54,11 +55,18 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "wcn_pool_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "wcn_morton_code": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "wcn_kmap_binned_workspace": (c_size_t, [c_int64]),
+    "wcn_kmap_counts_bytes": (c_size_t, [c_int64, c_int32]),
+    "wcn_kmap_binned_workspace": (c_size_t, [c_int64, c_int64]),
     "wcn_kmap_binned_supported": (c_int, [_3I, _3I]),
     "wcn_kmap_build_binned": (
         c_int,
-        [c_void_p, c_int64, _3I, _3I, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+        [c_void_p, c_int64, _3I, _3I, c_int64, c_int32, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "wcn_kmap_tally_sort_workspace": (c_size_t, [c_int64]),
+    "wcn_kmap_tally_sort": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+         c_void_p, c_void_p, c_int64, c_int64, c_void_p],
     ),
     "wcn_kmap_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

@@ -4,8 +4,7 @@
 //   probe       : one LANE per (output row, kernel offset); a 32-lane group covers one row so the
 //                 neighbour row is written as one contiguous 128-B line and the row's neighbour mask
 //                 is a single wave ballot
-//   bucketing   : per-block counts -> scan -> ballot/popcount ranking => pairs of each offset come
-//                 out ordered by output row (deterministic, no atomics on the output cursor)
+//   bucketing   : kmap_bucket.hip
 //
 // Reference behaviour being replaced (semantics only, nothing copied):
 //   warpconvnet/csrc/cuhash_hash_table.cu:19-262, cuhash_kernel_map.cu:68-134, 508-599,
@@ -15,7 +14,6 @@
 namespace wcn {
 
 constexpr int kBlockRows = 256;  // rows per probe workgroup
-constexpr int kCountRows = 64;   // rows per count block (= one wavefront of the count / scatter kernels)
 constexpr int kThreads = 256;
 
 // ------------------------------------------------------------------------------------------------
@@ -111,173 +109,6 @@ __global__ __launch_bounds__(kThreads) void kmap_probe_kernel(const Slot* __rest
       }
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// count: counts[k][wb] = number of rows of 64-row block wb that have offset k   (k-major for the scan)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void kmap_count_kernel(const uint32_t* __restrict__ mask, int64_t m, int K,
-                                                              int mw, int64_t nwb, int32_t* __restrict__ counts) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wb = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  if (wb >= nwb) return;
-  const int64_t row = wb * kCountRows + lane;
-  for (int w = 0; w < mw; ++w) {
-    const uint32_t bits = row < m ? mask[row * mw + w] : 0u;
-    const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;
-    int mine = 0;
-    for (int b = 0; b < kend; ++b) {
-      const int c = __popcll(__ballot((bits >> b) & 1u));
-      if (lane == b) mine = c;
-    }
-    if (lane < kend) counts[(int64_t)(w * 32 + lane) * nwb + wb] = mine;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// scan: one workgroup per offset k scans counts[k][0..nwb) in place (exclusive); totals[k] = bucket size.
-// A second single-wave kernel turns the totals into offsets[K+1].
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void kmap_scan_kernel(int32_t* __restrict__ counts, int64_t nwb, int K,
-                                                         int32_t* __restrict__ totals) {
-  // one workgroup per offset; kPer consecutive counts per thread and trip (the wave still reads one contiguous span),
-  // wave scan of the thread sums by shuffles, wave totals combined through LDS, running carry in a register
-  constexpr int kPer = 16;  // 16 K counts per trip: the 15 625 blocks of a 1 M-row map are one trip (one memory round trip)
-  __shared__ int s_wave[16];
-  int32_t* c = counts + (int64_t)blockIdx.x * nwb;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int carry = 0;
-  for (int64_t base = 0; base < nwb; base += 1024 * kPer) {
-    const int64_t i0 = base + (int64_t)tid * kPer;
-    int v[kPer];
-    int sum = 0;
-    // 16-B pieces per lane (nwb is a multiple of 4, rows are 16-B aligned): a lane-strided 4-B access costs one
-    // texture-addresser slot per lane and element - 16 of them made this kernel 16 us instead of 6
-#pragma unroll
-    for (int j = 0; j < kPer; j += 4) {
-      int4 t = make_int4(0, 0, 0, 0);
-      if (i0 + j < nwb) t = *reinterpret_cast<const int4*>(c + i0 + j);
-      v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
-      sum += t.x + t.y + t.z + t.w;
-    }
-    int incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int wave_base = 0, trip_total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const int t = s_wave[w];
-      if (w < wave) wave_base += t;
-      trip_total += t;
-    }
-    int run = carry + wave_base + incl - sum;  // exclusive prefix of this thread's first element
-#pragma unroll
-    for (int j = 0; j < kPer; j += 4) {
-      int4 t;
-      t.x = run; run += v[j];
-      t.y = run; run += v[j + 1];
-      t.z = run; run += v[j + 2];
-      t.w = run; run += v[j + 3];
-      if (i0 + j < nwb) *reinterpret_cast<int4*>(c + i0 + j) = t;
-    }
-    carry += trip_total;
-    __syncthreads();  // s_wave is rewritten by the next trip
-  }
-  if (tid == 0) totals[blockIdx.x] = carry;
-}
-// `mirror` (may be null): device-accessible pinned HOST buffer [K+2] that receives the offsets and the status word in the
-// same kernel - the host waits for an event behind this launch instead of queueing a separate D2H copy (a ~4 us copy
-// command plus the engine switch around it, on a pipeline of ~5 us kernels)
-__global__ void kmap_offsets_kernel(const int32_t* __restrict__ totals, int K, int32_t* __restrict__ offsets,
-                                    const int32_t* __restrict__ status, int32_t* __restrict__ mirror) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int acc = 0;
-    offsets[0] = 0;
-    if (mirror) mirror[0] = 0;
-    for (int k = 0; k < K; ++k) {
-      acc += totals[k];
-      offsets[k + 1] = acc;
-      if (mirror) mirror[k + 1] = acc;
-    }
-    if (mirror) mirror[K + 1] = status ? *status : 0;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// scatter: deterministic compaction.  One thread per output row, one wavefront per 64-row count block; the row's
-// mask says which offsets exist, so only present pairs touch the neighbour table.  Rank of a pair inside its
-// bucket = offsets[k] + scanned count of the block + popcount(ballot & lower lanes): no atomics, order = output row.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void kmap_scatter_kernel(const int32_t* __restrict__ nbr,
-                                                                const uint32_t* __restrict__ mask, int64_t m, int K,
-                                                                int kp, int mw, int64_t nwb,
-                                                                const int32_t* __restrict__ counts,
-                                                                const int32_t* __restrict__ offsets,
-                                                                int32_t* __restrict__ in_maps,
-                                                                int32_t* __restrict__ out_maps, int64_t pair_capacity,
-                                                                int32_t* __restrict__ status) {
-  // Per wave: 64 rows.  The rows' neighbour entries are copied into LDS with whole-row (coalesced) 16-B loads first:
-  // reading nbr[row][k] per lane inside the offset loop costs one L1 lookup per lane and offset (~1 lane per clock
-  // per CU), which made this kernel 2x slower than its HBM traffic.  [4 waves][64 rows][32 ints], 16-B chunks
-  // XOR-swizzled by row so the per-lane column reads spread over the banks.
-  __shared__ __attribute__((aligned(16))) int32_t s_tile[(kThreads / 64) * 64 * 32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t wb = (int64_t)blockIdx.x * (kThreads / 64) + wave;
-  if (wb >= nwb) return;
-  const int64_t row0 = wb * kCountRows;
-  const int64_t row = row0 + lane;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  int32_t* tile = s_tile + wave * 64 * 32;
-  bool overflow = false;
-  for (int w = 0; w < mw; ++w) {
-    const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;      // offsets in this mask word
-    const int cols4 = ((kp - w * 32) < 32 ? (kp - w * 32) : 32) >> 2;  // 16-B chunks per row in this word
-    // cols4 (<= 8) 16-B pieces per lane, all requested before the first one is stored: a predicated load inside the loop
-    // is waited for before the next one is issued (8 memory round trips per wave instead of 1)
-    int4 piece[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = lane + 64 * j;
-      const int r = e / cols4, c = e - r * cols4;
-      const int64_t rr = row0 + r < m ? row0 + r : m - 1;  // clamped: always a valid address
-      if (j < cols4) piece[j] = *reinterpret_cast<const int4*>(nbr + rr * kp + w * 32 + c * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = lane + 64 * j;
-      const int r = e / cols4, c = e - r * cols4;
-      if (j < cols4)
-        *reinterpret_cast<int4*>(tile + r * 32 + ((c ^ (r & 7)) << 2)) = row0 + r < m ? piece[j] : make_int4(-1, -1, -1, -1);
-    }
-    // bucket write positions of this wave for the word's offsets: lane b holds the base of offset w*32+b
-    int64_t base = 0;
-    if (lane < kend) base = (int64_t)offsets[w * 32 + lane] + counts[(int64_t)(w * 32 + lane) * nwb + wb];
-    const uint32_t bits = row < m ? mask[row * mw + w] : 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile is wave-private; LDS ops of a wave execute in order
-    for (int b = 0; b < kend; ++b) {
-      const bool v = (bits >> b) & 1u;
-      const unsigned long long ball = __ballot(v);
-      if (ball == 0ull) continue;  // wave-uniform
-      const int32_t lo = __builtin_amdgcn_readlane((int32_t)base, b);
-      const int32_t hi = __builtin_amdgcn_readlane((int32_t)(base >> 32), b);
-      if (v) {
-        const int64_t pos = (((int64_t)hi << 32) | (uint32_t)lo) + __popcll(ball & lt);
-        if (pos < pair_capacity) {
-          in_maps[pos] = tile[lane * 32 + (((b >> 2) ^ (lane & 7)) << 2) + (b & 3)];
-          out_maps[pos] = (int32_t)row;
-        } else {
-          overflow = true;
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // next word overwrites the tile
-  }
-  if (overflow) atomicOr(status, (int)WCN_FLAG_PAIR_OVERFLOW);
 }
 
 // [n, d] int32 coordinates + batch offsets -> [n, d+1] with the batch index in column 0 (one launch instead of
@@ -443,9 +274,6 @@ int wcn_hash_search(const void* slots, int64_t capacity, const int32_t* queries,
 
 int32_t wcn_kmap_row_pitch(int32_t num_offsets) { return (num_offsets + 7) & ~7; }
 int32_t wcn_kmap_mask_words(int32_t num_offsets) { return (num_offsets + 31) / 32; }
-// rounded up to a multiple of 4 so that every offset's row of the counts array is 16-B aligned (vector access in the scan)
-int64_t wcn_kmap_num_blocks(int64_t m) { return (ceil_div(m, kCountRows) + 3) & ~(int64_t)3; }
-
 int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, int64_t m, const int32_t ksize[3],
                    const int32_t stride[3], const int32_t dilation[3], int32_t* nbr, uint32_t* mask,
                    wcn_stream_t stream) {
@@ -484,56 +312,6 @@ int wcn_kmap_probe(const void* slots, int64_t capacity, const int32_t* query, in
                          K, kp, mw, nbr, mask);
       break;
   }
-  return launch_status();
-}
-
-int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream) {
-  if (m < 0 || num_offsets < 1 || num_offsets > 4096) return WCN_ERROR_INVALID_PARAMETERS;
-  if (m == 0) return WCN_SUCCESS;
-  if (!mask || !counts) return WCN_ERROR_INVALID_PARAMETERS;
-  const int64_t nwb = wcn_kmap_num_blocks(m);
-  hipLaunchKernelGGL(kmap_count_kernel, dim3((unsigned)ceil_div(nwb, kThreads / 64)), dim3(kThreads), 0,
-                     (hipStream_t)stream, mask, m, (int)num_offsets, wcn_kmap_mask_words(num_offsets), nwb, counts);
-  return launch_status();
-}
-
-static int kmap_scan_impl(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
-                          const int32_t* status, int32_t* mirror, wcn_stream_t stream);
-
-int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, wcn_stream_t stream) {
-  return kmap_scan_impl(counts, num_blocks, num_offsets, offsets, nullptr, nullptr, stream);
-}
-
-int wcn_kmap_scan_to_host(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, const int32_t* status,
-                          int32_t* host_mirror, wcn_stream_t stream) {
-  if (!host_mirror) return WCN_ERROR_INVALID_PARAMETERS;
-  return kmap_scan_impl(counts, num_blocks, num_offsets, offsets, status, host_mirror, stream);
-}
-
-static int kmap_scan_impl(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
-                          const int32_t* status, int32_t* mirror, wcn_stream_t stream) {
-  if (num_blocks < 0 || num_offsets < 1 || num_offsets > 4096 || !offsets || !counts) return WCN_ERROR_INVALID_PARAMETERS;
-  // totals live in the last K ints of the counts buffer (the caller allocates K * (num_blocks + 1) ints)
-  int32_t* totals = counts + (int64_t)num_offsets * num_blocks;
-  hipLaunchKernelGGL(kmap_scan_kernel, dim3((unsigned)num_offsets), dim3(1024), 0, (hipStream_t)stream, counts,
-                     num_blocks, (int)num_offsets, totals);
-  hipLaunchKernelGGL(kmap_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int32_t*)totals,
-                     (int)num_offsets, offsets, status, mirror);
-  return launch_status();
-}
-
-int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets, const int32_t* counts,
-                     const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status,
-                     wcn_stream_t stream) {
-  if (m < 0 || num_offsets < 1 || num_offsets > 4096 || pair_capacity < 0 || !status) return WCN_ERROR_INVALID_PARAMETERS;
-  if (m == 0) return WCN_SUCCESS;
-  if (!nbr || !mask || !counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps)))
-    return WCN_ERROR_INVALID_PARAMETERS;
-  const int K = num_offsets, kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
-  const int64_t nwb = wcn_kmap_num_blocks(m);
-  hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(nwb, kThreads / 64)), dim3(kThreads), 0,
-                     (hipStream_t)stream, nbr, mask, m, K, kp, mw, nwb, counts, offsets, in_maps, out_maps, pair_capacity,
-                     status);
   return launch_status();
 }
 

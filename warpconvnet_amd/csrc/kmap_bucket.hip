@@ -1,0 +1,481 @@
+// kmap_bucket.hip - per-offset bucketing of a neighbour table: the CSR pair lists (in_maps / out_maps / offsets) the
+// weight-gradient kernel and the reference API consume, in DETERMINISTIC order (every bucket ordered by output row,
+// no atomics on cursors).
+//
+//   tally    one pass over the masks: per-(offset, 256-row tile) pair counts from wave ballots, the first digit's
+//            histogram of the mask sort (it reads the same words), and - on the binned path - repair of the rows of
+//            duplicate coordinates (rows no block enumerated copy their winner's table row)
+//   scan     one workgroup per offset (exclusive scan over tiles) and per sort digit, ONE launch; the workgroup that
+//            finishes last turns the totals into offsets[K+1] and mirrors them + the status word to pinned host memory
+//   scatter  one workgroup per tile: neighbour rows through LDS with whole-row loads, pairs ranked by ballot +
+//            popcount, STAGED in LDS bucket by bucket and written out as contiguous runs (a 64-row wave storing its ~10
+//            pairs per bucket directly is one partial-line write request per bucket, wave and array)
+//
+// Reference behaviour replaced: warpconvnet/csrc/cuhash_kernel_map.cu:508-599 (postprocess_count / postprocess_scatter
+// with atomic cursors), mask_data_kernels.cu:23-124.
+#include "kmap_cells.h"
+#include "mask_sort.h"
+
+namespace wcn {
+
+constexpr int kTileRows = 256;  // rows per bucket tile = 4 waves x 64
+constexpr int kBkThreads = 256;
+constexpr int kTallyThreads = (kRsTile / kTileRows) * 64;  // one wave per tile, one workgroup per sort tile
+constexpr int kStageCap = 3072;  // pairs staged in LDS per (tile, mask word); denser tiles store directly
+
+static_assert(kRsTile % kTileRows == 0, "a sort tile is a whole number of bucket tiles");
+
+// rows of duplicate coordinates (binned path): copy the table row of the row the cell keeps
+__device__ __noinline__ void repair_row(int64_t row, const int4* __restrict__ coords, const CellTable& t, uint32_t cmask,
+                                        int kp, int mw, int32_t* __restrict__ nbr, uint32_t* __restrict__ mask,
+                                        int32_t* __restrict__ status) {
+  const int4 c = coords[row];
+  const int s = block_find(t.slots, cmask, pack_key(c.x, c.y >> kBlkShift, c.z >> kBlkShift, c.w >> kBlkShift));
+  int id = s >= 0 ? t.slots[s].id : -1;
+  if (id >= 0) id &= ~kIdLateBit;
+  int w = -1;
+  if (id >= 0) {
+    const int cell = ((c.y & (kBlk - 1)) * kBlk + (c.z & (kBlk - 1))) * kBlk + (c.w & (kBlk - 1));
+    w = t.cells[(int64_t)id * kCells + cell];
+  }
+  if (w >= 0 && w != row && !(mask[(int64_t)w * mw + (mw - 1)] & kMaskUnwritten)) {
+    atomicOr(status, (int)(WCN_FLAG_DUPLICATE_COORD | (w > row ? WCN_FLAG_NEED_STRICT : 0)));
+    for (int k = 0; k < kp; ++k) nbr[row * kp + k] = nbr[(int64_t)w * kp + k];
+    for (int q = 0; q < mw; ++q) mask[row * mw + q] = mask[(int64_t)w * mw + q];
+  } else {  // block table overflow (flagged by the builder): defined, empty content
+    for (int k = 0; k < kp; ++k) nbr[row * kp + k] = -1;
+    for (int q = 0; q < mw; ++q) mask[row * mw + q] = 0u;
+  }
+}
+
+// counts[k][tile] = rows of the 256-row tile that have offset k (k-major for the scan);  dcounts[digit][block] = first
+// digit histogram of the mask sort over the block's 2048 rows (HIST).
+template <bool HIST, bool REPAIR>
+__global__ __launch_bounds__(kTallyThreads) void kmap_tally_kernel(uint32_t* __restrict__ mask, int32_t* __restrict__ nbr,
+                                                                int64_t m, int K, int kp, int mw, int64_t ntile,
+                                                                int32_t* __restrict__ counts, int32_t* __restrict__ ticket,
+                                                                int nblk_sort, int32_t* __restrict__ dcounts,
+                                                                const int4* __restrict__ coords, CellTable t,
+                                                                uint32_t cmask, int32_t* __restrict__ status) {
+  __shared__ int s_hist[kRsBins];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (HIST) {
+    for (int i = tid; i < kRsBins; i += kTallyThreads) s_hist[i] = 0;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid == 0) *ticket = 0;  // consumed by the scan launch behind this one
+  constexpr int kTilesPerBlock = kRsTile / kTileRows;  // 8 = waves per workgroup
+  for (int tt = 0; tt < 1; ++tt) {
+    const int64_t tile = (int64_t)blockIdx.x * kTilesPerBlock + wave;
+    if (tile >= ntile) break;
+    const int64_t row0 = tile * kTileRows;
+    uint32_t last[kTileRows / 64];
+#pragma unroll
+    for (int sb = 0; sb < kTileRows / 64; ++sb) {  // the four 64-row groups of the tile: requested together
+      const int64_t row = row0 + sb * 64 + lane;
+      last[sb] = row < m ? mask[row * mw + (mw - 1)] : 0u;
+    }
+    if (REPAIR) {
+#pragma unroll
+      for (int sb = 0; sb < kTileRows / 64; ++sb) {
+        const int64_t row = row0 + sb * 64 + lane;
+        if (last[sb] & kMaskUnwritten) {
+          repair_row(row, coords, t, cmask, kp, mw, nbr, mask, status);
+          last[sb] = mask[row * mw + (mw - 1)];
+        }
+      }
+    }
+    for (int w = 0; w < mw; ++w) {
+      const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;
+      int mine = 0;
+#pragma unroll
+      for (int sb = 0; sb < kTileRows / 64; ++sb) {
+        const int64_t row = row0 + sb * 64 + lane;
+        const uint32_t bits = (w == mw - 1) ? last[sb] : (row < m ? mask[row * mw + w] : 0u);
+        if (HIST && w == 0 && row < m) atomicAdd(&s_hist[rs_digit(bits, 0)], 1);
+        for (int b = 0; b < kend; ++b) {
+          const int c = __popcll(__ballot((bits >> b) & 1u));
+          if (lane == b) mine += c;
+        }
+      }
+      if (lane < kend) counts[(int64_t)(w * 32 + lane) * ntile + tile] = mine;
+    }
+  }
+  if (HIST) {
+    __syncthreads();
+    if ((int)blockIdx.x < nblk_sort)
+      for (int i = tid; i < kRsBins; i += kTallyThreads) dcounts[(int64_t)i * nblk_sort + blockIdx.x] = s_hist[i];
+  }
+}
+
+// exclusive scan of one row of 32-bit counts by one 256-thread workgroup; returns the row total (all threads)
+__device__ __forceinline__ int scan_row_256(int32_t* __restrict__ c, int64_t n, int* s_wave) {
+  constexpr int kPer = 16;  // 4096 counts per trip: a 1 M-row map is one trip (one memory round trip)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int carry = 0;
+  for (int64_t base = 0; base < n; base += kBkThreads * kPer) {
+    const int64_t i0 = base + (int64_t)tid * kPer;
+    int v[kPer];
+    int sum = 0;
+    // 16-B pieces per lane (rows are 16-B aligned, n is a multiple of 4): a lane-strided 4-B access costs one
+    // texture-addresser slot per lane and element
+#pragma unroll
+    for (int j = 0; j < kPer; j += 4) {
+      int4 q = make_int4(0, 0, 0, 0);
+      if (i0 + j < n) q = *reinterpret_cast<const int4*>(c + i0 + j);
+      v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
+      sum += q.x + q.y + q.z + q.w;
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wave_base = 0, trip_total = 0;
+#pragma unroll
+    for (int w = 0; w < kBkThreads / 64; ++w) {
+      const int q = s_wave[w];
+      if (w < wave) wave_base += q;
+      trip_total += q;
+    }
+    int run = carry + wave_base + incl - sum;
+#pragma unroll
+    for (int j = 0; j < kPer; j += 4) {
+      int4 q;
+      q.x = run; run += v[j];
+      q.y = run; run += v[j + 1];
+      q.z = run; run += v[j + 2];
+      q.w = run; run += v[j + 3];
+      if (i0 + j < n) *reinterpret_cast<int4*>(c + i0 + j) = q;
+    }
+    carry += trip_total;
+    __syncthreads();  // s_wave is rewritten by the next trip
+  }
+  return carry;
+}
+
+// blocks [0, K): offset rows; blocks [K, K + kRsBins): sort digit rows (nblk_sort > 0).  `mirror` (may be null):
+// device-accessible pinned HOST buffer [K+2] that receives the offsets and the status word in the same kernel - the host
+// waits for an event behind this launch instead of queueing a separate D2H copy.
+__global__ __launch_bounds__(kBkThreads) void kmap_scan_kernel(int32_t* __restrict__ counts, int64_t ntile, int K,
+                                                               int32_t* __restrict__ totals, int32_t* __restrict__ ticket,
+                                                               int32_t* __restrict__ offsets,
+                                                               const int32_t* __restrict__ status,
+                                                               int32_t* __restrict__ mirror, int32_t* __restrict__ dcounts,
+                                                               int nblk_sort, int32_t* __restrict__ dtotals) {
+  __shared__ int s_wave[kBkThreads / 64];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= K) {  // sort digit row: exclusive scan over the sort tiles, digit total
+    const int d = blockIdx.x - K;
+    int32_t* row = dcounts + (int64_t)d * nblk_sort;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int chunk = (nblk_sort + kBkThreads - 1) / kBkThreads;
+    const int b0 = tid * chunk;
+    const int b1 = (b0 + chunk < nblk_sort) ? (b0 + chunk) : nblk_sort;
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += row[b];
+    int incl = sum;
+#pragma unroll
+    for (int q = 1; q < 64; q <<= 1) {
+      const int up = __shfl_up(incl, q);
+      if (lane >= q) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+    for (int b = b0; b < b1; ++b) {
+      const int v = row[b];
+      row[b] = run;
+      run += v;
+    }
+    if (tid == kBkThreads - 1) dtotals[d] = run;
+    return;
+  }
+  const int total = scan_row_256(counts + (int64_t)blockIdx.x * ntile, ntile, s_wave);
+  if (tid == 0) {
+    // device-scope store + fence + ticket: the workgroup that draws the last ticket sees every total
+    __hip_atomic_store(&totals[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = (atomicAdd(ticket, 1) == K - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // offsets = inclusive scan of the K totals (all requested at once: device-scope loads are uncached round trips)
+  int carry = 0;
+  for (int base = 0; base < K; base += kBkThreads) {
+    const int k = base + tid;
+    const int v = k < K ? __hip_atomic_load(&totals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wave_base = 0, trip_total = 0;
+#pragma unroll
+    for (int w = 0; w < kBkThreads / 64; ++w) {
+      const int q = s_wave[w];
+      if (w < wave) wave_base += q;
+      trip_total += q;
+    }
+    if (k < K) {
+      const int o = carry + wave_base + incl;
+      offsets[k + 1] = o;
+      if (mirror) mirror[k + 1] = o;
+    }
+    carry += trip_total;
+  }
+  if (tid == 0) {
+    offsets[0] = 0;
+    if (mirror) {
+      mirror[0] = 0;
+      mirror[K + 1] = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+  }
+}
+
+// One workgroup per 256-row tile.  Rank of a pair inside its bucket = offsets[k] + scanned count of the tile + pairs of
+// lower waves + popcount(row bitmap of the offset & lower rows): no atomics, order = output row.
+//
+// A wave reads its 64 neighbour rows as whole 16-B pieces (8 adjacent lanes = one 128-B row): lane l then HOLDS entries
+// (row l/8 + 8j, offsets 4(l%8) .. +3) for j = 0..7.  Instead of transposing them through an LDS tile (8 KB per wave: two
+// workgroups per CU) every holder ranks its own entries against the per-offset row bitmaps of the wave (27 ballots of the
+// mask bits, 256 B of LDS), so the only large LDS buffer is the staging area of the output.
+__global__ __launch_bounds__(kBkThreads) void kmap_scatter_kernel(const int32_t* __restrict__ nbr,
+                                                                  const uint32_t* __restrict__ mask, int64_t m, int K,
+                                                                  int kp, int mw, int64_t ntile,
+                                                                  const int32_t* __restrict__ counts,
+                                                                  const int32_t* __restrict__ offsets,
+                                                                  int32_t* __restrict__ in_maps,
+                                                                  int32_t* __restrict__ out_maps, int64_t pair_capacity,
+                                                                  int32_t* __restrict__ status) {
+  __shared__ int32_t s_in[kStageCap];
+  __shared__ int32_t s_out[kStageCap];
+  __shared__ unsigned long long s_ball[kBkThreads / 64][32];  // rows of the wave that have the offset
+  __shared__ int s_cnt[kBkThreads / 64][32];                  // pairs per (wave, offset), then exclusive over the waves
+  __shared__ int s_seg[33];                                   // first staged position of every offset
+  __shared__ int64_t s_gbase[32];                             // first global position of the tile's pairs of every offset
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tile_id = blockIdx.x;
+  const int64_t row0 = tile_id * kTileRows + wave * 64;
+  const int64_t row = row0 + lane;
+  bool overflow = false;
+  for (int w = 0; w < mw; ++w) {
+    const int kend = (K - w * 32) < 32 ? (K - w * 32) : 32;            // offsets in this mask word
+    const int cols4 = ((kp - w * 32) < 32 ? (kp - w * 32) : 32) >> 2;  // 16-B chunks per row in this word
+    // cols4 (<= 8) 16-B pieces per lane, all requested up front
+    int4 piece[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = lane + 64 * j;
+      const int r = e / cols4, c = e - r * cols4;
+      piece[j] = make_int4(-1, -1, -1, -1);
+      if (j < cols4 && row0 + r < m) piece[j] = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kp + w * 32 + c * 4);
+    }
+    const uint32_t bits = row < m ? mask[row * mw + w] : 0u;
+    // row bitmaps and pair counts of the word's offsets (lane b keeps offset w*32+b)
+    unsigned long long mine = 0ull;
+    for (int b = 0; b < kend; ++b) {
+      const unsigned long long ball = __ballot((bits >> b) & 1u);
+      if (lane == b) mine = ball;
+    }
+    if (lane < 32) {
+      s_ball[wave][lane] = mine;
+      s_cnt[wave][lane] = __popcll(mine);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      int tot = 0;
+      if (lane < 32) {
+#pragma unroll
+        for (int q = 0; q < kBkThreads / 64; ++q) {
+          const int c = s_cnt[q][lane];
+          s_cnt[q][lane] = tot;
+          tot += c;
+        }
+      }
+      int incl = tot;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+      }
+      if (lane < 32) s_seg[lane] = incl - tot;
+      if (lane == 31) s_seg[32] = incl;
+      if (lane < kend) s_gbase[lane] = (int64_t)offsets[w * 32 + lane] + counts[(int64_t)(w * 32 + lane) * ntile + tile_id];
+    }
+    __syncthreads();
+    const int total = s_seg[32];
+    const bool staged = total <= kStageCap;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j >= cols4) break;
+      const int e = lane + 64 * j;
+      const int r = e / cols4, c = e - r * cols4;
+      const int vals[4] = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int b = c * 4 + q;  // offset inside the word
+        if (vals[q] < 0 || b >= kend) continue;
+        const int local = s_cnt[wave][b] + __popcll(s_ball[wave][b] & ((1ull << r) - 1ull));
+        if (staged) {
+          s_in[s_seg[b] + local] = vals[q];
+          s_out[s_seg[b] + local] = (int32_t)(row0 + r);
+        } else {
+          const int64_t pos = s_gbase[b] + local;
+          if (pos < pair_capacity) {
+            in_maps[pos] = vals[q];
+            out_maps[pos] = (int32_t)(row0 + r);
+          } else {
+            overflow = true;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (staged) {
+      for (int e = tid; e < total; e += kBkThreads) {
+        int b = 0;  // offset of staged entry e: largest b with s_seg[b] <= e
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1)
+          if (b + step < 32 && s_seg[b + step] <= e) b += step;
+        const int64_t pos = s_gbase[b] + (e - s_seg[b]);
+        if (pos < pair_capacity) {
+          in_maps[pos] = s_in[e];
+          out_maps[pos] = s_out[e];
+        } else {
+          overflow = true;
+        }
+      }
+    }
+    __syncthreads();  // the next word rewrites the bitmaps and the staging area
+  }
+  if (overflow) atomicOr(status, (int)WCN_FLAG_PAIR_OVERFLOW);
+}
+
+static inline bool valid_k(int32_t k) { return k >= 1 && k <= 4096; }
+
+}  // namespace wcn
+
+using namespace wcn;
+
+extern "C" {
+
+// rounded up to a multiple of 4 so that every offset's row of the counts array is 16-B aligned (vector access in the scan)
+int64_t wcn_kmap_num_blocks(int64_t m) { return (ceil_div(m > 0 ? m : 0, kTileRows) + 3) & ~(int64_t)3; }
+
+size_t wcn_kmap_counts_bytes(int64_t m, int32_t num_offsets) {
+  // K rows of counts + K totals + the ticket word (+ slack)
+  return ((size_t)num_offsets * (size_t)(wcn_kmap_num_blocks(m) + 1) + 64) * 4;
+}
+
+static void launch_tally(uint32_t* mask, int32_t* nbr, int64_t m, int K, int32_t* counts, bool hist, int nblk_sort,
+                         int32_t* dcounts, const int32_t* coords, const CellTable* cells, int32_t* status, hipStream_t s) {
+  const int kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
+  const int64_t ntile = wcn_kmap_num_blocks(m);
+  int32_t* ticket = counts + (int64_t)K * (ntile + 1);
+  const dim3 grid((unsigned)ceil_div(m, kRsTile)), block(kTallyThreads);
+  CellTable none{};
+  const CellTable& t = cells ? *cells : none;
+  const uint32_t cmask = cells ? (uint32_t)(cells->capacity - 1) : 0u;
+#define WCN_TALLY(H, R)                                                                                                \
+  hipLaunchKernelGGL((kmap_tally_kernel<H, R>), grid, block, 0, s, mask, nbr, m, K, kp, mw, ntile, counts, ticket,       \
+                     nblk_sort, dcounts, (const int4*)coords, t, cmask, status)
+  if (hist && cells) WCN_TALLY(true, true);
+  else if (hist) WCN_TALLY(true, false);
+  else if (cells) WCN_TALLY(false, true);
+  else WCN_TALLY(false, false);
+#undef WCN_TALLY
+}
+
+static void launch_scan(int32_t* counts, int64_t ntile, int K, int32_t* offsets, const int32_t* status, int32_t* mirror,
+                        int nblk_sort, int32_t* dcounts, int32_t* dtotals, hipStream_t s) {
+  int32_t* totals = counts + (int64_t)K * ntile;
+  int32_t* ticket = totals + K;
+  hipLaunchKernelGGL(kmap_scan_kernel, dim3((unsigned)(K + (nblk_sort > 0 ? kRsBins : 0))), dim3(kBkThreads), 0, s, counts,
+                     ntile, K, totals, ticket, offsets, status, mirror, dcounts, nblk_sort, dtotals);
+}
+
+int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream) {
+  if (m < 0 || !valid_k(num_offsets)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  if (!mask || !counts) return WCN_ERROR_INVALID_PARAMETERS;
+  launch_tally(const_cast<uint32_t*>(mask), nullptr, m, num_offsets, counts, false, 0, nullptr, nullptr, nullptr, nullptr,
+               (hipStream_t)stream);
+  return launch_status();
+}
+
+// `counts` as written by wcn_kmap_count for the same map (the count launch also arms the ticket word behind the totals)
+static int scan_impl(int32_t* counts, int64_t num_blocks, int32_t K, int32_t* offsets, const int32_t* status,
+                     int32_t* mirror, wcn_stream_t stream) {
+  if (num_blocks < 0 || (num_blocks & 3) || !valid_k(K) || !offsets || !counts) return WCN_ERROR_INVALID_PARAMETERS;
+  launch_scan(counts, num_blocks, K, offsets, status, mirror, 0, nullptr, nullptr, (hipStream_t)stream);
+  return launch_status();
+}
+
+int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, wcn_stream_t stream) {
+  return scan_impl(counts, num_blocks, num_offsets, offsets, nullptr, nullptr, stream);
+}
+
+int wcn_kmap_scan_to_host(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, const int32_t* status,
+                          int32_t* host_mirror, wcn_stream_t stream) {
+  if (!host_mirror) return WCN_ERROR_INVALID_PARAMETERS;
+  return scan_impl(counts, num_blocks, num_offsets, offsets, status, host_mirror, stream);
+}
+
+size_t wcn_kmap_tally_sort_workspace(int64_t m) { return wcn_mask_argsort_workspace(m); }
+
+int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* counts, int32_t* offsets,
+                        int32_t* status, int32_t* host_mirror, int32_t* perm, void* sort_workspace,
+                        size_t sort_workspace_bytes, const int32_t* coords, void* binned_workspace, int64_t binned_n,
+                        int64_t max_blocks, wcn_stream_t stream) {
+  if (m < 0 || !valid_k(num_offsets) || !counts || !offsets || !status) return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  if (m == 0) {  // no rows: offsets are all zero, nothing to sort
+    if (hipMemsetAsync(offsets, 0, (size_t)(num_offsets + 1) * 4, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
+    if (host_mirror) {
+      if (hipMemsetAsync(host_mirror, 0, (size_t)(num_offsets + 1) * 4, s) != hipSuccess ||
+          hipMemcpyAsync(host_mirror + num_offsets + 1, status, 4, hipMemcpyDeviceToHost, s) != hipSuccess)
+        return WCN_ERROR_KERNEL_EXECUTION;
+    }
+    return WCN_SUCCESS;
+  }
+  if (m >= (1ll << 31) || !mask || !nbr || !perm || !sort_workspace ||
+      sort_workspace_bytes < wcn_kmap_tally_sort_workspace(m))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  if (binned_workspace && (!coords || binned_n != m || max_blocks < 1)) return WCN_ERROR_INVALID_PARAMETERS;
+  const SortPlan plan = sort_plan(sort_workspace, m, num_offsets < 32 ? num_offsets : 32);
+  CellTable cells{};
+  if (binned_workspace) cells = carve_cells(binned_workspace, binned_n, max_blocks);
+  launch_tally(mask, nbr, m, num_offsets, counts, true, plan.nblk, plan.counts, coords, binned_workspace ? &cells : nullptr,
+               status, s);
+  launch_scan(counts, wcn_kmap_num_blocks(m), num_offsets, offsets, status, host_mirror, plan.nblk, plan.counts, plan.totals, s);
+  sort_run(plan, mask, wcn_kmap_mask_words(num_offsets), m, perm, true, s);
+  return launch_status();
+}
+
+int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets, const int32_t* counts,
+                     const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status,
+                     wcn_stream_t stream) {
+  if (m < 0 || !valid_k(num_offsets) || pair_capacity < 0 || !status) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  if (!nbr || !mask || !counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps)))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  const int K = num_offsets, kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
+  const int64_t ntile = wcn_kmap_num_blocks(m);
+  hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(m, kTileRows)), dim3(kBkThreads), 0, (hipStream_t)stream,
+                     nbr, mask, m, K, kp, mw, ntile, counts, offsets, in_maps, out_maps, pair_capacity, status);
+  return launch_status();
+}
+
+}  // extern "C"

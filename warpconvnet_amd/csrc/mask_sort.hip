@@ -12,18 +12,12 @@
 //            are ranked 64 at a time: lanes with equal digits find each other with 9 ballots ("match-any"),
 //            rank = popcount(peers & lower lanes); the running base lives in LDS.  Stable by construction.
 // Descending order = ascending order of the inverted key.
-#include "wcn_common.h"
+#include "mask_sort.h"
 
 namespace wcn {
 
-constexpr int kRsBits = 9;
-constexpr int kRsBins = 1 << kRsBits;
-constexpr int kRsTile = 2048;
-constexpr int kRsThreads = 256;
 constexpr int kRsWaves = kRsThreads / 64;
 constexpr int kRsPerWave = kRsTile / kRsWaves;  // 512 keys, 8 batches of 64
-
-__device__ __forceinline__ uint32_t rs_digit(uint32_t key, int shift) { return ((~key) >> shift) & (kRsBins - 1); }
 
 // first pass reads the mask tensor directly (stride mw); later passes read the ping-pong key buffer
 __global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t key_stride,
@@ -168,20 +162,55 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t* 
   }
 }
 
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+SortPlan sort_plan(void* workspace, int64_t n, int num_bits) {
+  SortPlan p;
+  p.nblk = (int)ceil_div(n > 0 ? n : 1, kRsTile);
+  char* ws = (char*)workspace;
+  const size_t seg = al256((size_t)(n > 0 ? n : 1) * 4);
+  p.kbuf[0] = (uint32_t*)ws;
+  p.kbuf[1] = (uint32_t*)(ws ? ws + seg : nullptr);
+  p.vtmp = (int32_t*)(ws ? ws + 2 * seg : nullptr);
+  p.counts = (int32_t*)(ws ? ws + 3 * seg : nullptr);
+  p.totals = p.counts ? p.counts + (int64_t)kRsBins * p.nblk : nullptr;
+  // only the low `num_bits` bits of word 0 can be set (num_bits = min(K, 32)): 3 passes for a 3x3x3 kernel
+  if (num_bits > 32) num_bits = 32;
+  if (num_bits < 1) num_bits = 1;
+  p.passes = (num_bits + kRsBits - 1) / kRsBits;
+  p.bytes = 3 * seg + al256((size_t)kRsBins * (p.nblk + 1) * 4) + 256;
+  return p;
+}
+
+void sort_run(const SortPlan& p, const uint32_t* mask, int mask_words, int64_t n, int32_t* perm, bool first_counted,
+              hipStream_t s) {
+  const uint32_t* kin = mask;
+  int64_t stride = mask_words;
+  const int32_t* vin = nullptr;
+  for (int pass = 0; pass < p.passes; ++pass) {
+    const int shift = pass * kRsBits;
+    uint32_t* kout = p.kbuf[pass & 1];
+    int32_t* vout = ((p.passes - 1 - pass) & 1) ? p.vtmp : perm;  // last pass writes perm
+    if (!(pass == 0 && first_counted)) {  // the tally pass of the kernel-map build counts and scans the first digit itself
+      hipLaunchKernelGGL(rs_hist_kernel, dim3(p.nblk), dim3(kRsThreads), 0, s, kin, stride, n, shift, p.nblk, p.counts);
+      hipLaunchKernelGGL(rs_scan_kernel, dim3(kRsBins), dim3(256), 0, s, p.counts, p.nblk, p.totals);
+    }
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(p.nblk), dim3(kRsThreads), 0, s, kin, stride, vin, n, shift, p.nblk,
+                       (const int32_t*)p.counts, (const int32_t*)p.totals, kout, vout);
+    kin = kout;
+    stride = 1;
+    vin = vout;
+  }
+}
+
 }  // namespace wcn
 
 using namespace wcn;
 
 extern "C" {
 
-static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-size_t wcn_mask_argsort_workspace(int64_t n) {
-  if (n <= 0) return 256;
-  const int64_t nblk = ceil_div(n, kRsTile);
-  // two key buffers, one value buffer (the other is `perm`), per-(digit, block) counts + digit totals
-  return 3 * al256((size_t)n * 4) + al256((size_t)kRsBins * (nblk + 1) * 4) + 256;
-}
+size_t wcn_mask_argsort_workspace(int64_t n) { return sort_plan(nullptr, n, 32).bytes; }
 
 int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int32_t num_bits, int64_t n, int32_t* perm,
                      void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
@@ -189,32 +218,7 @@ int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int32_t num_bits,
   if (n == 0) return WCN_SUCCESS;
   if (n >= (1ll << 31) || !mask || !perm || !workspace || workspace_bytes < wcn_mask_argsort_workspace(n))
     return WCN_ERROR_INVALID_PARAMETERS;
-  hipStream_t s = (hipStream_t)stream;
-  const int nblk = (int)ceil_div(n, kRsTile);
-  char* ws = (char*)workspace;
-  const size_t seg = al256((size_t)n * 4);
-  uint32_t* kbuf[2] = {(uint32_t*)ws, (uint32_t*)(ws + seg)};
-  int32_t* vtmp = (int32_t*)(ws + 2 * seg);
-  int32_t* counts = (int32_t*)(ws + 3 * seg);
-  int32_t* totals = counts + (int64_t)kRsBins * nblk;
-  // only the low `num_bits` bits of word 0 can be set (num_bits = min(K, 32)): 3 passes for a 3x3x3 kernel
-  if (num_bits > 32) num_bits = 32;
-  const int passes = (num_bits + kRsBits - 1) / kRsBits;
-  const uint32_t* kin = mask;
-  int64_t stride = mask_words;
-  const int32_t* vin = nullptr;
-  for (int p = 0; p < passes; ++p) {
-    const int shift = p * kRsBits;
-    uint32_t* kout = kbuf[p & 1];
-    int32_t* vout = ((passes - 1 - p) & 1) ? vtmp : perm;  // last pass writes perm
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(kRsThreads), 0, s, kin, stride, n, shift, nblk, counts);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(kRsBins), dim3(256), 0, s, counts, nblk, totals);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(kRsThreads), 0, s, kin, stride, vin, n, shift, nblk,
-                       (const int32_t*)counts, (const int32_t*)totals, kout, vout);
-    kin = kout;
-    stride = 1;
-    vin = vout;
-  }
+  sort_run(sort_plan(workspace, n, num_bits), mask, mask_words, n, perm, false, (hipStream_t)stream);
   return launch_status();
 }
 

@@ -130,10 +130,14 @@ class Geometry:
             device, dtype = None, device
         if device is None:
             device = self.device
+        extra = self._extra_attributes
+        if torch.device(device) != torch.device(self.device):
+            # cached kernel maps / spatial caches hold tensors (and raw table pointers) of the old device
+            extra = {k: v for k, v in extra.items() if k not in ("_cache", "_spatial_cache")}
         return self.__class__(
             self.batched_coordinates.to(device=device),
             self.batched_features.to(device=device, dtype=dtype),
-            **self._extra_attributes,
+            **extra,
         )
 
     def _apply_feature_transform(self, fn) -> "Geometry":

@@ -121,6 +121,10 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
     return kmap._rev
 
 
+# binned builder: does this process see scenes with >= 4 voxels per occupied 8^3 block?  (size of the first-try block table)
+_BINNED_HINT = {"dense": True}
+
+
 @torch.compiler.disable
 @torch.no_grad()
 def generate_kernel_map(
@@ -177,67 +181,92 @@ def generate_kernel_map(
     kp, mw = L.wcn_kmap_row_pitch(K), L.wcn_kmap_mask_words(K)
     nblk = L.wcn_kmap_num_blocks(M)
 
-    # meta[0:K+1] = offsets, meta[K+1] = status flags -> one D2H copy
-    meta = None  # allocated below: the binned path clears the status word itself, the hash path needs zeros
-    nbr = torch.empty((M, kp), dtype=torch.int32, device=dev)
-    mask = torch.empty((M, mw), dtype=torch.int32, device=dev)
-    block_counts = torch.empty(K * (nblk + 1), dtype=torch.int32, device=dev)  # k-major counts + K totals
+    # meta[0:K+1] = offsets, meta[K+1] = status flags -> one host read (written to pinned memory by the scan kernel)
     unit_stride = all(s == 1 for s in stride)
     method_env = os.environ.get("WARPCONVNET_AMD_KMAP_METHOD", "auto").strip().lower()
     use_binned = (
-        method_env != "hash" and same_tensor and unit_stride
+        method_env != "hash" and same_tensor and unit_stride and N > 0
         and bool(L.wcn_kmap_binned_supported(_lib.i3(ksize), _lib.i3(dilation)))
     )
-    if method_env == "binned" and not use_binned:
-        raise RuntimeError("WARPCONVNET_AMD_KMAP_METHOD=binned needs a submanifold map (same coordinate tensor, stride 1, halo <= 4)")
-    table = PackedHashTable(max(16, 2 * N), device=dev)
-    meta = (torch.empty if (use_binned and N > 0) else torch.zeros)(K + 2, dtype=torch.int32, device=dev)
-    if use_binned:
-        # LDS-binned path: block-level hash + counting sort + LDS grid probes (csrc/kmap_binned.hip)
-        table._slots = torch.empty((table.capacity, 2), dtype=torch.int64, device=dev)
-        ws_bytes = L.wcn_kmap_binned_workspace(N)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        _lib.check(
-            L.wcn_kmap_build_binned(_lib.ptr(in_coords), N, _lib.i3(ksize), _lib.i3(dilation), _lib.ptr(table._slots),
-                                    table.capacity, _lib.ptr(ws), ws_bytes, _lib.ptr(nbr), _lib.ptr(mask),
-                                    _lib.ptr(meta[K + 1 :]), stream),
-            "wcn_kmap_build_binned",
-        )
-        table = None  # the block table is not a voxel table
-    else:
-        table._launch_insert(in_coords, meta[K + 1 :])
-        _lib.check(
-            L.wcn_kmap_probe(_lib.ptr(table.slots_tensor), table.capacity, _lib.ptr(out_coords), M, _lib.i3(ksize),
-                             _lib.i3(stride), _lib.i3(dilation), _lib.ptr(nbr), _lib.ptr(mask), stream),
-            "wcn_kmap_probe",
-        )
-    _lib.check(L.wcn_kmap_count(_lib.ptr(mask), M, K, _lib.ptr(block_counts), stream), "wcn_kmap_count")
-    # offsets + status flags are written to pinned host memory by the scan's last kernel itself (no copy command); the
-    # mask argsort does not depend on the pair count and keeps the GPU busy during the host round trip
-    meta_host = torch.empty(K + 2, dtype=torch.int32, pin_memory=True)
-    _lib.check(L.wcn_kmap_scan_to_host(_lib.ptr(block_counts), nblk, K, _lib.ptr(meta), _lib.ptr(meta[K + 1 :]),
-                                       ctypes.c_void_p(meta_host.data_ptr()), stream), "wcn_kmap_scan_to_host")
+    if method_env == "binned" and not use_binned and N > 0:
+        raise RuntimeError("WARPCONVNET_AMD_KMAP_METHOD=binned needs a submanifold map (same coordinate tensor, stride 1, "
+                           "halo <= 4, K % 32 != 0)")
     table_capacity = _next_power_of_2(max(16, 2 * N))
-    event = torch.cuda.Event()
-    event.record(torch.cuda.current_stream(dev))
-    perm = mask_argsort(mask, K)
+    # binned path: capacity of the block table.  Most scenes have >= 4 voxels per occupied 8^3 block; sparser ones raise
+    # TABLE_FULL on the device and are rebuilt with one block per voxel (always enough).  `strict`: see wcn.h.
+    max_blocks = max(1024, N // 4) if _BINNED_HINT["dense"] else max(N, 1)
+    strict = 0
+    # WARPCONVNET_AMD_ASYNC_KMAP=1 (opt-in): never wait - pairs go to worst-case sized buffers and offsets / flags are
+    # validated lazily (IntSearchResult.poll / first host access); the binned builder then runs in its no-retry
+    # configuration.  Default: wait for the mirror, raise range / capacity errors at build time like the reference,
+    # allocate exact-size pair buffers.
+    async_ok = os.environ.get("WARPCONVNET_AMD_ASYNC_KMAP", "0") in ("1", "true") and K * M * 8 <= (1 << 29)
+    if async_ok and use_binned:
+        max_blocks, strict = max(N, 1), 1
+    while True:
+        nbr = torch.empty((M, kp), dtype=torch.int32, device=dev)
+        mask = torch.empty((M, mw), dtype=torch.int32, device=dev)
+        block_counts = torch.empty(L.wcn_kmap_counts_bytes(M, K) // 4, dtype=torch.int32, device=dev)
+        perm = torch.empty(M, dtype=torch.int32, device=dev)
+        meta = (torch.empty if use_binned else torch.zeros)(K + 2, dtype=torch.int32, device=dev)
+        table, bin_ws = None, None
+        if use_binned:
+            # LDS-binned path: block-level hash + cell table + per-block LDS grid probes (csrc/kmap_binned.hip)
+            ws_bytes = L.wcn_kmap_binned_workspace(N, max_blocks)
+            bin_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(
+                L.wcn_kmap_build_binned(_lib.ptr(in_coords), N, _lib.i3(ksize), _lib.i3(dilation), max_blocks, strict,
+                                        _lib.ptr(bin_ws), ws_bytes, _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(meta[K + 1 :]),
+                                        stream),
+                "wcn_kmap_build_binned",
+            )
+        else:
+            table = PackedHashTable(max(16, 2 * N), device=dev)
+            table._launch_insert(in_coords, meta[K + 1 :])
+            _lib.check(
+                L.wcn_kmap_probe(_lib.ptr(table.slots_tensor), table.capacity, _lib.ptr(out_coords), M, _lib.i3(ksize),
+                                 _lib.i3(stride), _lib.i3(dilation), _lib.ptr(nbr), _lib.ptr(mask), stream),
+                "wcn_kmap_probe",
+            )
+        # tally (pair counts per tile + first sort digit + duplicate repair) -> scans (offsets + status flags written to
+        # pinned host memory by the kernel itself, no copy command) -> mask argsort; the sort does not depend on the pair
+        # count and keeps the GPU busy during the host round trip
+        meta_host = torch.empty(K + 2, dtype=torch.int32, pin_memory=True)
+        sort_bytes = L.wcn_kmap_tally_sort_workspace(M)
+        sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(
+            L.wcn_kmap_tally_sort(_lib.ptr(mask), _lib.ptr(nbr), M, K, _lib.ptr(block_counts), _lib.ptr(meta),
+                                  _lib.ptr(meta[K + 1 :]), ctypes.c_void_p(meta_host.data_ptr()), _lib.ptr(perm),
+                                  _lib.ptr(sort_ws), sort_bytes, _lib.ptr(in_coords) if use_binned else None,
+                                  _lib.ptr(bin_ws), N if use_binned else 0, max_blocks if use_binned else 0, stream),
+            "wcn_kmap_tally_sort",
+        )
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(dev))
+        if async_ok:
+            break
+        event.synchronize()
+        flags = int(meta_host[K + 1])
+        if use_binned and (flags & _lib.WCN_FLAG_TABLE_FULL) and max_blocks < N:
+            _BINNED_HINT["dense"] = False  # this process sees sparse scenes: start with the large table from now on
+            max_blocks = N
+            continue
+        if use_binned and (flags & _lib.WCN_FLAG_NEED_STRICT) and not strict:
+            strict = 1
+            continue
+        break
 
     odd = all(k % 2 == 1 for k in ksize)
     identity = K // 2 if (odd and unit_stride and N == M) else None
-    # WARPCONVNET_AMD_ASYNC_KMAP=1 (opt-in): never wait - pairs go to worst-case sized buffers and offsets / flags are
-    # validated lazily (IntSearchResult.poll / first host access).  Default: wait for the copy here, raise range /
-    # capacity errors at build time like the reference, allocate exact-size pair buffers.
-    async_ok = os.environ.get("WARPCONVNET_AMD_ASYNC_KMAP", "0") in ("1", "true") and K * M * 8 <= (1 << 29)
     has_duplicates = True  # unknown until the flags arrive (async mode): assume the worst
     if async_ok:
         pair_capacity = K * M
         offsets_host = None
     else:
-        event.synchronize()
-        PackedHashTable.raise_for_flags(int(meta_host[K + 1]), N, table_capacity)
+        PackedHashTable.raise_for_flags(flags, N, table_capacity)
         offsets_host = meta_host[: K + 1].clone()
         pair_capacity = int(offsets_host[-1])
-        has_duplicates = bool(int(meta_host[K + 1]) & _lib.WCN_FLAG_DUPLICATE_COORD)
+        has_duplicates = bool(flags & _lib.WCN_FLAG_DUPLICATE_COORD)
     in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
     out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
     _lib.check(
@@ -253,8 +282,11 @@ def generate_kernel_map(
         result = IntSearchResult(in_maps, out_maps, offsets_host, identity_map_index=identity)
     result._nbr, result._mask, result._perm = nbr, mask, perm
     result._offsets_dev = meta[: K + 1]
-    result._symmetric = bool(same_tensor and odd and unit_stride)
-    result._self_exact = result._symmetric and not has_duplicates
+    # Duplicate input rows break the k-flip identity the dgrad shortcut relies on (rev[n][k] == nbr[n][K-1-k] holds only
+    # when every coordinate is one row: a non-winner duplicate has neighbours but is nobody's neighbour), so such maps -
+    # and maps whose flags have not arrived yet (async mode) - take the explicit reverse table instead.
+    result._symmetric = bool(same_tensor and odd and unit_stride and not has_duplicates)
+    result._self_exact = result._symmetric
     result._num_in, result._num_out = N, M
     result._hashtable = table
     result._kernel_size = ksize

@@ -89,9 +89,16 @@ def _pool_map(voxels: Voxels, kernel_size: Tuple[int, ...], stride: Tuple[int, .
     bcoords_in = voxels.batch_indexed_coordinates
     if bcoords_in.dtype != torch.int32:
         bcoords_in = bcoords_in.to(torch.int32)
+    from warpconvnet_amd.geometry.coords.ops.serialization import POINT_ORDERING, to_point_ordering
+
     bcoords_out, out_offsets = stride_coords(bcoords_in, stride, order=order)
-    key = IntSearchCacheKey(kernel_size, ntuple(1, nd), False, False, str(STRIDED_CONV_MODE.STRIDE_ONLY), False,
-                            voxels.offsets, out_offsets)
+    # same key construction as the convolution (helper.py): the ordering of the OUTPUT rows is part of the key, or an
+    # ordered pool and an unordered strided layer on one tensor would share a map whose rows follow the other's order
+    order_e = to_point_ordering(order)
+    mode_key = str(STRIDED_CONV_MODE.STRIDE_ONLY)
+    if order_e != POINT_ORDERING.RANDOM:
+        mode_key = f"{mode_key}|{order_e.value}"
+    key = IntSearchCacheKey(kernel_size, ntuple(1, nd), False, False, mode_key, False, voxels.offsets, out_offsets)
     kernel_map = voxels.cache.get(key) if voxels.cache is not None else None
     if kernel_map is None:
         kernel_map = generate_kernel_map(bcoords_in, bcoords_out, stride, kernel_size, ntuple(1, nd))

@@ -13,6 +13,16 @@ from warpconvnet_amd.nn.functional.normalizations import batch_norm_module_forwa
 from .base_module import BaseSpatialModule
 
 
+def _has_hooks(module: nn.Module) -> bool:
+    """The fused BatchNorm(+ReLU) path calls the kernels, not ``module(x)``: a module that carries forward hooks (activation
+    capture, profilers, quantisation observers) - or any global module hook - runs the ordinary way so the hooks fire."""
+    import torch.nn.modules.module as _m
+
+    return bool(module._forward_hooks or module._forward_pre_hooks or module._backward_hooks or module._backward_pre_hooks
+                or _m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks
+                or _m._global_backward_pre_hooks)
+
+
 class Sequential(nn.Sequential, BaseSpatialModule):
     def forward(self, x: Geometry):
         assert isinstance(x, Geometry), f"Expected a Geometry, got {type(x)}"
@@ -23,12 +33,12 @@ class Sequential(nn.Sequential, BaseSpatialModule):
             module = mods[i]
             i += 1
             spatial = isinstance(module, BaseSpatialModule)
-            if not spatial and type(module) is nn.BatchNorm1d:
+            if not spatial and type(module) is nn.BatchNorm1d and not _has_hooks(module):
                 # BatchNorm1d on the feature tensor (and the ReLU behind it, the ConvBlock pattern of the reference's
                 # models) goes through the HIP kernels: same function, state and gradients (functional/normalizations.py)
                 feats = x.feature_tensor if isinstance(x, Geometry) else x
                 if hip_batch_norm_supported(feats) and feats.is_floating_point():
-                    fuse_relu = i < len(mods) and type(mods[i]) is nn.ReLU
+                    fuse_relu = i < len(mods) and type(mods[i]) is nn.ReLU and not _has_hooks(mods[i])
                     if isinstance(x, Geometry):
                         carrier = x
                     x = batch_norm_module_forward(module, feats, relu=fuse_relu)
