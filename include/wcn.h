@@ -135,7 +135,7 @@ int wcn_kmap_binned_supported(const int32_t ksize[3], const int32_t dilation[3])
 int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[3], const int32_t dilation[3],
                           int64_t max_blocks, int32_t strict, void* workspace, size_t workspace_bytes, int32_t* nbr,
                           uint32_t* mask, int32_t* status, wcn_stream_t stream);
-/* Everything between the neighbour table and the ONE host read of a build, three + (3 per further sort digit) launches:
+/* Everything between the neighbour table and the ONE host read of a build:
  *   tally  per-(offset, tile) pair counts from the masks, the first digit histogram of the mask sort, and - when
  *          `binned_workspace` (the workspace of the wcn_kmap_build_binned call that produced nbr / mask, with its n and
  *          max_blocks) is given - repair of the rows of duplicate coordinates

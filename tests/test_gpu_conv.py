@@ -113,10 +113,41 @@ def test_wgrad_fused_bias_grad(dtype, cin, cout):
     # duplicate coordinates: bucket K//2 is no longer "every row once" -> no fused bias gradient
     sd = np.concatenate([s[:2000], s[:17]], 0)
     kmd = _kmap(sd, sd, (3, 3, 3), same=True)
-    assert kmd._symmetric and not kmd._self_exact
+    assert not kmd._symmetric and not kmd._self_exact  # duplicates: dgrad takes the explicit reverse table
     _, dbd = hip_gemm.hip_wgrad(X[: len(sd)].contiguous(), dY[: len(sd)].contiguous(), kmd, (27, cin, cout), "auto",
                                 want_bias_grad=True)
     assert dbd is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("method", ["binned", "hash"])
+def test_duplicate_rows_all_three_gemms_vs_oracle(dtype, method, monkeypatch):
+    """Duplicate input coordinates (the smallest row wins every probe): the k-flip shortcut of dgrad does not hold - a
+    non-winner row has neighbours but is nobody's neighbour - so the map must route dgrad through the reverse table.
+    Map bit-exact vs the C oracle, forward / dgrad / wgrad vs the fp64 pair-list oracle (round-1 ADVICE)."""
+    monkeypatch.setenv("WARPCONVNET_AMD_KMAP_METHOD", method)
+    base = scene_u(2500, 41, 0)
+    s = np.concatenate([base, base[100:400], base[:50]], 0)  # 350 duplicate rows, some coordinates three times
+    rng = np.random.default_rng(5)
+    s = s[rng.permutation(len(s))]
+    km = _kmap(s, s, (3, 3, 3), same=True)
+    r = okmap.kernel_map(s, s, (3, 3, 3))
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+    np.testing.assert_array_equal(km.out_maps.cpu().numpy(), r["out_maps"])
+    assert not km._symmetric and not km._self_exact
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(77)
+    cin, cout = 64, 128
+    X = torch.randn(len(s), cin, generator=g).to(dev, dtype)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev, dtype)
+    dY = torch.randn(len(s), cout, generator=g).to(dev, dtype)
+    Y, dX, dW = _run_all(km, X, W, dY, "auto", len(s), len(s))
+    Yr, dXr, dWr = _oracle(r, X, W, dY, len(s))
+    assert rel_max_err(Y, Yr) < TOL[dtype] and rel_max_err(dX, dXr) < TOL[dtype] and rel_max_err(dW, dWr) < TOL[dtype]
+    # rows that lose their coordinate to a smaller row receive no gradient at all
+    winners = np.unique(r["in_maps"])
+    losers = np.setdiff1d(np.arange(len(s)), winners)
+    assert len(losers) > 0 and float(dX[torch.from_numpy(losers).to(dev)].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("scale", [1.0, 3.0e5])

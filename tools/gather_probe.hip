@@ -25,6 +25,18 @@ __global__ __launch_bounds__(256) void gather(const char* __restrict__ in, const
         const f4* p = reinterpret_cast<const f4*>(in + (long)r * 128 + (lane >> 5) * 64);
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[u][s] = p[s];
+      } else if (MODE == 2) {  // 16x16x32 operand order: lane (g, n) takes piece g of each half of row n (4 lanes, not adjacent)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r = idx[base + u * 32 + (s >> 1) * 16 + (lane & 15)];
+          v[u][s] = *reinterpret_cast<const f4*>(in + (long)r * 128 + (s & 1) * 64 + (lane >> 4) * 16);
+        }
+      } else if (MODE == 3) {  // row-shaped 64 B: 4 ADJACENT lanes cover half a row, 16 rows per instruction
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r = idx[base + u * 32 + (s >> 1) * 16 + (lane >> 2)];
+          v[u][s] = *reinterpret_cast<const f4*>(in + (long)r * 128 + (s & 1) * 64 + (lane & 3) * 16);
+        }
       } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -69,5 +81,14 @@ int main() {
   hipMemcpy(idx, h.data(), npairs * 4, hipMemcpyHostToDevice);
   run<0, 4>("fragment-shaped, sorted idx", in, idx, npairs, out, 2048);
   run<1, 4>("line-coalesced,  sorted idx", in, idx, npairs, out, 2048);
+  run<2, 4>("16x16x32 operand order, sorted idx", in, idx, npairs, out, 2048);
+  run<3, 4>("row-shaped 64 B (4 adjacent lanes), sorted", in, idx, npairs, out, 2048);
+  // everything in a 128 KB window: L1 / L2 hits only -> the address pipeline itself
+  for (long i = 0; i < npairs; ++i) h[i] = (int)(rng() % 1024);
+  hipMemcpy(idx, h.data(), npairs * 4, hipMemcpyHostToDevice);
+  run<0, 4>("fragment-shaped, 128 KB window", in, idx, npairs, out, 2048);
+  run<1, 4>("line-coalesced,  128 KB window", in, idx, npairs, out, 2048);
+  run<2, 4>("16x16x32 operand order, 128 KB window", in, idx, npairs, out, 2048);
+  run<3, 4>("row-shaped 64 B, 128 KB window", in, idx, npairs, out, 2048);
   return 0;
 }

@@ -24,3 +24,7 @@ for a, b, nm in ((0, 1, "halo gather"), (1, 2, "own cells + enumerate + prefetch
     print(f"  {nm:34s} mean {d.mean():6.2f} p50 {np.median(d):6.2f} p95 {np.percentile(d,95):6.2f}")
 life = (p[:, 3] - p[:, 0]) / 100.0
 print("  block life mean", life.mean(), "own_cnt mean", p[:, 4].mean(), "max", p[:, 4].max())
+st = (p[:, 5] - p[:, 5].min()) / 100.0
+en = (p[:, 3] - p[:, 5].min()) / 100.0
+print("  wave start percentiles [0,10,50,90,99,100]", np.percentile(st, [0, 10, 50, 90, 99, 100]).round(1))
+print("  wave end   percentiles [0,10,50,90,99,100]", np.percentile(en, [0, 10, 50, 90, 99, 100]).round(1))

@@ -514,6 +514,20 @@ static int dispatch_co(int cout, const void* in, const void* wp, void* out, cons
   }
 }
 
+// conv_mfma_lds.hip
+bool gather_gemm_lds_supported(int cin, int cout, int K, int dtype);
+int conv_gather_gemm_lds(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                         const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
+                         float* out32, hipStream_t s);
+
+// conv_mfma16.hip
+bool mfma16_supported(int cin, int cout, int K, int dtype);
+int conv_gather_gemm16(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                       const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
+                       float* out32, hipStream_t s);
+int pack_weight16(const void* w, int w_is_f32, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
+                  hipStream_t s);
+
 int mfma_chunk_for(int cin) {
   if (cin % 64 == 0) return 64;
   if (cin % 32 == 0) return 32;
@@ -521,11 +535,17 @@ int mfma_chunk_for(int cin) {
   return 0;
 }
 
-bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
-  if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
-  if (K < 1 || K > kMaxK) return false;
+// channel shapes of the 32x32x16 kernels in this file
+bool mfma32_shape(int cin, int cout) {
   if (mfma_chunk_for(cin) == 0) return false;
   return cout == 32 || cout == 64 || cout == 96 || cout == 128 || cout == 192 || cout == 256;
+}
+
+bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
+  if (mfma16_supported(cin, cout, K, dtype)) return true;
+  if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
+  if (K < 1 || K > kMaxK) return false;
+  return mfma32_shape(cin, cout);
 }
 
 template <typename T>
@@ -544,13 +564,20 @@ int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32
                           const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
                           float* out32, hipStream_t s) {
   if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (gather_gemm_lds_supported(cin, cout, K, dtype))  // rows staged through LDS (conv_mfma_lds.hip, opt-in)
+    return conv_gather_gemm_lds(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, dtype, out32, s);
+  if (mfma16_supported(cin, cout, K, dtype))  // 16x16x32 shape: row-shaped gathers (conv_mfma16.hip)
+    return conv_gather_gemm16(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, dtype, out32, s);
   if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, out32, s);
   return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, out32, s);
 }
 
 int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                          hipStream_t s) {
-  const int cic = mfma_chunk_for(cin);
+  // the layout of the packed image follows the kernel that will consume it (a pure function of the shape)
+  if (!gather_gemm_lds_supported(cin, cout, K, dtype) && mfma16_supported(cin, cout, K, dtype))
+    return pack_weight16(w, 1, K, cin, cout, dtype, transpose, flip, packed, s);
+  const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin);
   if (cic == 0 || cout % 32 != 0 || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   const int64_t total = (int64_t)K * cin * cout;
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
@@ -564,7 +591,9 @@ int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, in
 
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s) {
-  const int cic = mfma_chunk_for(cin);
+  if (!gather_gemm_lds_supported(cin, cout, K, dtype) && mfma16_supported(cin, cout, K, dtype))
+    return pack_weight16(w, 0, K, cin, cout, dtype, transpose, flip, packed, s);
+  const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin);
   if (cic == 0 || cout % 32 != 0 || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   const int64_t total = (int64_t)K * cin * cout;
   // bf16 and f16 are both 2-byte moves

@@ -124,31 +124,31 @@ __global__ __launch_bounds__(kInsertThreads) void cell_insert_kernel(BSlot* __re
   if (live) {
     key = pack_key(c.x, c.y >> kBlkShift, c.z >> kBlkShift, c.w >> kBlkShift);
     uint32_t s = hash_slot(key, cmask);
+    int idv = -1;
     for (uint32_t a = 0; a <= cmask; ++a) {
       unsigned long long* kptr = reinterpret_cast<unsigned long long*>(&slots[s].key);
-      // optimistic cached read first: a key, once written, never changes, so a matching value is final; an empty or
-      // stale value falls through to the coherent read below
-      // (wavefront-scope relaxed load = an ordinary cached load the compiler must still perform; a `volatile` access is
-      // emitted as a system-coherent `sc0 sc1` load that misses every cache)
-      unsigned long long cur = __hip_atomic_load(kptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (cur == key) { found = (int)s; break; }
-      cur = __hip_atomic_load(kptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // optimistic cached read first, key and id in ONE 16-B load: a key, once written, never changes, so a matching
+      // value is final (and so is the id of a block of an EARLIER launch); an empty - possibly stale - key falls through
+      // to the coherent read below
+      const uint4 v = *reinterpret_cast<const uint4*>(slots + s);
+      unsigned long long cur = ((unsigned long long)v.y << 32) | v.x;
+      if (cur == key) { found = (int)s; idv = (int)v.z; break; }
       if (cur == 0ull) {
-        cur = atomicCAS(kptr, 0ull, (unsigned long long)key);
-        if (cur == 0ull) {  // this thread created the block (its dense id is handed out below, once per wave)
-          created = true;
-          found = (int)s;
-          break;
+        cur = __hip_atomic_load(kptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0ull) {
+          cur = atomicCAS(kptr, 0ull, (unsigned long long)key);
+          if (cur == 0ull) {  // this thread created the block (its dense id is handed out below)
+            created = true;
+            found = (int)s;
+            break;
+          }
         }
+        if (cur == key) { found = (int)s; break; }
       }
-      if (cur == key) { found = (int)s; break; }
       s = (s + 1) & cmask;
     }
     if (found < 0) atomicOr(status, (int)WCN_FLAG_TABLE_FULL);
-    if (PHASE == 1 && found >= 0 && !created) {
-      const int v = slots[found].id;  // plain read: final for blocks of the sampled pass, possibly stale otherwise
-      if (v >= 0 && !(v & kIdLateBit)) id = v;
-    }
+    if (PHASE == 1 && idv >= 0 && !(idv & kIdLateBit)) id = idv;
   }
   // dense block ids: ONE counter update per workgroup (sampled pass: nearly every wave creates blocks) or per wave
   // (second pass: a few hundred creations in all, and no barrier for the million threads that only look up)
@@ -262,7 +262,9 @@ __device__ unsigned long long g_bprof[4096 * 8];
 
 // One wave per block.  LDS: the halo gather list (shared by the workgroup), then per wave grid[g.cells] row ids
 // (-1 = empty) and own[512] u16 grid indices of the block's occupied cells.
-template <int LPR>
+// FAST: every byte offset into nbr / mask fits 31 bits and every row index 24 bits (n < 2^24, n * kp * 4 < 2^31): the
+// addresses of the probe loop are one full-rate 24-bit multiply-add instead of two quarter-rate 64-bit ones.
+template <int LPR, bool FAST>
 __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t, const uint32_t* __restrict__ halo,
                                                                     CellGeom g, int K, int kp, int mw,
                                                                     int32_t* __restrict__ nbr,
@@ -270,11 +272,15 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
   extern __shared__ int s_mem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* s_halo = reinterpret_cast<uint32_t*>(s_mem);
-  const int halo_pad = (g.halo_cells + 255) & ~255;  // whole 4 x 64 gather rounds
-  const int per_wave = g.cells + kCells / 2;         // ints
+  const int halo_pad = (g.halo_cells + 63) & ~63;  // whole 64-lane gather rounds
+  const int per_wave = g.cells + 4 + kCells / 2 + 8;  // ints: grid, null cell, own list (+ padding entries)
   int* s_grid = s_mem + halo_pad + wave * per_wave;
-  unsigned short* s_own = reinterpret_cast<unsigned short*>(s_grid + g.cells);
+  // byte offsets (into s_grid) of the block's occupied cells, padded to whole probe trips with the NULL cell: a cell
+  // behind the grid that holds -1, so the probe loop needs no bounds checks (row -1 = nothing stored)
+  unsigned short* s_own = reinterpret_cast<unsigned short*>(s_grid + g.cells + 4);
+  const int null_cell = g.cells;
   for (int h = threadIdx.x; h < halo_pad; h += kNbThreads) s_halo[h] = h < g.halo_cells ? halo[h] : 0xFFFFFFFFu;
+  if (lane == 0) s_grid[null_cell] = -1;
   __syncthreads();  // the only workgroup barrier: the waves are independent from here on
 
   int nblocks = t.ctr[0];
@@ -284,41 +290,61 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
   constexpr int kVoxPerIter = 64 / LPR;
   const int sub = lane % LPR, vsel = lane / LPR;
   const int num_chunks = (kp + LPR - 1) / LPR;
-  auto block_id = [&](int seq) -> int { return seq; };
-
-  // software pipeline over the wave's blocks: the neighbour ids and the block's own 2 KB of the NEXT block are requested
-  // before the probe loop of the current one
+  // Software pipeline over the wave's blocks (stride nwaves).  While block i is probed out of LDS, the halo cells of
+  // block i+1 (gathered with the neighbour ids that arrived during block i-1) and the neighbour ids + own 2 KB of block
+  // i+2 are in flight: a block costs two dependent memory round trips, and a wave owns only two or three blocks.
+  const int rounds = (g.halo_cells + 63) >> 6;
+  auto load_head = [&](int seq, int& nb, int4& v0, int4& v1) {
+    nb = -1;
+    v0 = make_int4(-1, -1, -1, -1);
+    v1 = v0;
+    if (seq < nblocks) {
+      if (lane < 27) nb = t.nbtab[(int64_t)seq * 32 + lane];
+      const int4* own = reinterpret_cast<const int4*>(t.cells + (int64_t)seq * kCells) + lane * 2;
+      v0 = own[0];
+      v1 = own[1];
+    }
+  };
   int seq = gwave;
-  int id = seq < nblocks ? block_id(seq) : 0;
-  int nb = -1;
-  int4 v0 = make_int4(-1, -1, -1, -1), v1 = v0;
-  if (seq < nblocks) {
-    if (lane < 27) nb = t.nbtab[(int64_t)id * 32 + lane];
-    const int4* own = reinterpret_cast<const int4*>(t.cells + (int64_t)id * kCells) + lane * 2;
-    v0 = own[0];
-    v1 = own[1];
-  }
+  int nb_c, nb_n;
+  int4 c0, c1, n0, n1;
+  load_head(seq, nb_c, c0, c1);
+  load_head(seq + nwaves, nb_n, n0, n1);
+  int hv[8];  // halo values of the current block (3x3x3: all of them; larger halos reload per 8 rounds below)
+  auto gather = [&](int nb, int r0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      hv[u] = -1;
+      if (r0 + u < rounds) {
+        const uint32_t e = s_halo[(r0 + u) * 64 + lane];
+        const int nid = __shfl(nb, (int)((e >> 27) & 31u));
+        if (e != 0xFFFFFFFFu && nid >= 0) hv[u] = t.cells[(int64_t)nid * kCells + ((e >> 16) & (kCells - 1))];
+      }
+    }
+  };
+  auto scatter_halo = [&](int r0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (r0 + u < rounds) {
+        const uint32_t e = s_halo[(r0 + u) * 64 + lane];
+        if (e != 0xFFFFFFFFu) s_grid[e & 0xFFFFu] = hv[u];
+      }
+  };
+#ifdef WCN_PROF
+  if (lane == 0 && gwave < 4096) g_bprof[gwave * 8 + 5] = wall_clock64();
+#endif
+  if (seq < nblocks) gather(nb_c, 0);
   for (; seq < nblocks; seq += nwaves) {
     BSTAMP(0);
-    // ---- halo cells from the neighbours' sub-grids (absent neighbour: empty) ----
-    for (int h0 = 0; h0 < halo_pad; h0 += 4 * 64) {
-      uint32_t e[4];
-      int v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) e[u] = s_halo[h0 + u * 64 + lane];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[u] = -1;
-        const int nid = __shfl(nb, (int)((e[u] >> 27) & 31u));
-        if (e[u] != 0xFFFFFFFFu && nid >= 0) v[u] = t.cells[(int64_t)nid * kCells + ((e[u] >> 16) & (kCells - 1))];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (e[u] != 0xFFFFFFFFu) s_grid[e[u] & 0xFFFFu] = v[u];
+    // ---- halo cells into the grid (absent neighbour: empty) ----
+    scatter_halo(0);
+    for (int r0 = 8; r0 < rounds; r0 += 8) {  // kernels with a halo above 1: the rest of the list, not pipelined
+      gather(nb_c, r0);
+      scatter_halo(r0);
     }
     BSTAMP(1);
     // ---- own cells into the grid; occupied ones enumerated with a wave prefix sum ----
-    const int vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const int vals[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const int cell0 = ((lane >> 3) + g.hx) * g.px + ((lane & 7) + g.hy) * g.py + g.hz;
     int mine = 0;
 #pragma unroll
@@ -336,43 +362,70 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
     int at = incl - mine;
 #pragma unroll
     for (int z = 0; z < 8; ++z)
-      if (vals[z] >= 0) s_own[at++] = (unsigned short)(cell0 + z);
-    // ---- request the next block ----
-    const int seq_next = seq + nwaves;
-    if (seq_next < nblocks) {
-      id = block_id(seq_next);
-      nb = lane < 27 ? t.nbtab[(int64_t)id * 32 + lane] : -1;
-      const int4* own = reinterpret_cast<const int4*>(t.cells + (int64_t)id * kCells) + lane * 2;
-      v0 = own[0];
-      v1 = own[1];
-    }
+      if (vals[z] >= 0) s_own[at++] = (unsigned short)((cell0 + z) * 4);
+    if (lane < 2 * kVoxPerIter) s_own[own_cnt + lane] = (unsigned short)(null_cell * 4);
+    // ---- advance the pipeline: gather for block i+1, head loads for block i+2 ----
+    nb_c = nb_n; c0 = n0; c1 = n1;
+    if (seq + nwaves < nblocks) gather(nb_c, 0);
+    load_head(seq + 2 * nwaves, nb_n, n0, n1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     BSTAMP(2);
     // ---- answer the K probes of the block's voxels: one lane per (voxel, offset) ----
+    const char* grid_bytes = reinterpret_cast<const char*>(s_grid);
     for (int kc = 0; kc < num_chunks; ++kc) {
       const int k = kc * LPR + sub;
       const bool k_real = k < K, k_store = k < kp;
       const int l = k % g.kz, j = (k / g.kz) % g.ky, i = k / (g.kz * g.ky);
       const int ox = (i - g.cx) * g.dx, oy = (j - g.cy) * g.dy, oz = (l - g.cz) * g.dz;
-      const int delta = ox * g.px + oy * g.py + oz;  // grid offset of this lane's kernel offset
-      int32_t* nbr_k = nbr + k;
-      for (int e0 = 0; e0 < own_cnt; e0 += kVoxPerIter) {
-        const int e = e0 + vsel;
-        int found = -1;
-        int row = -1;
-        if (e < own_cnt) {
-          const int cell = s_own[e];
-          row = s_grid[cell];
-          if (k_real) found = s_grid[cell + delta];
-          if (k_store) nbr_k[(int64_t)row * kp] = found;
+      // grid byte offset of this lane's kernel offset; lanes beyond K read the voxel's own cell and ignore it
+      const int delta4 = k_real ? (ox * g.px + oy * g.py + oz) * 4 : 0;
+      const int w0 = (kc * LPR) >> 5;
+      // two voxel groups per trip: two independent LDS chains in flight
+      for (int e0 = 0; e0 < own_cnt; e0 += 2 * kVoxPerIter) {
+        const int cell_a = s_own[e0 + vsel], cell_b = s_own[e0 + kVoxPerIter + vsel];
+        const int row_a = *reinterpret_cast<const int*>(grid_bytes + cell_a);
+        const int row_b = *reinterpret_cast<const int*>(grid_bytes + cell_b);
+        int found_a = *reinterpret_cast<const int*>(grid_bytes + cell_a + delta4);
+        int found_b = *reinterpret_cast<const int*>(grid_bytes + cell_b + delta4);
+        if (!k_real) { found_a = -1; found_b = -1; }
+        const unsigned long long ball_a = __ballot(found_a >= 0), ball_b = __ballot(found_b >= 0);
+        uint32_t bits_a, bits_b, hi_a = 0, hi_b = 0;
+        if (LPR == 64) {
+          bits_a = (uint32_t)ball_a; hi_a = (uint32_t)(ball_a >> 32);
+          bits_b = (uint32_t)ball_b; hi_b = (uint32_t)(ball_b >> 32);
+        } else if (LPR == 32) {
+          bits_a = vsel ? (uint32_t)(ball_a >> 32) : (uint32_t)ball_a;
+          bits_b = vsel ? (uint32_t)(ball_b >> 32) : (uint32_t)ball_b;
+        } else {
+          bits_a = (uint32_t)(ball_a >> (vsel * LPR)) & ((1u << LPR) - 1u);
+          bits_b = (uint32_t)(ball_b >> (vsel * LPR)) & ((1u << LPR) - 1u);
         }
-        const unsigned long long ball = __ballot(found >= 0);
-        if (row >= 0 && sub == 0) {
-          const unsigned long long bits = (LPR == 64) ? ball : ((ball >> (vsel * LPR)) & ((1ull << (LPR & 63)) - 1ull));
-          const int w0 = (kc * LPR) >> 5;
-          if (w0 < mw) mask[(int64_t)row * mw + w0] = (uint32_t)bits;  // also clears the "unwritten" mark
-          if (LPR == 64 && w0 + 1 < mw) mask[(int64_t)row * mw + w0 + 1] = (uint32_t)(bits >> 32);
+        if (FAST) {
+          char* nbr_b = reinterpret_cast<char*>(nbr);
+          char* mask_b = reinterpret_cast<char*>(mask);
+          const uint32_t kp4 = (uint32_t)kp * 4u, mw4 = (uint32_t)mw * 4u, k4 = (uint32_t)k * 4u, w4 = (uint32_t)w0 * 4u;
+          if (row_a >= 0 && k_store) *reinterpret_cast<int*>(nbr_b + (__umul24((uint32_t)row_a, kp4) + k4)) = found_a;
+          if (row_b >= 0 && k_store) *reinterpret_cast<int*>(nbr_b + (__umul24((uint32_t)row_b, kp4) + k4)) = found_b;
+          if (sub == 0 && w0 < mw) {  // also clears the "unwritten" mark
+            if (row_a >= 0) *reinterpret_cast<uint32_t*>(mask_b + (__umul24((uint32_t)row_a, mw4) + w4)) = bits_a;
+            if (row_b >= 0) *reinterpret_cast<uint32_t*>(mask_b + (__umul24((uint32_t)row_b, mw4) + w4)) = bits_b;
+            if (LPR == 64 && w0 + 1 < mw) {
+              if (row_a >= 0) *reinterpret_cast<uint32_t*>(mask_b + (__umul24((uint32_t)row_a, mw4) + w4 + 4u)) = hi_a;
+              if (row_b >= 0) *reinterpret_cast<uint32_t*>(mask_b + (__umul24((uint32_t)row_b, mw4) + w4 + 4u)) = hi_b;
+            }
+          }
+        } else {
+          if (row_a >= 0 && k_store) nbr[(int64_t)row_a * kp + k] = found_a;
+          if (row_b >= 0 && k_store) nbr[(int64_t)row_b * kp + k] = found_b;
+          if (sub == 0 && w0 < mw) {
+            if (row_a >= 0) mask[(int64_t)row_a * mw + w0] = bits_a;
+            if (row_b >= 0) mask[(int64_t)row_b * mw + w0] = bits_b;
+            if (LPR == 64 && w0 + 1 < mw) {
+              if (row_a >= 0) mask[(int64_t)row_a * mw + w0 + 1] = hi_a;
+              if (row_b >= 0) mask[(int64_t)row_b * mw + w0 + 1] = hi_b;
+            }
+          }
         }
       }
     }
@@ -448,8 +501,8 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
     hipLaunchKernelGGL(cell_finish_kernel, dim3((unsigned)wgs), dim3(256), 0, s, (const BSlot*)t.slots, cmask,
                        (const int4*)coords, n, t, g, mw, (const uint32_t*)mask, (int)strict);
   }
-  const int halo_pad = (g.halo_cells + 255) & ~255;
-  const size_t shm = ((size_t)halo_pad + (size_t)(kNbThreads / 64) * (g.cells + kCells / 2)) * 4;
+  const int halo_pad = (g.halo_cells + 63) & ~63;
+  const size_t shm = ((size_t)halo_pad + (size_t)(kNbThreads / 64) * (g.cells + 4 + kCells / 2 + 8)) * 4;
   // resident waves only (the loop strides over the blocks): LDS allows 160 KB / shm workgroups per CU
   int per_cu = (int)((160 * 1024) / (shm + 512));
   if (per_cu > 8) per_cu = 8;
@@ -457,8 +510,16 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   int64_t want = ceil_div(max_blocks < n ? max_blocks : n, kNbThreads / 64);  // never more waves than blocks
   if (want > 256 * per_cu) want = 256 * per_cu;
   const dim3 grid((unsigned)want), block(kNbThreads);
+  const bool fast = n < (1ll << 24) && n * kp * 4 < (1ll << 31);
 #define WCN_CELL_NB(L)                                                                                                 \
-  hipLaunchKernelGGL(cell_neighbors_kernel<L>, grid, block, shm, s, t, (const uint32_t*)t.halo, g, K, kp, mw, nbr, mask)
+  do {                                                                                                                 \
+    if (fast)                                                                                                          \
+      hipLaunchKernelGGL((cell_neighbors_kernel<L, true>), grid, block, shm, s, t, (const uint32_t*)t.halo, g, K, kp,  \
+                         mw, nbr, mask);                                                                               \
+    else                                                                                                               \
+      hipLaunchKernelGGL((cell_neighbors_kernel<L, false>), grid, block, shm, s, t, (const uint32_t*)t.halo, g, K, kp, \
+                         mw, nbr, mask);                                                                               \
+  } while (0)
   switch (lanes_per_row_b(kp)) {
     case 8: WCN_CELL_NB(8); break;
     case 16: WCN_CELL_NB(16); break;

@@ -251,22 +251,37 @@ __global__ __launch_bounds__(kBkThreads) void kmap_scan_kernel(int32_t* __restri
 // (row l/8 + 8j, offsets 4(l%8) .. +3) for j = 0..7.  Instead of transposing them through an LDS tile (8 KB per wave: two
 // workgroups per CU) every holder ranks its own entries against the per-offset row bitmaps of the wave (27 ballots of the
 // mask bits, 256 B of LDS), so the only large LDS buffer is the staging area of the output.
-__global__ __launch_bounds__(kBkThreads) void kmap_scatter_kernel(const int32_t* __restrict__ nbr,
-                                                                  const uint32_t* __restrict__ mask, int64_t m, int K,
-                                                                  int kp, int mw, int64_t ntile,
-                                                                  const int32_t* __restrict__ counts,
-                                                                  const int32_t* __restrict__ offsets,
-                                                                  int32_t* __restrict__ in_maps,
-                                                                  int32_t* __restrict__ out_maps, int64_t pair_capacity,
-                                                                  int32_t* __restrict__ status) {
-  __shared__ int32_t s_in[kStageCap];
-  __shared__ int32_t s_out[kStageCap];
-  __shared__ unsigned long long s_ball[kBkThreads / 64][32];  // rows of the wave that have the offset
-  __shared__ int s_cnt[kBkThreads / 64][32];                  // pairs per (wave, offset), then exclusive over the waves
-  __shared__ int s_seg[33];                                   // first staged position of every offset
-  __shared__ int64_t s_gbase[32];                             // first global position of the tile's pairs of every offset
+struct KsArgs {
+  const int32_t* nbr;
+  const uint32_t* mask;
+  int64_t m;
+  int K, kp, mw;
+  int64_t ntile;
+  const int32_t* counts;
+  const int32_t* offsets;
+  int32_t* in_maps;
+  int32_t* out_maps;
+  int64_t pair_capacity;
+  int32_t* status;
+};
+constexpr size_t kKsLds = (size_t)2 * kStageCap * 4 + 32 * 8 + (size_t)(kBkThreads / 64) * 32 * 12 + 36 * 4;
+
+__device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_id, char* smem) {
+  const int32_t* __restrict__ nbr = q.nbr;
+  const uint32_t* __restrict__ mask = q.mask;
+  const int64_t m = q.m, ntile = q.ntile, pair_capacity = q.pair_capacity;
+  const int K = q.K, kp = q.kp, mw = q.mw;
+  const int32_t* __restrict__ counts = q.counts;
+  const int32_t* __restrict__ offsets = q.offsets;
+  int32_t* __restrict__ in_maps = q.in_maps;
+  int32_t* __restrict__ out_maps = q.out_maps;
+  int32_t* s_in = reinterpret_cast<int32_t*>(smem);
+  int32_t* s_out = s_in + kStageCap;
+  int64_t* s_gbase = reinterpret_cast<int64_t*>(s_out + kStageCap);  // [32] first global position of the tile's pairs of every offset
+  unsigned long long(*s_ball)[32] = reinterpret_cast<unsigned long long(*)[32]>(s_gbase + 32);  // rows of the wave that have the offset
+  int(*s_cnt)[32] = reinterpret_cast<int(*)[32]>(s_ball + kBkThreads / 64);  // pairs per (wave, offset), then exclusive over the waves
+  int* s_seg = reinterpret_cast<int*>(s_cnt + kBkThreads / 64);               // [33] first staged position of every offset
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t tile_id = blockIdx.x;
   const int64_t row0 = tile_id * kTileRows + wave * 64;
   const int64_t row = row0 + lane;
   bool overflow = false;
@@ -360,7 +375,12 @@ __global__ __launch_bounds__(kBkThreads) void kmap_scatter_kernel(const int32_t*
     }
     __syncthreads();  // the next word rewrites the bitmaps and the staging area
   }
-  if (overflow) atomicOr(status, (int)WCN_FLAG_PAIR_OVERFLOW);
+  if (overflow) atomicOr(q.status, (int)WCN_FLAG_PAIR_OVERFLOW);
+}
+
+__global__ __launch_bounds__(kBkThreads) void kmap_scatter_kernel(KsArgs q) {
+  extern __shared__ char s_ks[];
+  kmap_scatter_body(q, blockIdx.x, s_ks);
 }
 
 static inline bool valid_k(int32_t k) { return k >= 1 && k <= 4096; }
@@ -459,9 +479,21 @@ int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_off
   if (binned_workspace) cells = carve_cells(binned_workspace, binned_n, max_blocks);
   launch_tally(mask, nbr, m, num_offsets, counts, true, plan.nblk, plan.counts, coords, binned_workspace ? &cells : nullptr,
                status, s);
-  launch_scan(counts, wcn_kmap_num_blocks(m), num_offsets, offsets, status, host_mirror, plan.nblk, plan.counts, plan.totals, s);
-  sort_run(plan, mask, wcn_kmap_mask_words(num_offsets), m, perm, true, s);
+  launch_scan(counts, wcn_kmap_num_blocks(m), num_offsets, offsets, status, host_mirror, plan.nblk, plan.counts,
+              plan.totals, s);
+  RsLaunch l[12];
+  const int count = sort_launches(plan, mask, wcn_kmap_mask_words(num_offsets), m, perm, true, l);
+  sort_run_range(l, 0, count, s);
   return launch_status();
+}
+
+static KsArgs ks_args(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t K, const int32_t* counts,
+                      const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status) {
+  KsArgs q;
+  q.nbr = nbr; q.mask = mask; q.m = m; q.K = K; q.kp = wcn_kmap_row_pitch(K); q.mw = wcn_kmap_mask_words(K);
+  q.ntile = wcn_kmap_num_blocks(m); q.counts = counts; q.offsets = offsets; q.in_maps = in_maps; q.out_maps = out_maps;
+  q.pair_capacity = pair_capacity; q.status = status;
+  return q;
 }
 
 int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets, const int32_t* counts,
@@ -471,10 +503,9 @@ int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_
   if (m == 0) return WCN_SUCCESS;
   if (!nbr || !mask || !counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps)))
     return WCN_ERROR_INVALID_PARAMETERS;
-  const int K = num_offsets, kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
-  const int64_t ntile = wcn_kmap_num_blocks(m);
-  hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(m, kTileRows)), dim3(kBkThreads), 0, (hipStream_t)stream,
-                     nbr, mask, m, K, kp, mw, ntile, counts, offsets, in_maps, out_maps, pair_capacity, status);
+  const KsArgs q = ks_args(nbr, mask, m, num_offsets, counts, offsets, in_maps, out_maps, pair_capacity, status);
+  hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(m, kTileRows)), dim3(kBkThreads), kKsLds,
+                     (hipStream_t)stream, q);
   return launch_status();
 }
 

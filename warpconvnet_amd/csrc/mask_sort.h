@@ -1,5 +1,19 @@
-// mask_sort.h - internal interface of the mask radix sort (mask_sort.hip), shared with the kernel-map tally pass
-// (kmap_bucket.hip), which counts and scans the first digit while it reads the masks anyway.
+// mask_sort.h - stable LSD radix argsort of the neighbour masks (descending), hand-written for wave64: the kernel BODIES
+// (shared with kmap_bucket.hip, which counts / scans the first digit inside its tally pass and co-schedules the pair
+// scatter with the later passes) and the launch plan.
+//
+// perm = rows ordered by DESCENDING mask word 0, ties in ascending row order.  Rows with the same neighbourhood
+// pattern become adjacent, so a wavefront of the gather-GEMM can skip absent offsets.
+// Reference counterpart: mask_argsort_uint32 (warpconvnet/csrc/mask_data_kernels.cu:187-220, CUB radix sort).
+//
+// 9-bit digits (512 bins) => 3 passes for the 27-bit masks of a 3x3x3 kernel (4 for 32 bits).  Per pass:
+//   hist     block-local LDS histogram of its 2048-key tile              -> counts[digit][block]
+//   scan     one workgroup per digit: exclusive scan over blocks + digit total (digit bases are scanned in the
+//            scatter prologue)                                           -> global base of every (digit, block)
+//   scatter  wave w owns a contiguous quarter of the tile; per-wave digit counts give each wave its base, then keys
+//            are ranked 64 at a time: lanes with equal digits find each other with 9 ballots ("match-any"),
+//            rank = popcount(peers & lower lanes); the running base lives in LDS.  Stable by construction.
+// Descending order = ascending order of the inverted key.
 #pragma once
 
 #include "wcn_common.h"
@@ -10,9 +24,32 @@ constexpr int kRsBits = 9;
 constexpr int kRsBins = 1 << kRsBits;
 constexpr int kRsTile = 2048;
 constexpr int kRsThreads = 256;
+constexpr int kRsWaves = kRsThreads / 64;
+constexpr int kRsPerWave = kRsTile / kRsWaves;  // 512 keys, 8 batches of 64
+constexpr size_t kRsScatterLds = (size_t)(kRsWaves * kRsBins + kRsBins + kRsWaves) * 4;
 
-// descending order = ascending order of the inverted key
 __device__ __forceinline__ uint32_t rs_digit(uint32_t key, int shift) { return ((~key) >> shift) & (kRsBins - 1); }
+
+enum RsRole { kRsHist = 0, kRsScan = 1, kRsScatter = 2 };
+
+struct RsArgs {
+  const uint32_t* kin;  // first pass: the mask tensor itself (stride = mask words); later passes: the ping-pong buffer
+  int64_t stride;
+  const int32_t* vin;   // carried row ids (null: identity)
+  int64_t n;
+  int shift;
+  int nblk;
+  int32_t* counts;      // [kRsBins][nblk]
+  int32_t* totals;      // [kRsBins]
+  uint32_t* kout;
+  int32_t* vout;
+};
+
+struct RsLaunch {
+  int role;
+  int blocks;
+  RsArgs a;
+};
 
 struct SortPlan {
   int nblk;           // tiles of kRsTile keys
@@ -25,8 +62,152 @@ struct SortPlan {
 };
 
 SortPlan sort_plan(void* workspace, int64_t n, int num_bits);
-// `first_counted`: counts / totals already hold the scanned histogram of the first digit
-void sort_run(const SortPlan& plan, const uint32_t* mask, int mask_words, int64_t n, int32_t* perm, bool first_counted,
-              hipStream_t stream);
+// every launch of the sort, in order (at most 3 per pass); `first_counted`: counts / totals already hold the scanned
+// histogram of the first digit, so the first pass is its scatter alone
+int sort_launches(const SortPlan& plan, const uint32_t* mask, int mask_words, int64_t n, int32_t* perm, bool first_counted,
+                  RsLaunch out[12]);
+void sort_run_range(const RsLaunch* launches, int begin, int end, hipStream_t stream);
+
+// ---- kernel bodies: `blk` = tile / digit index, `smem` >= 2 KB (hist), 16 B (scan), kRsScatterLds (scatter) ----
+__device__ __forceinline__ void rs_hist_body(const RsArgs& a, int blk, char* smem) {
+  int* s_hist = reinterpret_cast<int*>(smem);
+  for (int i = threadIdx.x; i < kRsBins; i += kRsThreads) s_hist[i] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blk * kRsTile;
+  // all of a thread's keys are requested before the first one is used: predicated loads inside the loop are waited for
+  // one at a time (8 memory round trips instead of 1)
+  constexpr int kPer = kRsTile / kRsThreads;
+  uint32_t k[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const int64_t idx = base + threadIdx.x + j * kRsThreads;
+    k[j] = a.kin[(idx < a.n ? idx : a.n - 1) * a.stride];
+  }
+#pragma unroll
+  for (int j = 0; j < kPer; ++j)
+    if (base + threadIdx.x + j * kRsThreads < a.n) atomicAdd(&s_hist[rs_digit(k[j], a.shift)], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kRsBins; i += kRsThreads) a.counts[(int64_t)i * a.nblk + blk] = s_hist[i];
+}
+
+// one workgroup per digit: exclusive scan of counts[d][0..nblk) in place, totals[d] = row sum
+__device__ __forceinline__ void rs_scan_body(const RsArgs& a, int digit, char* smem) {
+  int* s_part = reinterpret_cast<int*>(smem);
+  int32_t* row = a.counts + (int64_t)digit * a.nblk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (a.nblk + kRsThreads - 1) / kRsThreads;
+  const int b0 = tid * chunk;
+  const int b1 = (b0 + chunk < a.nblk) ? (b0 + chunk) : a.nblk;
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += row[b];
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  int run = incl - sum;
+  for (int w = 0; w < wave; ++w) run += s_part[w];
+  for (int b = b0; b < b1; ++b) {
+    const int v = row[b];
+    row[b] = run;
+    run += v;
+  }
+  if (tid == kRsThreads - 1) a.totals[digit] = run;
+}
+
+__device__ __forceinline__ void rs_scatter_body(const RsArgs& a, int blk, char* smem) {
+  int* s_base = reinterpret_cast<int*>(smem);  // [kRsWaves][kRsBins] per-wave digit counts, then running output positions
+  int* s_dstart = s_base + kRsWaves * kRsBins;  // first output position of every digit (scan of the digit totals)
+  int* s_wsum = s_dstart + kRsBins;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t wave_begin = (int64_t)blk * kRsTile + (int64_t)wave * kRsPerWave;
+  // the wave's 8 x 64 keys (and carried values) are requested up front and kept in registers: the ranking loop below is a
+  // serial chain through LDS, and a global load inside it costs one memory round trip per 64 keys
+  constexpr int kBatches = kRsPerWave / 64;
+  uint32_t kreg[kBatches];
+  int32_t vreg[kBatches];
+#pragma unroll
+  for (int j = 0; j < kBatches; ++j) {
+    const int64_t idx = wave_begin + j * 64 + lane;
+    const int64_t at = idx < a.n ? idx : a.n - 1;
+    kreg[j] = a.kin[at * a.stride];
+    vreg[j] = a.vin ? a.vin[at] : (int32_t)at;
+  }
+  // ... and so are the digit totals and this block's (digit, block) bases: everything the kernel reads from global memory
+  // is in flight at once
+  const int t0 = a.totals[2 * tid], t1 = a.totals[2 * tid + 1];
+  int blk_base[kRsBins / kRsThreads];
+#pragma unroll
+  for (int j = 0; j < kRsBins / kRsThreads; ++j) blk_base[j] = a.counts[(int64_t)(tid + j * kRsThreads) * a.nblk + blk];
+  {  // exclusive scan of the 512 digit totals: 2 per thread, wave scan, 4 wave partials
+    int incl = t0 + t1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - (t0 + t1);
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    s_dstart[2 * tid] = base;
+    s_dstart[2 * tid + 1] = base + t0;
+  }
+  for (int i = tid; i < kRsWaves * kRsBins; i += kRsThreads) s_base[i] = 0;
+  __syncthreads();
+  // phase 1: digit counts of this wave's sub-tile
+#pragma unroll
+  for (int j = 0; j < kBatches; ++j)
+    if (wave_begin + j * 64 + lane < a.n) atomicAdd(&s_base[wave * kRsBins + rs_digit(kreg[j], a.shift)], 1);
+  __syncthreads();
+  // phase 2: counts -> starting positions (global base of (digit, block) + waves before this one)
+#pragma unroll
+  for (int j = 0; j < kRsBins / kRsThreads; ++j) {
+    const int d = tid + j * kRsThreads;
+    int run = s_dstart[d] + blk_base[j];
+#pragma unroll
+    for (int w = 0; w < kRsWaves; ++w) {
+      const int c = s_base[w * kRsBins + d];
+      s_base[w * kRsBins + d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  // phase 3: rank 64 keys at a time, in order
+  volatile int* my_base = s_base + wave * kRsBins;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < kBatches; ++j) {
+    const int64_t idx = wave_begin + j * 64 + lane;
+    const bool live = idx < a.n;
+    const uint32_t key = kreg[j];
+    const uint32_t d = live ? rs_digit(key, a.shift) : 0u;
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < kRsBits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long ball = __ballot(bit);
+      peers &= bit ? ball : ~ball;
+    }
+    if (live) {
+      const int rank = __popcll(peers & lt);
+      const int pos = my_base[d] + rank;
+      a.kout[pos] = key;
+      a.vout[pos] = vreg[j];
+      // the last peer advances the running base after every peer has read it (same wave, LDS ops are in order)
+      if ((peers >> lane) == 1ull) my_base[d] = pos + 1;
+    }
+  }
+}
+
+template <int ROLE>
+__device__ __forceinline__ void rs_body(const RsArgs& a, int blk, char* smem) {
+  if (ROLE == kRsHist) rs_hist_body(a, blk, smem);
+  else if (ROLE == kRsScan) rs_scan_body(a, blk, smem);
+  else rs_scatter_body(a, blk, smem);
+}
 
 }  // namespace wcn

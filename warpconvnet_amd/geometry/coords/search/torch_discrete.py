@@ -267,6 +267,8 @@ def generate_kernel_map(
         offsets_host = meta_host[: K + 1].clone()
         pair_capacity = int(offsets_host[-1])
         has_duplicates = bool(flags & _lib.WCN_FLAG_DUPLICATE_COORD)
+    if has_duplicates and same_tensor:
+        identity = None  # "output row i == input row i at the centre offset" fails for the rows that lost their coordinate
     in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
     out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
     _lib.check(
@@ -287,6 +289,9 @@ def generate_kernel_map(
     # and maps whose flags have not arrived yet (async mode) - take the explicit reverse table instead.
     result._symmetric = bool(same_tensor and odd and unit_stride and not has_duplicates)
     result._self_exact = result._symmetric
+    # duplicate OUTPUT rows (a submanifold map over repeated coordinates) share their input rows per offset: the
+    # [N_in, K] reverse table has one slot per (input row, offset), so dgrad then goes through the pair lists
+    result._has_duplicates = bool(same_tensor and has_duplicates)
     result._num_in, result._num_out = N, M
     result._hashtable = table
     result._kernel_size = ksize

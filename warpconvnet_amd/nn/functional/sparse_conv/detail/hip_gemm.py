@@ -201,6 +201,21 @@ def hip_colsum(t: Tensor) -> Tensor:
     return out
 
 
+def _dgrad_pair_lists(dy: Tensor, w: Tensor, kernel_map: IntSearchResult, num_in: int) -> Tensor:
+    """Input gradient of a map built over REPEATED coordinates (degenerate input: `Voxels.unique()` removes it).  Several
+    output rows then pair with one input row at the same offset, which neither the k-flipped forward table nor the
+    one-slot-per-(row, offset) reverse table can express: scatter-add over the pair lists, fp32 accumulation - the
+    reference's own explicit formulation (`explicit.py:60-92`).  Correct, not fast."""
+    K, cin, cout = w.shape
+    dx = torch.zeros(num_in, cin, dtype=torch.float32, device=dy.device)
+    wf = w.float()
+    for k in range(K):
+        in_map, out_map = kernel_map[k]
+        if in_map.shape[0]:
+            dx.index_add_(0, in_map.long(), dy[out_map.long()].float() @ wf[k].T)
+    return dx.to(dy.dtype)
+
+
 def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_in_coords: int,
               algo: str = "auto") -> Tensor:
     """dx[n] = sum_k dy[rev[n][k]] @ w[k]^T; a submanifold map reuses the forward table with k reversed."""
@@ -209,6 +224,8 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
         raise RuntimeError(f"hip dgrad error: {_lib.status_string(-6)} ({dy.dtype} vs {w.dtype})")
     K, cin, cout = w.shape
     kernel_map.poll()
+    if getattr(kernel_map, "_has_duplicates", False):
+        return _dgrad_pair_lists(dy, w, kernel_map, num_in_coords)
     attach_tables_from_csr(kernel_map, num_in_coords, dy.shape[0])
     if kernel_map._symmetric:
         tbl, mask, perm, flip = kernel_map._nbr, kernel_map._mask, kernel_map._perm, True

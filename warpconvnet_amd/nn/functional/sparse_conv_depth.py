@@ -139,7 +139,16 @@ def _implicit_depthwise_backward_logic(grad_output: Tensor, in_features: Tensor,
     fwd_tbl = _tables(kernel_map, n_in, n_out)
     dx = dw = None
     if needs[0]:
-        if kernel_map._symmetric:
+        if getattr(kernel_map, "_has_duplicates", False):
+            # repeated coordinates (degenerate input): several output rows pair with one input row per offset, which the
+            # one-slot-per-(row, offset) tables cannot express -> scatter-add over the pair lists (reference formulation)
+            dxf = torch.zeros(n_in, C, dtype=torch.float32, device=dev)
+            for k in range(K):
+                in_map, out_map = kernel_map[k]
+                if in_map.shape[0]:
+                    dxf.index_add_(0, in_map.long(), g[out_map.long()].float() * w[k].float())
+            dx = dxf
+        elif kernel_map._symmetric:
             dx = _hip_gather(g, w, fwd_tbl, n_in, K, True)  # rev[n][k] == nbr[n][K-1-k] for a submanifold map
         else:
             rev_tbl, _, _ = reverse_tables(kernel_map, n_in)
