@@ -106,6 +106,208 @@ def cpu_baseline(n_sample, seed):
                        f"+ fwd+bwd {t3 - t2:.2f}s (torch CPU, {torch.get_num_threads()} threads)")
 
 
+def secondary_configs(dev):
+    """BASELINE configs 3 and 5 as secondary figures of the same run (never the headline): MinkUNet-14 forward + backward
+    on surface scenes of 200 k and 1 M voxels, and PointConv(32->64, kNN 16) on 200 k points followed by voxelisation and
+    a depthwise k=3 convolution, forward + backward.  Milliseconds per iteration (HIP events, 3 warm-up + 5 timed)."""
+    from tests.minkunet14 import MinkUNet14
+    from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
+    from warpconvnet_amd.geometry.types.points import Points
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules import PointConv, SparseDepthwiseConv3d
+
+    out = {}
+    torch.manual_seed(0)
+    net = MinkUNet14(3, 20).to(dev)
+    for label, n_vox in (("200k", 200_000), ("1M", 1_000_000)):
+        c = torch.from_numpy(scene_surface(n_vox, seed=3)).to(dev)
+        n = c.shape[0]
+        f = torch.randn(n, 3, device=dev)
+        off = torch.tensor([0, n], dtype=torch.int32)
+
+        def unet_step():
+            net.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(Voxels(c, f, offsets=off))
+            y.feature_tensor.float().square().mean().backward()
+
+        out[f"minkunet14_{label}_ms"] = round(time_events(unet_step, 5, warmup=3), 3)
+        out[f"minkunet14_{label}_voxels"] = n
+    g = torch.Generator().manual_seed(5)
+    n = 200_000
+    pts = (torch.rand(n, 3, generator=g) * torch.tensor([50.0, 50.0, 4.0])).to(dev)
+    pf = torch.randn(n, 32, generator=g).to(dev)
+    torch.manual_seed(0)
+    pconv = PointConv(32, 64, RealSearchConfig(mode="knn", knn_k=16)).to(dev)
+    dw = SparseDepthwiseConv3d(64, 3).to(dev)
+
+    def point_step():
+        pconv.zero_grad(set_to_none=True)
+        dw.zero_grad(set_to_none=True)
+        o = pconv(Points(pts, pf, offsets=torch.tensor([0, n])))
+        y = dw(o.to_voxels(0.25))
+        y.feature_tensor.sum().backward()
+
+    out["pointconv_dw_ms"] = round(time_events(point_step, 5, warmup=3), 3)
+    out["pointconv_dw_points"] = n
+    return out
+
+
+def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, value, ms_per_step):
+    """Rank 0: per-kernel timing IN THE STEP (HIP events on the launch stream between the four phases of an unrolled step,
+    so every kernel meets the cache state it meets in the module step), roofline figures, secondary configs, CPU baseline."""
+    from warpconvnet_amd import _lib
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    bcoords = torch.cat([torch.zeros(N, 1, dtype=torch.int32, device=dev), coords], 1).contiguous()
+    km = generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3))
+    L = int(km.offsets[-1])
+    X = feats.detach()
+    W = conv.weight.detach().to(torch.bfloat16)
+    it = max(5, args.steps)
+    Lc = _lib.lib()
+    stream = _lib.stream_handle(dev)
+    wp_f = hip_gemm.pack_weight(W, False, False)
+    wp_d = hip_gemm.pack_weight(W, True, True)
+    y_buf = torch.empty(N, COUT, dtype=torch.bfloat16, device=dev)
+    dx_buf = torch.empty(N, CIN, dtype=torch.bfloat16, device=dev)
+    dw_buf = torch.empty(KVOL, CIN, COUT, dtype=torch.float32, device=dev)
+    db_buf = torch.empty(COUT, dtype=torch.float32, device=dev)
+    ws_bytes = Lc.wcn_conv_wgrad_workspace(KVOL, CIN, COUT, _lib.WCN_ALGO_MFMA)
+    ws_buf = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    bias = conv.bias.detach().float()
+
+    def k_fwd(m):
+        Lc.wcn_conv_gather_gemm(_lib.ptr(X), _lib.ptr(wp_f), _lib.ptr(y_buf), _lib.ptr(m._nbr), _lib.ptr(m._mask),
+                                _lib.ptr(m._perm), _lib.ptr(bias), N, N, CIN, COUT, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 0, 0, stream)
+
+    def k_dgrad(m):
+        Lc.wcn_conv_gather_gemm(_lib.ptr(grad_out), _lib.ptr(wp_d), _lib.ptr(dx_buf), _lib.ptr(m._nbr), _lib.ptr(m._mask),
+                                _lib.ptr(m._perm), None, N, N, COUT, CIN, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 1, 1, stream)
+
+    def k_wgrad(m):
+        # the weight-gradient entry point as the training step calls it (bias gradient fused): main kernel + the two
+        # small fixed-order reduce kernels
+        Lc.wcn_conv_wgrad_bias(_lib.ptr(X), _lib.ptr(grad_out), _lib.ptr(dw_buf), _lib.ptr(m.in_maps_device),
+                               _lib.ptr(m.out_maps_device), _lib.ptr(m._offsets_dev), N, N, CIN, COUT, KVOL, _lib.WCN_BF16,
+                               KVOL // 2, _lib.ptr(db_buf), _lib.ptr(ws_buf), ws_bytes, stream)
+
+    # ---- unrolled step: map build -> forward -> dgrad -> wgrad back to back, one event between the phases ----
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(it)]
+    for rep in range(-2, it):
+        e = ev[max(rep, 0)]
+        e[0].record()
+        m = generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3))
+        e[1].record()
+        k_fwd(m)
+        e[2].record()
+        k_dgrad(m)
+        e[3].record()
+        k_wgrad(m)
+        e[4].record()
+    torch.cuda.synchronize()
+    in_step = [float(np.mean([ev[r][p].elapsed_time(ev[r][p + 1]) for r in range(it)])) for p in range(4)]
+    t_kmap, tk_fwd, tk_dgrad, tk_wgrad = in_step
+    # isolated figures (back-to-back launches of one kernel find part of their operands in the 256 MiB Infinity Cache):
+    # reported next to the in-step ones, never used for the roofline
+    iso = {"fwd": time_events(lambda: k_fwd(km), it), "dgrad": time_events(lambda: k_dgrad(km), it),
+           "wgrad": time_events(lambda: k_wgrad(km), it),
+           "kmap": time_events(lambda: generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3)), it)}
+
+    ab = algorithmic_bytes(N, L)
+    e = 2
+    comp = {  # compulsory traffic (SURVEY §8d): every L*C term replaced by N*C - what an ideal cache would leave
+        "kmap": ab["kmap"],
+        "fwd": N * CIN * e + KVOL * CIN * COUT * e + N * COUT * e + 4 * KVOL * N,
+        "dgrad": N * COUT * e + KVOL * CIN * COUT * e + N * CIN * e + 4 * KVOL * N,
+        "wgrad": N * (CIN + COUT) * e + 4 * KVOL * CIN * COUT + 4 * KVOL * N,
+    }
+    names = {
+        "fwd": "gather_gemm_mfma_kernel<bf16,64,128> (fwd)",
+        "dgrad": "gather_gemm_mfma_kernel<bf16,64,64> (dgrad)",
+        "wgrad": "wgrad_mfma_kernel<bf16,64,128> (+ wgrad_reduce)",
+        "kmap": "kernel map build (all launches)",
+    }
+    times = {"fwd": tk_fwd, "dgrad": tk_dgrad, "wgrad": tk_wgrad, "kmap": t_kmap}
+
+    def entry(key):
+        ms = times[key]
+        return {"achieved": round(ab[key] / (ms * 1e-3) / 1e9, 1), "frac": round(ab[key] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "compulsory_frac": round(comp[key] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
+                "isolated_ms": round(iso[key], 4), "algorithmic_bytes_per_launch": int(ab[key])}
+
+    # the dominant kernel = the GEMM with the largest IN-STEP time (stable: dgrad moves the most bytes)
+    dom_key = max(("fwd", "dgrad", "wgrad"), key=lambda k: times[k])
+    dom = entry(dom_key)
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    if N == 1_000_000 and args.scene == "uniform" and os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            pmc = json.load(f)
+        if dom_key in pmc:
+            traffic = pmc[dom_key]["hbm_bytes"]
+            traffic_src = "profiles/r02_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+
+    # map-cached variant (SURVEY §8d: networks amortise the map over the layers of a resolution level)
+    x_cached = Voxels(coords, feats, offsets=offsets)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        conv(x_cached)  # fills x_cached.cache
+
+    def cached_step():
+        for p in params:
+            p.grad = None
+        feats.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yc = conv(x_cached)
+        yc.batched_features.batched_tensor.backward(grad_out)
+
+    t_cached = time_events(cached_step, it)
+    total_bytes = sum(ab.values())
+    result = {
+        "metric": "M active voxels/sec fwd+bwd, SparseConv3d 64\u2192128 k=3, 1/2/4/8 MI355X",  # = BASELINE.json:metric
+        "value": round(value, 3),
+        "unit": "M voxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[1]: one {N}-voxel {'uniform (U)' if args.scene == 'uniform' else 'surface-like (S, secondary)'} scene per GPU, SparseConv3d 64->128 k=3, bf16 autocast, "
+                        "kernel-map build + AB fwd + ABt dgrad + AtB wgrad per step",
+            "voxels_per_gpu": N, "pairs_per_scene": L, "coord_order": args.coord_order, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": names[dom_key], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["frac"], "compulsory_frac": dom["compulsory_frac"], "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
+            "timing": "HIP events on the launch stream between the phases of an unrolled step (map build -> fwd -> dgrad -> wgrad), "
+                      "i.e. in-step; profiles/r02_kernel_trace_stats.md is the rocprofv3 trace of this command",
+        },
+        "roofline_all": {names[k]: entry(k) for k in ("fwd", "dgrad", "wgrad", "kmap")},
+        "phases_ms": {"kmap": round(t_kmap, 4), "fwd_kernel": round(tk_fwd, 4), "dgrad_kernel": round(tk_dgrad, 4),
+                      "wgrad_kernels": round(tk_wgrad, 4), "sum": round(sum(in_step), 4)},
+        "whole_step_hbm_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "whole_step_compulsory_hbm_frac": round(sum(comp.values()) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "map_cached": {"value": round(N / (t_cached * 1e-3) / 1e6, 3), "unit": "M voxels/s", "ms_per_step": round(t_cached, 4),
+                       "note": "same step with the kernel map taken from the geometry's cache (fwd + dgrad + wgrad only)"},
+    }
+    if world == 1 and not args.no_secondary:
+        try:
+            result["secondary"] = secondary_configs(dev)
+        except Exception as exc:  # the headline line must come out even if a secondary workload fails
+            result["secondary"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +316,7 @@ def main():
     ap.add_argument("--voxels", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)  # the whole configs[1] scene: ~10-15 s of CPU work
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the MinkUNet-14 / PointConv secondary timings")
     ap.add_argument("--coord-order", choices=["generator", "block"], default="generator",
                     help="generator: rows in the order the reference's generator emits them (the headline workload); "
                          "block: the same scene with rows sorted by 16^3 block then x,y,z (what a voxelised scan looks like) - "
@@ -191,123 +394,7 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- per-phase / per-kernel timing with HIP events on the launch stream (rank 0) ----
-        from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
-
-        bcoords = torch.cat([torch.zeros(N, 1, dtype=torch.int32, device=dev), coords], 1).contiguous()
-        km = generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3))
-        L = int(km.offsets[-1])
-        X = feats.detach()
-        W = conv.weight.detach().to(torch.bfloat16)
-        it = max(5, args.steps)
-        t_kmap = time_events(lambda: generate_kernel_map(bcoords, bcoords, (1, 1, 1), (3, 3, 3)), it)
-        t_fwd = time_events(lambda: hip_gemm.hip_forward(X, W, km, N, "hip_mfma"), it)
-        t_dgrad = time_events(lambda: hip_gemm.hip_dgrad(grad_out, W, km, N, "hip_mfma"), it)
-        t_wgrad = time_events(lambda: hip_gemm.hip_wgrad(X, grad_out, km, (KVOL, CIN, COUT), "hip_mfma"), it)
-        # dominant kernel alone: exactly one launch per event pair (weights pre-packed)
-        Lc = _lib.lib()
-        stream = _lib.stream_handle(dev)
-        wp_f = hip_gemm.pack_weight(W, False, False)
-        wp_d = hip_gemm.pack_weight(W, True, True)
-        y_buf = torch.empty(N, COUT, dtype=torch.bfloat16, device=dev)
-        dx_buf = torch.empty(N, CIN, dtype=torch.bfloat16, device=dev)
-
-        def k_fwd():
-            Lc.wcn_conv_gather_gemm(_lib.ptr(X), _lib.ptr(wp_f), _lib.ptr(y_buf), _lib.ptr(km._nbr), _lib.ptr(km._mask),
-                                    _lib.ptr(km._perm), None, N, N, CIN, COUT, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 0, 0, stream)
-
-        def k_dgrad():
-            Lc.wcn_conv_gather_gemm(_lib.ptr(grad_out), _lib.ptr(wp_d), _lib.ptr(dx_buf), _lib.ptr(km._nbr), _lib.ptr(km._mask),
-                                    _lib.ptr(km._perm), None, N, N, COUT, CIN, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 1, 1, stream)
-
-        # the weight-gradient entry point as the training step calls it (bias gradient fused): main kernel + the two
-        # small fixed-order reduce kernels, nothing else inside the event pair
-        dw_buf = torch.empty(KVOL, CIN, COUT, dtype=torch.float32, device=dev)
-        db_buf = torch.empty(COUT, dtype=torch.float32, device=dev)
-        ws_bytes = Lc.wcn_conv_wgrad_workspace(KVOL, CIN, COUT, _lib.WCN_ALGO_MFMA)
-        ws_buf = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-
-        def k_wgrad():
-            Lc.wcn_conv_wgrad_bias(_lib.ptr(X), _lib.ptr(grad_out), _lib.ptr(dw_buf), _lib.ptr(km.in_maps_device),
-                                   _lib.ptr(km.out_maps_device), _lib.ptr(km._offsets_dev), N, N, CIN, COUT, KVOL, _lib.WCN_BF16,
-                                   KVOL // 2, _lib.ptr(db_buf), _lib.ptr(ws_buf), ws_bytes, stream)
-
-        tk_fwd, tk_dgrad, tk_wgrad = time_events(k_fwd, it), time_events(k_dgrad, it), time_events(k_wgrad, it)
-        ab = algorithmic_bytes(N, L)
-        kernels = {
-            "gather_gemm_mfma_kernel<bf16,64,128> (fwd)": (tk_fwd, ab["fwd"]),
-            "gather_gemm_mfma_kernel<bf16,64,64> (dgrad)": (tk_dgrad, ab["dgrad"]),
-            "wgrad_mfma_kernel<bf16,64,128> (+ wgrad_reduce)": (tk_wgrad, ab["wgrad"]),
-        }
-        dom = max(kernels, key=lambda k: kernels[k][0])
-        dom_ms, dom_bytes = kernels[dom]
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process;
-        # tools/collect_profiles.sh + tools/rocpd_stats.py produce the file from this very command line)
-        # map-cached variant (networks amortise the map over the layers of a resolution level): the same
-        # module step on a geometry whose cache already holds the kernel map - GEMMs only, through autograd
-        x_cached = Voxels(coords, feats, offsets=offsets)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            conv(x_cached)  # fills x_cached.cache
-
-        def cached_step():
-            for p in params:
-                p.grad = None
-            feats.grad = None
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                yc = conv(x_cached)
-            yc.batched_features.batched_tensor.backward(grad_out)
-
-        t_cached = time_events(cached_step, it)
-        # compulsory-traffic lower bound: every L*C term replaced by N*C - what an ideal cache would leave
-        e = 2
-        compulsory = (ab["kmap"]
-                      + (N * CIN * e + KVOL * CIN * COUT * e + N * COUT * e + 4 * KVOL * N)
-                      + (N * COUT * e + KVOL * CIN * COUT * e + N * CIN * e + 4 * KVOL * N)
-                      + (N * (CIN + COUT) * e + 4 * KVOL * CIN * COUT + 4 * KVOL * N))
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if N == 1_000_000 and args.scene == "uniform" and os.path.exists(pmc_file):
-            with open(pmc_file) as f:
-                pmc = json.load(f)
-            key = "fwd" if "(fwd)" in dom else ("dgrad" if "(dgrad)" in dom else "wgrad")
-            traffic, traffic_src = pmc[key]["hbm_bytes"], "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)"
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        total_bytes = sum(ab.values())
-        result = {
-            "metric": "M active voxels/sec fwd+bwd, SparseConv3d 64\u2192128 k=3, 1/2/4/8 MI355X",  # = BASELINE.json:metric
-            "value": round(value, 3),
-            "unit": "M voxels/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic",
-            "config": {
-                "workload": f"configs[1]: one {N}-voxel {'uniform (U)' if args.scene == 'uniform' else 'surface-like (S, secondary)'} scene per GPU, SparseConv3d 64->128 k=3, bf16 autocast, "
-                            "kernel-map build + AB fwd + ABt dgrad + AtB wgrad per step",
-                "voxels_per_gpu": N, "pairs_per_scene": L, "coord_order": args.coord_order, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)",
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
-            },
-            "roofline_all": {name: {"achieved": round(b / (ms * 1e-3) / 1e9, 1), "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(b)}
-                             for name, (ms, b) in {**kernels, "kernel map build (~20 launches)": (t_kmap, ab["kmap"])}.items()},
-            "phases_ms": {"kmap": round(t_kmap, 4), "fwd": round(t_fwd, 4), "dgrad": round(t_dgrad, 4), "wgrad": round(t_wgrad, 4),
-                          "fwd_kernel_only": round(tk_fwd, 4), "dgrad_kernel_only": round(tk_dgrad, 4), "wgrad_kernels_only": round(tk_wgrad, 4)},
-            "whole_step_hbm_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "whole_step_compulsory_hbm_frac": round(compulsory / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "map_cached": {"value": round(N / (t_cached * 1e-3) / 1e6, 3), "unit": "M voxels/s", "ms_per_step": round(t_cached, 4),
-                           "note": "same step with the kernel map taken from the geometry's cache (fwd + dgrad + wgrad only)"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)
+        result = report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, value, ms_per_step)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

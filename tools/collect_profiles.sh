@@ -1,13 +1,25 @@
 #!/bin/bash
-# Runs ON the GPU box (through gpurun): rocprofv3 kernel trace + separate PMC passes of the default bench command.
-# Summaries are produced afterwards with tools/rocpd_stats.py from the merged gpurun_out/prof/*.db files.
+# Runs ON the GPU box (through gpurun): rocprofv3 kernel trace + separate PMC passes of the default bench command
+# (counters in their own runs, never combined with runtime / marker traces), summaries into gpurun_out/prof/ as text.
+# Usage: bash tools/collect_profiles.sh [round-tag, default r02]
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof
-CMD="python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r01_trace -- $CMD > gpurun_out/prof/r01_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof -o r01_fetch -- $CMD > gpurun_out/prof/r01_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof -o r01_write -- $CMD > gpurun_out/prof/r01_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d gpurun_out/prof -o r01_mfma -- $CMD > gpurun_out/prof/r01_mfma.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d gpurun_out/prof -o r01_l2 -- $CMD > gpurun_out/prof/r01_l2.log 2>&1
-grep -h metric gpurun_out/prof/r01_trace.log | tail -1
-ls -la gpurun_out/prof | grep r01_
+CMD="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${R}_trace -- $CMD > gpurun_out/prof/${R}_trace.log 2>&1
+grep -h '"metric"' gpurun_out/prof/${R}_trace.log | tail -1 > gpurun_out/prof/${R}_bench_line.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof -o ${R}_fetch -- $CMD > gpurun_out/prof/${R}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof -o ${R}_write -- $CMD > gpurun_out/prof/${R}_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d gpurun_out/prof -o ${R}_mfma -- $CMD > gpurun_out/prof/${R}_mfma.log 2>&1
+# secondary workloads (MinkUNet-14 at 200 k / 1 M voxels, PointConv + depthwise): kernel trace of the full default command
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${R}_secondary -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/${R}_secondary.log 2>&1
+python tools/rocpd_stats.py gpurun_out/prof/${R}_trace_results.db > gpurun_out/prof/${R}_kernel_trace_stats.md
+python tools/rocpd_stats.py gpurun_out/prof/${R}_secondary_results.db > gpurun_out/prof/${R}_secondary_kernel_trace_stats.md
+python tools/rocpd_stats.py gpurun_out/prof/${R}_fetch_results.db pmc > gpurun_out/prof/${R}_pmc_fetch_size.md
+python tools/rocpd_stats.py gpurun_out/prof/${R}_write_results.db pmc > gpurun_out/prof/${R}_pmc_write_size.md
+python tools/rocpd_stats.py gpurun_out/prof/${R}_mfma_results.db mfma > gpurun_out/prof/${R}_pmc_mfma_busy.md
+python tools/rocpd_stats.py traffic gpurun_out/prof/${R}_fetch_results.db gpurun_out/prof/${R}_write_results.db > gpurun_out/prof/${R}_pmc_traffic.json
+rm -f gpurun_out/prof/*_results.db   # the summaries travel back, the databases do not fit the 64 MiB return budget
+head -30 gpurun_out/prof/${R}_kernel_trace_stats.md
+cat gpurun_out/prof/${R}_bench_line.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['phases_ms'], d['roofline'])"
+tail -3 gpurun_out/prof/${R}_secondary.log | grep metric | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('secondary'))"

@@ -80,6 +80,25 @@ def traffic(fetch_db, write_db):
         fetch = 2.0 * 1024 * (fk[0] if fk else 0.0)
         write = 1024 * (wk[0] if wk else 0.0)
         out[name] = {"fetch_bytes": int(fetch), "write_bytes": int(write), "hbm_bytes": int(fetch + write)}
+    # kernel-map build: per BUILD = sum over its kernels of (average per dispatch x dispatches per build)
+    def per_build(db, counter, table):
+        rows = sqlite3.connect(db).execute(
+            "select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+        per_kernel = {}
+        for k, v in rows:
+            if any(t in k for t in ("cell_", "kmap_", "rs_kernel")):
+                a = per_kernel.setdefault(k, [0, 0.0])
+                a[0] += 1
+                a[1] += v
+        if not per_kernel:
+            return 0.0, {}
+        builds = min(n for k, (n, t) in per_kernel.items() if "cell_prepare" in k) if any("cell_prepare" in k for k in per_kernel) else 1
+        detail = {short(k): round(t / builds, 1) for k, (n, t) in per_kernel.items()}
+        return sum(t for n, t in per_kernel.values()) / builds, detail
+    kf, kfd = per_build(fetch_db, "FETCH_SIZE", f)
+    kw, kwd = per_build(write_db, "WRITE_SIZE", w)
+    out["kmap"] = {"fetch_bytes": int(2.0 * 1024 * kf), "write_bytes": int(1024 * kw), "hbm_bytes": int(2.0 * 1024 * kf + 1024 * kw),
+                   "fetch_kib_per_build_by_kernel": kfd, "write_kib_per_build_by_kernel": kwd}
     print(json.dumps(out, indent=1))
 
 

@@ -154,7 +154,40 @@ SIGNATURES = {
     ),
 }
 
-_LIB: Optional[ctypes.CDLL] = None
+_LIB = None  # _GuardedLib
+
+
+class _GuardedLib:
+    """The loaded library with the reference bindings' device guard (`c10::cuda::CUDAGuard` in every pybind entry point):
+    the C-ABI takes raw pointers and a stream, launches go to the CURRENT device, so a call whose tensors live on another
+    GPU (model on cuda:1 while cuda:0 is current, several GPUs driven from one process) switches the device for the call.
+    The device of a call is the one its stream handle was asked for (`stream_handle(device)`, evaluated as the last
+    argument of every launching call); pure host entry points never pass through the switch."""
+
+    def __init__(self, handle: ctypes.CDLL):
+        self._h = handle
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        argtypes = fn.argtypes or []
+        if not argtypes or argtypes[-1] is not c_void_p or name in _HOST_ONLY:
+            setattr(self, name, fn)
+            return fn
+
+        def guarded(*args, _fn=fn):
+            dev = _CALL_DEVICE[0]
+            if dev is None or dev == torch.cuda.current_device():
+                return _fn(*args)
+            with torch.cuda.device(dev):
+                return _fn(*args)
+
+        guarded.__name__ = name
+        setattr(self, name, guarded)
+        return guarded
+
+
+_HOST_ONLY = {"wcn_status_string"}
+_CALL_DEVICE = [None]  # device index of the stream handed out last (single-threaded dispatch: evaluated per call)
 
 
 def build(verbose: bool = False) -> str:
@@ -183,7 +216,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        _LIB = handle
+        _LIB = _GuardedLib(handle)
     return _LIB
 
 
@@ -209,10 +242,11 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 def stream_handle(device: torch.device) -> int:
     """hipStream_t of the current PyTorch stream on ``device``.  Every C-ABI call needs it (~900 per MinkUNet iteration):
     the raw accessor skips building a ``torch.cuda.Stream`` object (≈ 6 us -> 0.3 us per call)."""
+    idx = device.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    _CALL_DEVICE[0] = idx
     if _RAW_STREAM is not None:
-        idx = device.index
-        if idx is None:
-            idx = torch.cuda.current_device()
         return _RAW_STREAM(idx)
     return torch.cuda.current_stream(device).cuda_stream
 

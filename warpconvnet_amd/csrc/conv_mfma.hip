@@ -480,15 +480,14 @@ static int launch_gather_gemm(const void* in, const void* wp, void* out, const i
   typedef GatherGemm<T, CIC, CO, RB> G;
   const int kp = wcn_kmap_row_pitch(K);
   const int mw = wcn_kmap_mask_words(K);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_mfma_kernel<T, CIC, CO, RB, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_mfma_kernel<T, CIC, CO, RB, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
-      return WCN_ERROR_KERNEL_INITIALIZATION;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
+  const int rc = once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_mfma_kernel<T, CIC, CO, RB, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_mfma_kernel<T, CIC, CO, RB, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
+  });
+  if (rc != WCN_SUCCESS) return rc;
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
   if (mw == 1)
     hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, false>), dim3(grid), dim3(256), G::LDS_BYTES, s,

@@ -404,18 +404,14 @@ static int launch16(const void* in, const void* wp, void* out, const int32_t* nb
                     hipStream_t s) {
   typedef GG16<T, CIC, CO, RG> G;
   const int kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
-  // the attribute is per device: remember which devices have it (bit set = done; a lost race only repeats the call)
-  static unsigned long long done_mask = 0ull;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return WCN_ERROR_KERNEL_INITIALIZATION;
-  if (dev >= 64 || !((__atomic_load_n(&done_mask, __ATOMIC_RELAXED) >> dev) & 1ull)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm16_kernel<T, CIC, CO, RG, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm16_kernel<T, CIC, CO, RG, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
-      return WCN_ERROR_KERNEL_INITIALIZATION;
-    if (dev < 64) __atomic_fetch_or(&done_mask, 1ull << dev, __ATOMIC_RELAXED);
-  }
+  static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
+  const int rc = once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm16_kernel<T, CIC, CO, RG, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm16_kernel<T, CIC, CO, RG, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
+  });
+  if (rc != WCN_SUCCESS) return rc;
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
   if (mw == 1)
     hipLaunchKernelGGL((gather_gemm16_kernel<T, CIC, CO, RG, false>), dim3(grid), dim3(256), G::LDS_BYTES, s, (const T*)in,

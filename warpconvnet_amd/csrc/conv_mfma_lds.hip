@@ -348,16 +348,12 @@ static int launch_lds(const void* in, const void* wp, void* out, const int32_t* 
                       const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
                       hipStream_t s) {
   typedef GGLds<T, CO> G;
-  // the attribute is per device: remember which devices have it (bit set = done; a lost race only repeats the call)
-  static unsigned long long done_mask = 0ull;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return WCN_ERROR_KERNEL_INITIALIZATION;
-  if (dev >= 64 || !((done_mask >> dev) & 1ull)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_lds_kernel<T, CO>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
-      return WCN_ERROR_KERNEL_INITIALIZATION;
-    if (dev < 64) __atomic_fetch_or(&done_mask, 1ull << dev, __ATOMIC_RELAXED);
-  }
+  static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
+  const int rc = once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_lds_kernel<T, CO>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
+  });
+  if (rc != WCN_SUCCESS) return rc;
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
   hipLaunchKernelGGL((gather_gemm_lds_kernel<T, CO>), dim3(grid), dim3(256), G::LDS_BYTES, s, (const T*)in, (const T*)wp,
                      (T*)out, nbr, mask, perm, epi, n_out, cin, K, wcn_kmap_row_pitch(K), out32);

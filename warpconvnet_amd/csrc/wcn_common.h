@@ -94,6 +94,18 @@ inline int launch_status() {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Per-device one-time setup (kernel attributes are per device context): bit d of `done` = device d is set up.  The only
+// process-wide state of the library, idempotent: a lost race or a device index above 63 just repeats the setup call.
+template <typename F>
+inline int once_per_device(unsigned long long& done, F&& setup) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return WCN_ERROR_KERNEL_INITIALIZATION;
+  if (dev >= 0 && dev < 64 && ((__atomic_load_n(&done, __ATOMIC_RELAXED) >> dev) & 1ull)) return WCN_SUCCESS;
+  if (!setup()) return WCN_ERROR_KERNEL_INITIALIZATION;
+  if (dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELAXED);
+  return WCN_SUCCESS;
+}
+
 // Epilogue of the gather GEMM, applied in fp32 before the result is rounded to the storage dtype:
 //   y = act((acc + bias) * scale + shift + residual)      every term optional (null / 0 = absent)
 // BatchNorm in inference mode is scale = gamma / sqrt(var + eps), shift = beta - mean * scale.

@@ -383,20 +383,29 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
                         const int32_t* offsets, int cin, int cout, int K, void* workspace, int cs_k, float* bias_grad,
                         hipStream_t s) {
   typedef Wgrad<T, CIT, COT> W;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
+  const int rc = once_per_device(attr_done, [] {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<T, CIT, COT, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES) != hipSuccess)
-      return WCN_ERROR_KERNEL_INITIALIZATION;
+      return false;
     if constexpr (W::GRID) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<T, CIT, COT, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES) != hipSuccess)
-        return WCN_ERROR_KERNEL_INITIALIZATION;
+        return false;
     }
-    attr_set = true;
+    return true;
+  });
+  if (rc != WCN_SUCCESS) return rc;
+  // read-only page of zeros: a per-device constant (never written), its address looked up once per device
+  static char* zero_pages[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return WCN_ERROR_KERNEL_INITIALIZATION;
+  char* zero_page = (dev >= 0 && dev < 64) ? __atomic_load_n(&zero_pages[dev], __ATOMIC_RELAXED) : nullptr;
+  if (!zero_page) {
+    if (hipGetSymbolAddress((void**)&zero_page, HIP_SYMBOL(g_wgrad_zero_page)) != hipSuccess)
+      return WCN_ERROR_KERNEL_INITIALIZATION;
+    if (dev >= 0 && dev < 64) __atomic_store_n(&zero_pages[dev], zero_page, __ATOMIC_RELAXED);
   }
-  char* zero_page = nullptr;
-  if (hipGetSymbolAddress((void**)&zero_page, HIP_SYMBOL(g_wgrad_zero_page)) != hipSuccess) return WCN_ERROR_KERNEL_INITIALIZATION;
   float* slabs = (float*)((char*)workspace + kZeroPage);
   float* cs_slabs = slabs + (size_t)(kWgradGrid + K) * cin * cout;
   const dim3 grid(kWgradGrid, (cin / CIT) * (cout / COT));

@@ -98,10 +98,35 @@ def resolve_wgrad_algo(algo: str, cin: int, cout: int, dtype: torch.dtype) -> in
 
 def pack_weight(weight: Tensor, transpose: bool, flip: bool, dtype: Optional[torch.dtype] = None) -> Tensor:
     """Fragment-ordered weight image for the MFMA gather-GEMM.  ``weight`` is the forward [K, Cin, Cout]; an fp32 master
-    weight with a 16-bit ``dtype`` is rounded while it is packed (one launch instead of cast + pack)."""
+    weight with a 16-bit ``dtype`` is rounded while it is packed (one launch instead of cast + pack).
+
+    The image of a PARAMETER (a leaf that requires grad) is kept on the tensor object itself and reused while its version
+    counter stands - inference, gradient accumulation, several micro-batches per optimizer step, a layer applied more than
+    once; any in-place update bumps ``_version`` and the next use repacks.  Temporaries (autocast copies, computed
+    weights) are never remembered: the cache lives and dies with the parameter object, there is no global table."""
     K, c_in, c_out = weight.shape
     kin, kout = (c_out, c_in) if transpose else (c_in, c_out)  # kernel-side channel roles
     dtype = dtype or weight.dtype
+    key = (dtype, bool(transpose), bool(flip))
+    cache = getattr(weight, "_wcn_packed", None)
+    if cache is not None:
+        hit = cache.get(key)
+        if hit is not None and hit[0] == weight._version:
+            return hit[1]
+    packed = _pack_weight_uncached(weight, K, kin, kout, transpose, flip, dtype)
+    if weight.requires_grad and weight.is_leaf:
+        if cache is None:
+            cache = {}
+            try:
+                weight._wcn_packed = cache
+            except AttributeError:
+                return packed
+        cache[key] = (weight._version, packed)
+    return packed
+
+
+def _pack_weight_uncached(weight: Tensor, K: int, kin: int, kout: int, transpose: bool, flip: bool,
+                          dtype: torch.dtype) -> Tensor:
     packed = torch.empty(weight.numel(), dtype=dtype, device=weight.device)
     if weight.dtype == torch.float32 and dtype != torch.float32:
         _lib.check(
