@@ -437,6 +437,20 @@ def test_full_size_properties():
     assert abs((W.double() * dW.double()).sum().item() - lhs) / abs(lhs) < 2e-2
     dense = X.float().T @ dY.float()
     assert rel_max_err(dW[13], dense) < 2e-2
+    # (5b) sub-sampled rows of dgrad against fp64: for a submanifold map the pair (in n, out m, k) exists iff
+    # (in m, out n, K-1-k) does, so dX[n] = sum_k dY[pair_table[K-1-k][n]] @ W[k]^T
+    refx = torch.zeros(512, 64, dtype=torch.float64, device=dev)
+    for k in range(27):
+        idx = pt[26 - k][rows].long()
+        valid = (idx >= 0).double().unsqueeze(1)
+        refx += (dY[idx.clamp_min(0)].double() * valid) @ W[k].double().T
+    assert rel_max_err(dX[rows], refx) < 2e-2
+    # (5c) whole buckets of wgrad against fp64 (corner, edge, centre, opposite corner): dW[k] = X[in_k]^T dY[out_k]
+    off = km.offsets.tolist()
+    for k in (0, 7, 13, 26):
+        i, o = km.in_maps[off[k] : off[k + 1]].long(), km.out_maps[off[k] : off[k + 1]].long()
+        want = X[i].double().T @ dY[o].double()
+        assert rel_max_err(dW[k], want) < 2e-2, k
     # (6) run-to-run determinism of all three kernels
     assert torch.equal(hip_gemm.hip_forward(X, W, km, N, "hip_mfma"), Y)
     assert torch.equal(hip_gemm.hip_dgrad(dY, W, km, N, "hip_mfma"), dX)

@@ -38,19 +38,45 @@ def test_minkunet14_hip_vs_explicit(monkeypatch):
     builds, fwd_errs, bwd_errs = [], [], []
     real_gen, real_fwd, real_bwd = td.generate_kernel_map, backends.run_forward, backends.run_backward
 
+    from oracle import conv as oconv
+    from oracle import kmap as okmap
+
+    oracle_errs = []
+
     def counting(*a, **k):
         builds.append((tuple(a[3]), tuple(a[2])))
-        return real_gen(*a, **k)
+        km = real_gen(*a, **k)
+        # every map the network builds is the ORACLE's map, bit for bit (C restatement of the reference's kernels)
+        r = okmap.kernel_map(a[0].cpu().numpy(), a[1].cpu().numpy(), tuple(a[3]), tuple(a[2]))
+        np.testing.assert_array_equal(km.offsets.numpy(), r["offsets"])
+        np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+        np.testing.assert_array_equal(km.out_maps.cpu().numpy(), r["out_maps"])
+        return km
+
+    def _maps(kmap):
+        return kmap.in_maps.cpu().numpy(), kmap.out_maps.cpu().numpy(), kmap.offsets.numpy()
 
     def both_fwd(algo, ctx):
         ref = real_fwd("explicit_gemm", ctx)
-        fwd_errs.append((rel_max_err(real_fwd("auto", ctx), ref), tuple(ctx.weight.shape)))
+        got = real_fwd("auto", ctx)
+        fwd_errs.append((rel_max_err(got, ref), tuple(ctx.weight.shape)))
+        # ... and against the fp64 oracle (oracle/conv.py, pinned by reference-generated vectors) on the values the GPU saw
+        dt = ctx.compute_dtype or ctx.in_features.dtype
+        i, o, off = _maps(ctx.kernel_map)
+        want = oconv.forward(ctx.in_features.to(dt).double().cpu(), ctx.weight.to(dt).double().cpu(), i, o, off, ctx.num_out_coords)
+        oracle_errs.append(("fwd", rel_max_err(got, want), tuple(ctx.weight.shape)))
         return ref
 
     def both_bwd(algo, ctx):
         ref = real_bwd("explicit_gemm", ctx)
         got = real_bwd("auto", ctx)
         bwd_errs.append((rel_max_err(got[0], ref[0]), rel_max_err(got[1], ref[1]), tuple(ctx.weight.shape)))
+        dt = ctx.compute_dtype or ctx.in_features.dtype
+        i, o, off = _maps(ctx.kernel_map)
+        dxr, dwr = oconv.backward(ctx.grad_output.to(dt).double().cpu(), ctx.in_features.to(dt).double().cpu(),
+                                  ctx.weight.to(dt).double().cpu(), i, o, off)
+        oracle_errs.append(("dgrad", rel_max_err(got[0], dxr), tuple(ctx.weight.shape)))
+        oracle_errs.append(("wgrad", rel_max_err(got[1], dwr), tuple(ctx.weight.shape)))
         return ref
 
     monkeypatch.setattr(helper, "generate_kernel_map", counting)
@@ -71,6 +97,8 @@ def test_minkunet14_hip_vs_explicit(monkeypatch):
     assert max(e for e, _ in fwd_errs) < 2e-2, sorted(fwd_errs)[-3:]
     assert max(e for e, _, _ in bwd_errs) < 2e-2 and max(e for _, e, _ in bwd_errs) < 2e-2, sorted(bwd_errs)[-3:]
     assert {s for _, s in fwd_errs} >= {(27, 192, 128), (27, 96, 96), (8, 256, 128), (27, 256, 256), (8, 32, 32)}
+    # 24 forward + 24 dgrad + 24 wgrad comparisons with the fp64 oracle, reference tolerance for 16-bit storage
+    assert len(oracle_errs) == 72 and max(e for _, e, _ in oracle_errs) < 2e-2, sorted(oracle_errs, key=lambda t: t[1])[-3:]
 
     # the same network end to end on the HIP kernels: same forward up to accumulated bf16 rounding, finite gradients
     monkeypatch.setattr(unified, "run_forward", real_fwd)

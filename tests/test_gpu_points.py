@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util import rel_max_err
+
 pytestmark = pytest.mark.gpu
 
 
@@ -70,27 +72,79 @@ def test_pointconv_gpu_matches_reference_golden(golden_dir, name, kw):
         torch.testing.assert_close(v.cpu(), torch.from_numpy(g[f"{name}_grad_{k}"]), rtol=5e-3, atol=5e-4)
 
 
-def test_pointconv_config5_shape_runs():
-    """BASELINE config 5 shape: 200 k fp32 points, PointConv(32 -> 64, knn 16), then voxelise and a depthwise k=3 conv."""
+def test_pointconv_config5_full_size_parity():
+    """BASELINE config 5 at FULL size: 200 k fp32 points, PointConv(32 -> 64, knn 16), voxelise, depthwise k=3 conv.
+    kNN against brute force and PointConv output rows against the CPU evaluation of the same module on a 2 000-query
+    subsample (the full problem is 4e10 distance evaluations on the CPU); the depthwise convolution, forward and both
+    gradients, against oracle.conv.depthwise_* on the oracle's kernel map for ALL voxels."""
+    import copy
+
+    from oracle import conv as oconv
+    from oracle import kmap as okmap
     from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
     from warpconvnet_amd.geometry.types.points import Points
     from warpconvnet_amd.nn.modules import PointConv, SparseDepthwiseConv3d
+    from warpconvnet_amd.ops.reductions import row_reduction
 
     dev = _dev()
     g = torch.Generator().manual_seed(5)
-    n = 200_000
+    n, k = 200_000, 16
     coords = (torch.rand(n, 3, generator=g) * torch.tensor([50.0, 50.0, 4.0])).to(dev)
-    pc = Points(coords, torch.randn(n, 32, generator=g).to(dev), offsets=torch.tensor([0, n]))
+    feats = torch.randn(n, 32, generator=g)
+    pc = Points(coords, feats.to(dev), offsets=torch.tensor([0, n]))
+    cfg = RealSearchConfig(mode="knn", knn_k=k)
     torch.manual_seed(0)
-    conv = PointConv(32, 64, RealSearchConfig(mode="knn", knn_k=16)).to(dev)
+    conv = PointConv(32, 64, cfg).to(dev)
     out = conv(pc)
     assert out.feature_tensor.shape == (n, 64) and torch.isfinite(out.feature_tensor).all()
+
+    # ---- kNN of all 200 k queries, checked on a subsample against brute force in fp64 ----
+    nb = pc.neighbors(query_coords=pc.batched_coordinates, search_args=cfg)
+    idx = nb.neighbor_indices.long().view(n, k)
+    sub = torch.randperm(n, generator=g)[:2000].to(dev)
+    cd = coords.double()
+    for lo in range(0, len(sub), 500):
+        q = sub[lo : lo + 500]
+        d2 = ((cd[q].unsqueeze(1) - cd.unsqueeze(0)) ** 2).sum(-1)  # [500, n]
+        want_d, want_i = torch.topk(d2, k, dim=1, largest=False)
+        got_d = torch.gather(d2, 1, idx[q])
+        torch.testing.assert_close(torch.sort(got_d, 1).values, want_d, rtol=1e-5, atol=1e-9)
+        same = (torch.sort(idx[q], 1).values == torch.sort(want_i, 1).values).all(1)
+        assert same.float().mean() > 0.99  # differences only from exact distance ties
+
+    # ---- PointConv rows of the subsample: the same module evaluated on the CPU from the (verified) neighbour lists ----
+    ref = copy.deepcopy(conv).cpu()
+    q = sub.cpu()
+    fi = feats[idx[sub].cpu().view(-1)]                     # neighbour features  [2000*k, 32]
+    fq = feats[q].repeat_interleave(k, dim=0)              # query features      [2000*k, 32]
+    edge = [fi, fq]
+    if conv.use_rel_pos or conv.use_rel_pos_encode:
+        rel = coords.cpu()[idx[sub].cpu().view(-1)] - coords.cpu()[q].repeat_interleave(k, dim=0)
+        edge.append(ref.positional_encoding(rel) if conv.use_rel_pos_encode else rel)
+    with torch.no_grad():
+        e = ref.edge_transform_mlp(torch.cat(edge, 1))
+        splits = torch.arange(0, len(q) * k + 1, k)
+        want = ref.out_transform_mlp(torch.cat([row_reduction(e, splits, reduction=r) for r in conv.reductions], -1))
+    torch.testing.assert_close(out.feature_tensor[sub].detach().cpu(), want, rtol=1e-3, atol=1e-4)
+
+    # ---- voxelise + depthwise convolution: all voxels against the oracle (kernel map bit-exact, features fp64) ----
     vox = out.to_voxels(0.25)
-    dw = SparseDepthwiseConv3d(64, 3).to(dev)
-    y = dw(vox)
-    assert y.feature_tensor.shape == vox.feature_tensor.shape and torch.isfinite(y.feature_tensor).all()
-    y.feature_tensor.sum().backward()
-    assert conv.edge_transform_mlp.block[0].weight.grad is not None and dw.weight.grad is not None
+    torch.manual_seed(1)
+    dw = SparseDepthwiseConv3d(64, 3, bias=False).to(dev)
+    x = vox.replace(batched_features=vox.feature_tensor.detach().clone().requires_grad_(True))
+    y = dw(x)
+    gy = torch.randn(y.feature_tensor.shape, generator=g).to(dev)
+    y.feature_tensor.backward(gy)
+    bc = vox.batch_indexed_coordinates.cpu().numpy()
+    r = okmap.kernel_map(bc, bc, (3, 3, 3))
+    km = next(iter(x.cache.values()))
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+    np.testing.assert_array_equal(km.out_maps.cpu().numpy(), r["out_maps"])
+    xd, wd = x.feature_tensor.detach().double().cpu(), dw.weight.detach().double().cpu()
+    yr = oconv.depthwise_forward(xd, wd, r["in_maps"], r["out_maps"], r["offsets"], len(bc))
+    dxr, dwr = oconv.depthwise_backward(gy.double().cpu(), xd, wd, r["in_maps"], r["out_maps"], r["offsets"])
+    assert rel_max_err(y.feature_tensor.detach(), yr) < 1e-3
+    assert rel_max_err(x.feature_tensor.grad, dxr) < 1e-3 and rel_max_err(dw.weight.grad, dwr) < 1e-3
 
 
 @pytest.mark.parametrize("n,m,radius,shape", [(20000, 4000, 0.05, "cube"), (5000, 5000, 0.0, "cube"), (30000, 1500, 2.0, "slab"),

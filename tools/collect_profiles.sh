@@ -22,4 +22,4 @@ python tools/rocpd_stats.py traffic gpurun_out/prof/${R}_fetch_results.db gpurun
 rm -f gpurun_out/prof/*_results.db   # the summaries travel back, the databases do not fit the 64 MiB return budget
 head -30 gpurun_out/prof/${R}_kernel_trace_stats.md
 cat gpurun_out/prof/${R}_bench_line.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['phases_ms'], d['roofline'])"
-tail -3 gpurun_out/prof/${R}_secondary.log | grep metric | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('secondary'))"
+grep -h "\"metric\"" gpurun_out/prof/${R}_secondary.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('secondary'))"
