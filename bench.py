@@ -337,7 +337,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from warpconvnet_amd import _lib
-    from warpconvnet_amd.dist import allreduce_gradients
+    from warpconvnet_amd.dist import GradientBuckets
     from warpconvnet_amd.geometry.types.voxels import Voxels
     from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
     from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
@@ -359,17 +359,22 @@ def main():
     torch.manual_seed(0)
     conv = SparseConv3d(CIN, COUT, 3, bias=True).to(dev)
     params = [p for p in conv.parameters()]
+    # N > 1: persistent flat gradient bucket, the all-reduce is launched from the autograd hook of the last gradient
+    buckets = GradientBuckets(params) if world > 1 else None
 
     def step():
-        for p in params:
-            p.grad = None
+        if buckets is not None:
+            buckets.zero_grad()
+        else:
+            for p in params:
+                p.grad = None
         feats.grad = None
         x = Voxels(coords, feats, offsets=offsets)  # fresh geometry -> kernel map rebuilt every step
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = conv(x)
         y.batched_features.batched_tensor.backward(grad_out)
-        if world > 1:
-            allreduce_gradients(params)
+        if buckets is not None:
+            buckets.finish()
 
     for _ in range(args.warmup):
         step()
