@@ -232,3 +232,67 @@ def test_expand_coords_matches_set_union():
         np.testing.assert_array_equal(out[:1500], s[:1500])
         out2, _ = expand_coords(torch.from_numpy(s).to(dev), ks, dl, kernel_batch=1)
         np.testing.assert_array_equal(np.unique(out2.cpu().numpy(), axis=0), want)
+
+
+def _brute_offsets_map(in_np, out_np, offsets, stride):
+    """Dictionary brute force for an explicit offset table (method of the reference's
+    tests/coords/test_kernel_map_invariants.py:205-230): buckets ordered by output row."""
+    table = {}
+    for r, c in enumerate(map(tuple, in_np.tolist())):
+        table.setdefault(c, r)
+    ins, outs, offs = [], [], [0]
+    for off in offsets:
+        for m, (b, x, y, z) in enumerate(out_np.tolist()):
+            hit = table.get((b, x * stride[0] + off[0], y * stride[1] + off[1], z * stride[2] + off[2]))
+            if hit is not None:
+                ins.append(hit)
+                outs.append(m)
+        offs.append(len(ins))
+    return np.array(ins, np.int32), np.array(outs, np.int32), np.array(offs, np.int32)
+
+
+@pytest.mark.parametrize("ksize,dil,centre", [((3, 3, 3), (1, 1, 1), (0, 0, 0)), ((3, 3, 3), (2, 1, 1), (2, 1, 0)),
+                                              ((2, 2, 2), (1, 1, 1), (1, 1, 1)), ((5, 3, 1), (1, 2, 1), (1, 0, 0))])
+def test_custom_kernel_center_offset(ksize, dil, centre):
+    """`kernel_center_offset` (reference torch_discrete.py:24-56, 387-401; `offset` method only): offsets (i - c) * dilation
+    with the caller's centre c, against a dictionary brute force over the explicit offset table."""
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map, kernel_offsets_from_size
+
+    s = scene_u(1500, 61, 0)
+    o = np.ascontiguousarray(scene_u(1400, 62, 0))  # a different output set: the full map comes back (no halving)
+    dev = torch.device("cuda:0")
+    km = generate_kernel_map(torch.from_numpy(s).to(dev), torch.from_numpy(o).to(dev), (1, 1, 1), ksize, dil, centre, method="offset")
+    offsets = kernel_offsets_from_size(ksize, dil, centre)[:, 1:].tolist()
+    assert offsets[0] == [(0 - c) * d for c, d in zip(centre, dil)]
+    i, out, off = _brute_offsets_map(s, o, offsets, (1, 1, 1))
+    np.testing.assert_array_equal(km.offsets.numpy(), off)
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), i)
+    np.testing.assert_array_equal(km.out_maps.cpu().numpy(), out)
+    with pytest.raises(AssertionError):  # the reference's `size` method rejects a custom centre
+        generate_kernel_map(torch.from_numpy(s).to(dev), torch.from_numpy(o).to(dev), (1, 1, 1), ksize, dil, centre, method="size")
+
+
+def test_offset_method_and_skip_symmetric_return_the_first_half():
+    """Reference behaviour (torch_discrete.py:211-219, 363-370, 387-401): on an odd kernel over equally sized coordinate
+    sets, method="offset" and skip_symmetric_kernel_map=True keep offsets 0 .. K//2-1 only, identity_map_index = K//2."""
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+    s = scene_u(3000, 63, 0)
+    c = torch.from_numpy(s).to(torch.device("cuda:0"))
+    full = generate_kernel_map(c, c, (1, 1, 1), (3, 3, 3))
+    r = okmap.kernel_map(s, s, (3, 3, 3))
+    for kw in (dict(method="offset"), dict(skip_symmetric_kernel_map=True)):
+        half = generate_kernel_map(c, c, (1, 1, 1), (3, 3, 3), **kw)
+        assert len(half) == 13 and half.identity_map_index == 13
+        np.testing.assert_array_equal(half.offsets.numpy(), r["offsets"][:14])
+        np.testing.assert_array_equal(half.in_maps.cpu().numpy(), r["in_maps"][: r["offsets"][13]])
+        np.testing.assert_array_equal(half.out_maps.cpu().numpy(), r["out_maps"][: r["offsets"][13]])
+        # the dropped half is the mirror image of the kept one: pair (i, o) at offset k <=> pair (o, i) at offset K-1-k
+        for k in (0, 5, 12):
+            a = set(zip(*[t.cpu().tolist() for t in half[k]]))
+            b = set((o_, i_) for i_, o_ in zip(*[t.cpu().tolist() for t in full[26 - k]]))
+            assert a == b
+    with pytest.raises(AssertionError):
+        generate_kernel_map(c, c, (1, 1, 1), (2, 2, 2), skip_symmetric_kernel_map=True)  # even kernel
+    with pytest.raises(ValueError):
+        generate_kernel_map(c, c, (1, 1, 1), (3, 3, 3), method="hash")

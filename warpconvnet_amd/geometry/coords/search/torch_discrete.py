@@ -121,6 +121,14 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
     return kmap._rev
 
 
+def _first_half(full: IntSearchResult) -> IntSearchResult:
+    """Buckets 0 .. K//2 - 1 of a full odd-kernel map as their own result (plain CSR container, identity index K//2)."""
+    c = len(full) // 2
+    offs = full.offsets[: c + 1].clone()
+    n = int(offs[-1])
+    return IntSearchResult(full.in_maps_device[:n].clone(), full.out_maps_device[:n].clone(), offs, identity_map_index=c)
+
+
 # binned builder: does this process see scenes with >= 4 voxels per occupied 8^3 block?  (size of the first-try block table)
 _BINNED_HINT = {"dense": True}
 
@@ -149,10 +157,36 @@ def generate_kernel_map(
         raise RuntimeError(
             "generate_kernel_map runs on the GPU through libwcn_hip.so; got CPU coordinates (no CPU fallback)"
         )
-    if skip_symmetric_kernel_map:
-        raise NotImplementedError("skip_symmetric_kernel_map is not implemented in this build")
+    if method not in ("offset", "size"):
+        raise ValueError(f"Invalid method: {method}. Choose 'offset', or 'size'.")
+    odd_kernel = all(int(k) % 2 == 1 for k in kernel_size)
+    if skip_symmetric_kernel_map:  # reference torch_discrete.py:319-326, 383-385
+        assert len(batch_indexed_in_coords) == len(batch_indexed_out_coords), (
+            "You can only skip symmetric kernel map if the input and output coordinates are the same.")
+        assert odd_kernel, "Kernel size must be odd for symmetric skipping."
+    if method == "size":  # (reference :403-409; dilation itself IS supported by this build's size path)
+        assert kernel_center_offset is None, (
+            "Custom kernel_center_offset is not supported with method='size'. Use method='offset' instead.")
+    # The reference's `offset` method on an odd kernel over equally sized coordinate sets, and `skip_symmetric_kernel_map`,
+    # return only the FIRST HALF of the buckets (offsets 0 .. K//2 - 1, identity_map_index = K//2: the second half is the
+    # mirror image; `torch_discrete.py:363-370, 387-401, 211-219`).  Here the full map is built once and cut.
+    half_map = (skip_symmetric_kernel_map or method == "offset") and odd_kernel and (
+        len(batch_indexed_in_coords) == len(batch_indexed_out_coords))
     if kernel_center_offset is not None:
-        raise NotImplementedError("custom kernel_center_offset is not implemented in this build")
+        # offsets with a custom centre are the default offsets plus a constant: in = out*s + off_default[k] + delta with
+        # delta = (c_default - c_custom) * dilation, i.e. the default-centre map of the input coordinates shifted by -delta
+        # (row indices unchanged).  The shifted set is a different tensor, so the general (hash) builder runs.
+        nd = len(kernel_size)
+        dil = ntuple(kernel_dilation if kernel_dilation is not None else 1, nd)
+        c_def = [(int(k) - 1) // 2 if int(k) % 2 == 1 else 0 for k in kernel_size]
+        delta = [(cd - int(cu)) * int(d) for cd, cu, d in zip(c_def, kernel_center_offset, dil)]
+        shift = torch.tensor([0] + delta, dtype=torch.int32, device=dev)
+        full = generate_kernel_map(batch_indexed_in_coords - shift, batch_indexed_out_coords, in_to_out_stride_ratio,
+                                   kernel_size, kernel_dilation, None, "size", False)
+        return _first_half(full) if half_map else full
+    if half_map:
+        return _first_half(generate_kernel_map(batch_indexed_in_coords, batch_indexed_out_coords, in_to_out_stride_ratio,
+                                               kernel_size, kernel_dilation, None, "size", False))
     same_tensor = (
         batch_indexed_in_coords.data_ptr() == batch_indexed_out_coords.data_ptr()
         and batch_indexed_in_coords.shape == batch_indexed_out_coords.shape
