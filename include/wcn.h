@@ -233,6 +233,18 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
                          int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,
                          int32_t algo, int32_t w_transposed, int32_t k_flip, wcn_stream_t stream);
 
+/* Channel groups in ONE launch (weight [K, G, Cin/G, Cout/G]; reference: group index on grid.z of the fused kernel,
+ * MaskGemm_forward_64x64x32_1s_flat.h:117-123; sparse_conv.py:147-157).  Per-group widths cin_g x cout_g must be a shape
+ * of the 32x32x16 kernels (wcn_mfma_grouped_supported); feature rows hold all groups side by side ([N, G*cin_g] in,
+ * [N, G*cout_g] out), `bias` (optional) has G*cout_g entries.  wcn_pack_weight_grouped writes the G fragment-ordered
+ * images back to back in one launch from the forward weight ([K, G, cin_g, cout_g], fp32 or the storage dtype);
+ * transpose = 1, flip = 1 with swapped widths gives the dgrad images of a submanifold map, as for wcn_pack_weight. */
+int wcn_mfma_grouped_supported(int32_t cin_g, int32_t cout_g, int32_t num_offsets, int32_t dtype);
+int wcn_pack_weight_grouped(const void* w, int32_t w_is_f32, int32_t num_offsets, int32_t groups, int32_t cin_g,
+                            int32_t cout_g, int32_t dtype, int32_t transpose, int32_t flip, void* packed, wcn_stream_t stream);
+int wcn_conv_gather_gemm_grouped(const void* in, const void* w_packed, void* out, const int32_t* nbr, const uint32_t* mask,
+                                 const int32_t* perm, const float* bias, int64_t n_in, int64_t n_out, int32_t cin_g,
+                                 int32_t cout_g, int32_t groups, int32_t num_offsets, int32_t dtype, wcn_stream_t stream);
 /* As wcn_conv_gather_gemm with algo = WCN_ALGO_MFMA, but the result is written as fp32 straight from the fp32
  * accumulators (in / w_packed are WCN_F16 or WCN_BF16).  Used for fp32 feature tensors: operands are cast to fp16 with
  * an exact power-of-two rescale by the caller, the product is scaled back in fp32 - the reference's production

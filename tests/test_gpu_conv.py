@@ -207,7 +207,8 @@ def test_mfma_large_kernel_volumes(ksize, stride, cin, cout):
 
 
 @pytest.mark.parametrize("dtype,cin,cout,groups", [(torch.bfloat16, 128, 256, 2), (torch.float16, 64, 64, 4),
-                                                    (torch.float32, 24, 36, 3), (torch.bfloat16, 32, 32, 32)])
+                                                    (torch.float32, 24, 36, 3), (torch.bfloat16, 32, 32, 32),
+                                                    (torch.bfloat16, 64, 128, 2), (torch.float16, 128, 128, 4)])
 def test_grouped_conv_hip_vs_oracle(dtype, cin, cout, groups):
     """Channel groups through the module API on the GPU (auto backend: MFMA where the per-group shape allows, hip_ref
     otherwise, e.g. groups == channels) == G independent convolutions on channel slices (oracle)."""
@@ -233,6 +234,33 @@ def test_grouped_conv_hip_vs_oracle(dtype, cin, cout, groups):
     assert rel_max_err(X.grad, dXr) < tol
     assert rel_max_err(conv.weight.grad, dWr) < tol
     assert rel_max_err(conv.bias.grad, dY.double().sum(0).cpu()) < tol
+
+
+def test_grouped_conv_is_one_launch_per_direction(monkeypatch):
+    """Groups whose per-group widths are an MFMA shape: ONE grouped gather-GEMM launch for the forward pass and one for
+    dgrad (group index on grid.y) - no per-group launches, no channel-slice copies, no concatenation; `groups == channels`
+    takes the depthwise kernels (one launch each way) instead of C one-channel problems."""
+    from warpconvnet_amd import _lib
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    L = _lib.lib()
+    calls = {"grouped": 0, "plain": 0, "dw": 0}
+    for name, key in (("wcn_conv_gather_gemm_grouped", "grouped"), ("wcn_conv_gather_gemm", "plain"), ("wcn_dwconv_gather", "dw")):
+        real = getattr(L, name)
+        monkeypatch.setattr(L, name, (lambda *a, _r=real, _k=key: (calls.__setitem__(_k, calls[_k] + 1), _r(*a))[1]))
+    s = scene_u(2000, 52, 0)
+    coords = torch.from_numpy(s[:, 1:]).to(dev)
+    for cin, cout, groups, want in ((128, 256, 4, {"grouped": 2, "plain": 0, "dw": 0}), (64, 64, 64, {"grouped": 0, "plain": 0, "dw": 2})):
+        for k in calls:
+            calls[k] = 0
+        torch.manual_seed(6)
+        conv = SparseConv3d(cin, cout, 3, groups=groups).to(dev).to(torch.bfloat16)
+        X = torch.randn(len(s), cin, device=dev).to(torch.bfloat16).requires_grad_(True)
+        y = conv(Voxels(coords, X, offsets=torch.tensor([0, len(s)])))
+        y.feature_tensor.backward(torch.randn_like(y.feature_tensor))
+        assert calls == want, (cin, cout, groups, calls)
 
 
 @pytest.mark.parametrize("ksize,stride", [((2, 2, 2), (2, 2, 2)), ((3, 3, 3), (2, 2, 2))])

@@ -102,6 +102,16 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
          c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     ),
+    "wcn_mfma_grouped_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
+    "wcn_pack_weight_grouped": (
+        c_int,
+        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
+    ),
+    "wcn_conv_gather_gemm_grouped": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
+         c_int32, c_int32, c_int32, c_void_p],
+    ),
     "wcn_conv_gather_gemm_f32out": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,

@@ -18,6 +18,12 @@ int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int tra
                      hipStream_t s);
 int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                          hipStream_t s);
+bool mfma_grouped_supported(int cin, int cout, int K, int dtype);
+int conv_gather_gemm_grouped(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                             const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int groups,
+                             int K, int dtype, hipStream_t s);
+int pack_weight_grouped(const void* w, int w_is_f32, int K, int groups, int cin, int cout, int dtype, int transpose, int flip,
+                        void* packed, hipStream_t s);
 // wgrad_mfma.hip
 bool mfma_wgrad_supported(int cin, int cout, int dtype);
 size_t wgrad_mfma_workspace(int K, int cin, int cout);
@@ -99,6 +105,29 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
       // AUTO cannot be resolved here because the two algorithms take different weight images.
       return WCN_ERROR_INVALID_PARAMETERS;
   }
+}
+
+int wcn_mfma_grouped_supported(int32_t cin_g, int32_t cout_g, int32_t num_offsets, int32_t dtype) {
+  return mfma_grouped_supported(cin_g, cout_g, num_offsets, dtype) ? 1 : 0;
+}
+
+int wcn_pack_weight_grouped(const void* w, int32_t w_is_f32, int32_t num_offsets, int32_t groups, int32_t cin_g,
+                            int32_t cout_g, int32_t dtype, int32_t transpose, int32_t flip, void* packed, wcn_stream_t stream) {
+  if (!w || !packed || num_offsets < 1 || groups < 1 || cin_g < 1 || cout_g < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  return pack_weight_grouped(w, w_is_f32, num_offsets, groups, cin_g, cout_g, dtype, transpose, flip, packed,
+                             (hipStream_t)stream);
+}
+
+int wcn_conv_gather_gemm_grouped(const void* in, const void* w_packed, void* out, const int32_t* nbr, const uint32_t* mask,
+                                 const int32_t* perm, const float* bias, int64_t n_in, int64_t n_out, int32_t cin_g,
+                                 int32_t cout_g, int32_t groups, int32_t num_offsets, int32_t dtype, wcn_stream_t stream) {
+  if (n_in < 0 || n_out < 0 || cin_g < 1 || cout_g < 1 || groups < 1 || num_offsets < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n_out == 0) return WCN_SUCCESS;
+  if (!w_packed || !out || !nbr || !mask || (n_in > 0 && !in)) return WCN_ERROR_INVALID_PARAMETERS;
+  ConvEpilogue epi;
+  epi.bias = bias;
+  return conv_gather_gemm_grouped(in, w_packed, out, nbr, mask, perm, epi, n_out, cin_g, cout_g, groups, num_offsets, dtype,
+                                  (hipStream_t)stream);
 }
 
 int wcn_conv_gather_gemm_f32out(const void* in, const void* w, float* out, const int32_t* nbr, const uint32_t* mask,

@@ -115,6 +115,31 @@ __global__ void pack_weight_cast_kernel(const float* __restrict__ w, TD* __restr
   packed[e] = (TD)w[src];
 }
 
+// grouped weights [K, G, cin, cout] (forward layout; cin / cout per group) -> G packed images back to back, one launch
+template <typename TS, typename TD>
+__global__ void pack_weight_grouped_kernel(const TS* __restrict__ w, TD* __restrict__ packed, int K, int groups, int cin,
+                                           int cout, int cic, int transpose, int flip) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_group = (int64_t)K * cin * cout;
+  if (e >= per_group * groups) return;
+  const int grp = (int)(e / per_group);
+  const int NS = cic / 16, NB = cout / 32, nchunk = cin / cic;
+  int64_t t = e - (int64_t)grp * per_group;
+  const int j = (int)(t % 8); t /= 8;
+  const int lane = (int)(t % 64); t /= 64;
+  const int s = (int)(t % NS); t /= NS;
+  const int b = (int)(t % NB); t /= NB;
+  const int chunk = (int)(t % nchunk); t /= nchunk;
+  const int k = (int)t;
+  const int h = lane >> 5, m = lane & 31;
+  const int ci = chunk * cic + h * (cic / 2) + 8 * s + j;
+  const int co = ((m >> 2) & 1) * (cout / 2) + 16 * b + 4 * (m >> 3) + (m & 3);
+  const int64_t kg = (int64_t)(flip ? (K - 1 - k) : k) * groups + grp;
+  // not transposed: w[k][g][ci][co]; transposed: w is the forward weight [K, G, cout, cin] in kernel-side names
+  const int64_t src = transpose ? ((kg * cout + co) * cin + ci) : ((kg * cin + ci) * cout + co);
+  packed[e] = (TD)w[src];
+}
+
 // ---- main kernel -------------------------------------------------------------------------------------
 template <typename T, int CIC, int CO, int RB>
 struct GatherGemm {
@@ -135,8 +160,22 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
                                                                T* __restrict__ out, const int32_t* __restrict__ nbr,
                                                                const uint32_t* __restrict__ mask,
                                                                const int32_t* __restrict__ perm,
-                                                               const ConvEpilogue epi, int64_t n_out, int cin,
-                                                               int K, int kp, int mw, float* __restrict__ out32) {
+                                                               ConvEpilogue epi, int64_t n_out, int cin,
+                                                               int K, int kp, int mw, float* __restrict__ out32,
+                                                               int in_stride, int out_stride) {
+  // Channel groups (weight [K, G, Cin/G, Cout/G], reference MaskGemm_forward_64x64x32_1s_flat.h:117-123): ONE launch, the
+  // group on grid.y.  `cin` / CO are the PER-GROUP widths, rows are in_stride / out_stride elements apart, group g reads
+  // channels [g*cin, (g+1)*cin) and writes [g*CO, (g+1)*CO); the packed weight images of the groups follow each other.
+  {
+    const int grp = blockIdx.y;
+    in += (int64_t)grp * cin;
+    wp += (int64_t)grp * K * cin * CO;
+    if (out) out += (int64_t)grp * CO;
+    if (out32) out32 += (int64_t)grp * CO;
+    if (epi.bias) epi.bias += grp * CO;
+    if (epi.scale) { epi.scale += grp * CO; epi.shift += grp * CO; }
+    if (epi.residual) epi.residual = reinterpret_cast<const T*>(epi.residual) + (int64_t)grp * CO;
+  }
   typedef GatherGemm<T, CIC, CO, RB> G;
   typedef typename G::frag_t frag_t;
   constexpr int NS = G::NS, NB = G::NB, RPW = G::ROWS_PER_WAVE, TILE = G::TILE;
@@ -258,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 #ifdef WCN_ABL_LOCAL
         if (idx >= 0) idx &= 1023;  // dev ablation: all gathers hit a 128 KB window
 #endif
-        const T* p = in + (int64_t)idx * cin + chunk * CIC + h * (CIC / 2);
+        const T* p = in + (int64_t)idx * in_stride + chunk * CIC + h * (CIC / 2);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           frag_t v;
@@ -368,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
     for (int rb = 0; rb < RB; ++rb) {
       const int32_t r = s_rows[wave * RPW + rb * 32 + n];
       if (r < 0) continue;
-      float* dst = out32 + (int64_t)r * CO + h * (CO / 2);
+      float* dst = out32 + (int64_t)r * out_stride + h * (CO / 2);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -392,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
   for (int rb = 0; rb < RB; ++rb) {
     const int i = wave * RPW + rb * 32 + n;
     const int32_t r = s_rows[i];
-    T* dst = out + (int64_t)r * CO + h * (CO / 2);
+    T* dst = out + (int64_t)r * out_stride + h * (CO / 2);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       frag_t lo, hi;
@@ -416,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
         }
       }
       if (!kStaged && epi.residual && r >= 0) {  // direct path: the lane owns 16 contiguous channels of its row
-        const T* rp = reinterpret_cast<const T*>(epi.residual) + (int64_t)r * CO + h * (CO / 2) + 16 * b;
+        const T* rp = reinterpret_cast<const T*>(epi.residual) + (int64_t)r * out_stride + h * (CO / 2) + 16 * b;
         const frag_t r0 = *reinterpret_cast<const frag_t*>(rp), r1 = *reinterpret_cast<const frag_t*>(rp + 8);
 #pragma unroll
         for (int q = 0; q < 8; ++q) { acc[b][rb][q] += (float)r0[q]; acc[b][rb][8 + q] += (float)r1[q]; }
@@ -451,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
             frag_t o = *reinterpret_cast<const frag_t*>(stage + row * kPitch + piece * 16);
             if (epi.residual) {  // residual rows are read the way the output is written: whole rows, adjacent lanes
               const frag_t rv = __builtin_nontemporal_load(
-                  reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(epi.residual) + (int64_t)rr * CO + piece * 8));
+                  reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(epi.residual) + (int64_t)rr * out_stride + piece * 8));
 #pragma unroll
               for (int q = 0; q < 8; ++q) {
                 float f = (float)o[q] + (float)rv[q];
@@ -460,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
               }
             }
             // streamed once: non-temporal, so the output does not push the gathered input out of the caches
-            __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)rr * CO + piece * 8));
+            __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)rr * out_stride + piece * 8));
           }
         }
       }
@@ -476,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_mfma_kernel(const T* __res
 template <typename T, int CIC, int CO, int RB>
 static int launch_gather_gemm(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                               const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
-                              hipStream_t s) {
+                              hipStream_t s, int groups = 1) {
   typedef GatherGemm<T, CIC, CO, RB> G;
   const int kp = wcn_kmap_row_pitch(K);
   const int mw = wcn_kmap_mask_words(K);
@@ -488,27 +527,28 @@ static int launch_gather_gemm(const void* in, const void* wp, void* out, const i
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
   });
   if (rc != WCN_SUCCESS) return rc;
-  const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
+  const dim3 grid((unsigned)ceil_div(n_out, G::TILE), (unsigned)groups);
+  const int in_stride = cin * groups, out_stride = CO * groups;
   if (mw == 1)
-    hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, false>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32);
+    hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, false>), grid, dim3(256), G::LDS_BYTES, s, (const T*)in,
+                       (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32, in_stride, out_stride);
   else
-    hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, true>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32);
+    hipLaunchKernelGGL((gather_gemm_mfma_kernel<T, CIC, CO, RB, true>), grid, dim3(256), G::LDS_BYTES, s, (const T*)in,
+                       (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32, in_stride, out_stride);
   return launch_status();
 }
 
 template <typename T, int CIC>
 static int dispatch_co(int cout, const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                        const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
-                       hipStream_t s) {
+                       hipStream_t s, int groups) {
   switch (cout) {
-    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
@@ -550,14 +590,30 @@ bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
 template <typename T>
 static int dispatch_cic(int cin, int cout, const void* in, const void* wp, void* out, const int32_t* nbr,
                         const uint32_t* mask, const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int K, float* out32,
-                        hipStream_t s) {
+                        hipStream_t s, int groups = 1) {
   switch (mfma_chunk_for(cin)) {
-    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
+
+// channel groups in ONE launch: per-group widths cin x cout, the 32x32x16 kernels (group index on grid.y)
+bool mfma_grouped_supported(int cin, int cout, int K, int dtype) {
+  return (dtype == WCN_F16 || dtype == WCN_BF16) && K >= 1 && K <= kMaxK && mfma32_shape(cin, cout);
+}
+int conv_gather_gemm_grouped(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                             const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int groups,
+                             int K, int dtype, hipStream_t s) {
+  if (groups < 1 || groups > 65535 || !mfma_grouped_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (dtype == WCN_BF16)
+    return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, nullptr, s, groups);
+  return dispatch_cic<_Float16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, nullptr, s, groups);
+}
+// packed images of all groups for the kernels above (always the 32x32x16 layout), one launch
+int pack_weight_grouped(const void* w, int w_is_f32, int K, int groups, int cin, int cout, int dtype, int transpose, int flip,
+                        void* packed, hipStream_t s);
 
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                           const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
@@ -598,6 +654,27 @@ int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int tra
   // bf16 and f16 are both 2-byte moves
   hipLaunchKernelGGL(pack_weight_kernel<uint16_t>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                      (const uint16_t*)w, (uint16_t*)packed, K, cin, cout, cic, transpose, flip);
+  return launch_status();
+}
+
+int pack_weight_grouped(const void* w, int w_is_f32, int K, int groups, int cin, int cout, int dtype, int transpose, int flip,
+                        void* packed, hipStream_t s) {
+  const int cic = mfma_chunk_for(cin);
+  if (groups < 1 || cic == 0 || !mfma32_shape(cin, cout) || (dtype != WCN_F16 && dtype != WCN_BF16))
+    return WCN_ERROR_UNSUPPORTED_CONFIG;
+  const int64_t total = (int64_t)groups * K * cin * cout;
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (w_is_f32) {
+    if (dtype == WCN_BF16)
+      hipLaunchKernelGGL((pack_weight_grouped_kernel<float, __bf16>), grid, block, 0, s, (const float*)w, (__bf16*)packed, K,
+                         groups, cin, cout, cic, transpose, flip);
+    else
+      hipLaunchKernelGGL((pack_weight_grouped_kernel<float, _Float16>), grid, block, 0, s, (const float*)w, (_Float16*)packed,
+                         K, groups, cin, cout, cic, transpose, flip);
+  } else {
+    hipLaunchKernelGGL((pack_weight_grouped_kernel<uint16_t, uint16_t>), grid, block, 0, s, (const uint16_t*)w,
+                       (uint16_t*)packed, K, groups, cin, cout, cic, transpose, flip);
+  }
   return launch_status();
 }
 

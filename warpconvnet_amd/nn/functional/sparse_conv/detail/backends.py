@@ -117,6 +117,65 @@ BACKWARD_BACKENDS: Dict[str, BwdFn] = {
 }
 
 
+def _hip_algo(algo: str, t: Tensor) -> bool:
+    return algo in ("auto", "hip_mfma") and t.is_cuda
+
+
+def _is_depthwise(ctx) -> bool:
+    w = ctx.weight
+    return w.ndim == 4 and w.shape[2] == 1 and w.shape[3] == 1 and w.shape[1] == ctx.groups
+
+
+def _grouped_fast_forward(algo: str, ctx: FwdCtx):
+    """Single-launch paths of a grouped convolution: the depthwise kernels when every group is one channel
+    (`SparseConv3d(groups=C)`: weight [K, C, 1, 1] is the depthwise weight [K, C]), the grouped gather-GEMM (group on
+    grid.y) when the per-group widths are an MFMA shape.  None = take the per-group loop."""
+    if not _hip_algo(algo, ctx.in_features):
+        return None
+    dt = ctx.compute_dtype or ctx.in_features.dtype
+    if _is_depthwise(ctx):
+        from warpconvnet_amd.nn.functional.sparse_conv_depth import _implicit_depthwise_forward_logic
+
+        K, C = ctx.weight.shape[0], ctx.groups
+        out = _implicit_depthwise_forward_logic(ctx.in_features, ctx.weight.reshape(K, C), ctx.kernel_map, ctx.num_out_coords, dt)
+        return out if ctx.bias is None else out + ctx.bias.to(out.dtype)
+    if hip_gemm.grouped_supported(ctx.weight, dt, False) and hip_gemm.grouped_supported(ctx.weight, dt, True):
+        out = hip_gemm.hip_forward_grouped(ctx.in_features.to(dt), ctx.weight, ctx.kernel_map, ctx.num_out_coords, ctx.bias)
+        return out.to(ctx.in_features.dtype) if ctx.compute_dtype is not None else out
+    return None
+
+
+def _grouped_fast_backward(algo: str, ctx: BwdCtx):
+    if not _hip_algo(algo, ctx.grad_output):
+        return None
+    dt = ctx.compute_dtype or ctx.in_features.dtype
+    need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    if _is_depthwise(ctx):
+        from warpconvnet_amd.nn.functional.sparse_conv_depth import _implicit_depthwise_backward_logic
+
+        K, C = ctx.weight.shape[0], ctx.groups
+        dx, dw = _implicit_depthwise_backward_logic(ctx.grad_output, ctx.in_features, ctx.weight.reshape(K, C), ctx.kernel_map,
+                                                    dt, (need_dx, need_dw))
+        return dx, (None if dw is None else dw.reshape(K, C, 1, 1))
+    if not (hip_gemm.grouped_supported(ctx.weight, dt, False) and hip_gemm.grouped_supported(ctx.weight, dt, True)):
+        return None
+    G = ctx.groups
+    dy = ctx.grad_output.to(dt)
+    dx = dw = None
+    if need_dx:
+        dx = hip_gemm.hip_dgrad_grouped(dy, ctx.weight, ctx.kernel_map, ctx.in_features.shape[0]).to(ctx.in_features.dtype)
+    if need_dw:
+        # the AtB kernel tiles the [Cin, Cout] plane; the block-diagonal problem runs as G calls on channel slices
+        x = ctx.in_features.to(dt)
+        K, _, cg_in, cg_out = ctx.weight.shape
+        dws = []
+        for g in range(G):
+            xs, gs = _group_slices(x, G, g), _group_slices(dy, G, g)
+            dws.append(hip_gemm.hip_wgrad(xs, gs, ctx.kernel_map, (K, cg_in, cg_out), algo))
+        dw = torch.stack(dws, dim=1)
+    return dx, dw
+
+
 def _group_slices(t: Tensor, groups: int, g: int) -> Tensor:
     c = t.shape[1] // groups
     return t[:, g * c : (g + 1) * c].contiguous()
@@ -128,6 +187,9 @@ def run_forward(algo: str, ctx: FwdCtx):
     except KeyError:
         raise ValueError(f"Unsupported forward algorithm: {algo}")
     if ctx.groups > 1:
+        fast = _grouped_fast_forward(algo, ctx)
+        if fast is not None:
+            return fast
         # Channel groups (weight [K, G, Cin/G, Cout/G], reference sparse_conv.py:147-157): G independent problems on
         # channel slices, same kernel map.  Slices are made contiguous (the kernels take dense [N, C] rows).
         G = ctx.groups
@@ -153,6 +215,9 @@ def run_backward(algo: str, ctx: BwdCtx):
     except KeyError:
         raise ValueError(f"Unsupported backward algorithm: {algo}")
     if ctx.groups > 1:
+        fast = _grouped_fast_backward(algo, ctx)
+        if fast is not None:
+            return fast
         G = ctx.groups
         dxs, dws, dbs = [], [], []
         for g in range(G):

@@ -316,3 +316,95 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
     if scale is not None:
         dw = dw * scale
     return (dw, None) if want_bias_grad else dw
+
+
+# ---- channel groups -----------------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=None)
+def _grouped_ok(kin: int, kout: int, K: int, code: int) -> bool:
+    return bool(_lib.lib().wcn_mfma_grouped_supported(kin, kout, K, code))
+
+
+def grouped_supported(weight: Tensor, dtype: torch.dtype, transposed: bool) -> bool:
+    """Can the grouped gather-GEMM take this weight ([K, G, Cin/G, Cout/G]) in ONE launch?  Per-group widths must be a
+    shape of the 32x32x16 kernels, storage 16-bit."""
+    if weight.ndim != 4 or not weight.is_cuda or dtype not in (torch.float16, torch.bfloat16):
+        return False
+    K, G, cg_in, cg_out = weight.shape
+    kin, kout = (cg_out, cg_in) if transposed else (cg_in, cg_out)
+    return _grouped_ok(kin, kout, K, _lib.dtype_code(dtype))
+
+
+def _pack_grouped(weight: Tensor, transpose: bool, flip: bool, dtype: torch.dtype) -> Tensor:
+    """G packed images back to back, one launch; cached on the parameter per version like `pack_weight`."""
+    K, G, cg_in, cg_out = weight.shape
+    kin, kout = (cg_out, cg_in) if transpose else (cg_in, cg_out)
+    key = ("grouped", dtype, bool(transpose), bool(flip))
+    cache = getattr(weight, "_wcn_packed", None)
+    if cache is not None:
+        hit = cache.get(key)
+        if hit is not None and hit[0] == weight._version:
+            return hit[1]
+    w = weight.contiguous()
+    if w.dtype not in (torch.float32, dtype):
+        w = w.to(dtype)
+    packed = torch.empty(w.numel(), dtype=dtype, device=w.device)
+    _lib.check(
+        _lib.lib().wcn_pack_weight_grouped(_lib.ptr(w), int(w.dtype == torch.float32), K, G, kin, kout, _lib.dtype_code(dtype),
+                                           int(transpose), int(flip), _lib.ptr(packed), _lib.stream_handle(w.device)),
+        "wcn_pack_weight_grouped",
+    )
+    if weight.requires_grad and weight.is_leaf:
+        if cache is None:
+            cache = {}
+            try:
+                weight._wcn_packed = cache
+            except AttributeError:
+                return packed
+        cache[key] = (weight._version, packed)
+    return packed
+
+
+def _grouped_gather(x: Tensor, packed: Tensor, tbl: Tensor, mask: Tensor, perm: Tensor, n_out: int, kin: int, kout: int,
+                    G: int, K: int, bias: Optional[Tensor]) -> Tensor:
+    out = torch.empty((n_out, G * kout), dtype=x.dtype, device=x.device)
+    if n_out == 0:
+        return out
+    _lib.check(
+        _lib.lib().wcn_conv_gather_gemm_grouped(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(out), _lib.ptr(tbl), _lib.ptr(mask),
+                                                _lib.ptr(perm), _lib.ptr(bias), x.shape[0], n_out, kin, kout, G, K,
+                                                _lib.dtype_code(x.dtype), _lib.stream_handle(x.device)),
+        "wcn_conv_gather_gemm_grouped",
+    )
+    return out
+
+
+def hip_forward_grouped(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_out_coords: int,
+                        bias: Optional[Tensor] = None) -> Tensor:
+    """y[m][g] = sum_k x[nbr[m][k]][g] @ w[k][g]: all groups in one launch, the group index on grid.y (reference: one launch
+    with the group on grid.z, `MaskGemm_forward_64x64x32_1s_flat.h:117-123`).  No channel-slice copies, no concatenation."""
+    x = _prep(in_features, "in_features")
+    K, G, cg_in, cg_out = weight.shape
+    assert K == len(kernel_map) and x.shape[1] == G * cg_in
+    if bias is not None:
+        bias = _prep(bias.detach().float(), "bias")
+    kernel_map.poll()
+    attach_tables_from_csr(kernel_map, x.shape[0], num_out_coords)
+    packed = _pack_grouped(weight, False, False, x.dtype)
+    return _grouped_gather(x, packed, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cg_in, cg_out, G, K, bias)
+
+
+def hip_dgrad_grouped(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_in_coords: int) -> Tensor:
+    dy = _prep(grad_output, "grad_output")
+    K, G, cg_in, cg_out = weight.shape
+    kernel_map.poll()
+    if getattr(kernel_map, "_has_duplicates", False):
+        return torch.cat([_dgrad_pair_lists(dy[:, g * cg_out : (g + 1) * cg_out], weight[:, g].to(dy.dtype), kernel_map,
+                                            num_in_coords) for g in range(G)], dim=1)
+    attach_tables_from_csr(kernel_map, num_in_coords, dy.shape[0])
+    if kernel_map._symmetric:
+        tbl, mask, perm, flip = kernel_map._nbr, kernel_map._mask, kernel_map._perm, True
+    else:
+        tbl, mask, perm = reverse_tables(kernel_map, num_in_coords)
+        flip = False
+    packed = _pack_grouped(weight, True, flip, dy.dtype)
+    return _grouped_gather(dy, packed, tbl, mask, perm, num_in_coords, cg_out, cg_in, G, K, None)
