@@ -139,8 +139,9 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
  *   tally  per-(offset, tile) pair counts from the masks, the first digit histogram of the mask sort, and - when
  *          `binned_workspace` (the workspace of the wcn_kmap_build_binned call that produced nbr / mask, with its n and
  *          max_blocks) is given - repair of the rows of duplicate coordinates
- *   scan   offsets int32 [K+1] on the device and, if `host_mirror` (K + 2 int32 of pinned, device-accessible HOST
- *          memory) is given, offsets ++ [*status] there in the same launch
+ *   scan   offsets int32 [K+1] on the device and, if `host_mirror` (K + 3 int32 of pinned, device-accessible HOST
+ *          memory) is given, offsets ++ [*status] ++ [ready] there in the same launch: `ready` (cleared by the caller)
+ *          becomes 1 last, behind a system-scope fence, so the host may spin on it instead of waiting for an event
  *   sort   perm = rows by descending mask (wcn_mask_argsort), the first digit already counted
  * counts: wcn_kmap_counts_bytes(m, K) bytes, consumed by wcn_kmap_scatter.  sort_workspace:
  * wcn_kmap_tally_sort_workspace(m) bytes.  reference: postprocess_count + torch.cumsum + mask_argsort
@@ -158,7 +159,7 @@ int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t
  * reference: host torch.cumsum in torch_discrete.py:268-272. */
 int wcn_kmap_scan(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets,
                   wcn_stream_t stream);
-/* the same, and in the same launch offsets[0..K] ++ [*status] are also written to `host_mirror` - K + 2 int32 of pinned
+/* the same, and in the same launch offsets[0..K] ++ [*status] ++ [ready = 1] are also written to `host_mirror` - K + 3 int32 of pinned
  * (device-accessible) HOST memory: the one host read of a build (torch_discrete.py:268-272 does `.item()` per value)
  * becomes an event wait behind this kernel, no copy command. */
 int wcn_kmap_scan_to_host(int32_t* counts, int64_t num_blocks, int32_t num_offsets, int32_t* offsets, const int32_t* status,

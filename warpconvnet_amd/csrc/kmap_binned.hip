@@ -134,7 +134,9 @@ __global__ __launch_bounds__(kInsertThreads) void cell_insert_kernel(BSlot* __re
       unsigned long long cur = ((unsigned long long)v.y << 32) | v.x;
       if (cur == key) { found = (int)s; idv = (int)v.z; break; }
       if (cur == 0ull) {
-        cur = __hip_atomic_load(kptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // sampled pass: most keys really are absent, go straight to the CAS (it returns the current value either way);
+        // second pass: an empty-looking slot is almost always a stale line, a coherent load is cheaper than an atomic
+        if (PHASE == 1) cur = __hip_atomic_load(kptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0ull) {
           cur = atomicCAS(kptr, 0ull, (unsigned long long)key);
           if (cur == 0ull) {  // this thread created the block (its dense id is handed out below)

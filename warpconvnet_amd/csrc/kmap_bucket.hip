@@ -235,11 +235,16 @@ __global__ __launch_bounds__(kBkThreads) void kmap_scan_kernel(int32_t* __restri
     }
     carry += trip_total;
   }
+  __syncthreads();
   if (tid == 0) {
     offsets[0] = 0;
     if (mirror) {
       mirror[0] = 0;
       mirror[K + 1] = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      // READY word, written last and behind a system-scope fence: a host that spins on it (instead of sleeping in an event
+      // wait, 20-50 us of wake-up latency on this platform) sees complete offsets and flags once it reads non-zero
+      __threadfence_system();
+      __hip_atomic_store(&mirror[K + 2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -463,7 +468,7 @@ int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_off
   hipStream_t s = (hipStream_t)stream;
   if (m == 0) {  // no rows: offsets are all zero, nothing to sort
     if (hipMemsetAsync(offsets, 0, (size_t)(num_offsets + 1) * 4, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
-    if (host_mirror) {
+    if (host_mirror) {  // (the READY word stays clear: the caller of an empty build waits for its event)
       if (hipMemsetAsync(host_mirror, 0, (size_t)(num_offsets + 1) * 4, s) != hipSuccess ||
           hipMemcpyAsync(host_mirror + num_offsets + 1, status, 4, hipMemcpyDeviceToHost, s) != hipSuccess)
         return WCN_ERROR_KERNEL_EXECUTION;

@@ -32,17 +32,20 @@ __device__ __forceinline__ uint32_t rs_digit(uint32_t key, int shift) { return (
 
 enum RsRole { kRsHist = 0, kRsScan = 1, kRsScatter = 2 };
 
+// A pass reads either the mask tensor itself (first pass: keys at `kin[i * stride]`, row id = i) or the (key, row) PAIRS the
+// previous pass wrote, and writes pairs again - ONE 8-B scattered store per element, the scatter kernels are bound by
+// the number of scattered stores (tools/cell_probe.hip: 16 us per million) - or, in the last pass, the row ids alone.
 struct RsArgs {
-  const uint32_t* kin;  // first pass: the mask tensor itself (stride = mask words); later passes: the ping-pong buffer
+  const uint32_t* kin;  // first pass only
   int64_t stride;
-  const int32_t* vin;   // carried row ids (null: identity)
+  const uint2* pin;     // later passes: (key, row) pairs
   int64_t n;
   int shift;
   int nblk;
   int32_t* counts;      // [kRsBins][nblk]
   int32_t* totals;      // [kRsBins]
-  uint32_t* kout;
-  int32_t* vout;
+  uint2* pout;          // all but the last pass
+  int32_t* vout;        // last pass: the permutation
 };
 
 struct RsLaunch {
@@ -54,8 +57,7 @@ struct RsLaunch {
 struct SortPlan {
   int nblk;           // tiles of kRsTile keys
   int passes;
-  uint32_t* kbuf[2];  // ping-pong keys
-  int32_t* vtmp;      // ping-pong values (the other buffer is `perm`)
+  uint2* pbuf[2];     // ping-pong (key, row) pairs
   int32_t* counts;    // [kRsBins][nblk] per-(digit, tile) counts, scanned in place
   int32_t* totals;    // [kRsBins] digit totals
   size_t bytes;
@@ -81,7 +83,8 @@ __device__ __forceinline__ void rs_hist_body(const RsArgs& a, int blk, char* sme
 #pragma unroll
   for (int j = 0; j < kPer; ++j) {
     const int64_t idx = base + threadIdx.x + j * kRsThreads;
-    k[j] = a.kin[(idx < a.n ? idx : a.n - 1) * a.stride];
+    const int64_t at = idx < a.n ? idx : a.n - 1;
+    k[j] = a.pin ? a.pin[at].x : a.kin[at * a.stride];
   }
 #pragma unroll
   for (int j = 0; j < kPer; ++j)
@@ -133,8 +136,14 @@ __device__ __forceinline__ void rs_scatter_body(const RsArgs& a, int blk, char* 
   for (int j = 0; j < kBatches; ++j) {
     const int64_t idx = wave_begin + j * 64 + lane;
     const int64_t at = idx < a.n ? idx : a.n - 1;
-    kreg[j] = a.kin[at * a.stride];
-    vreg[j] = a.vin ? a.vin[at] : (int32_t)at;
+    if (a.pin) {
+      const uint2 kv = a.pin[at];
+      kreg[j] = kv.x;
+      vreg[j] = (int32_t)kv.y;
+    } else {
+      kreg[j] = a.kin[at * a.stride];
+      vreg[j] = (int32_t)at;
+    }
   }
   // ... and so are the digit totals and this block's (digit, block) bases: everything the kernel reads from global memory
   // is in flight at once
@@ -195,8 +204,8 @@ __device__ __forceinline__ void rs_scatter_body(const RsArgs& a, int blk, char* 
     if (live) {
       const int rank = __popcll(peers & lt);
       const int pos = my_base[d] + rank;
-      a.kout[pos] = key;
-      a.vout[pos] = vreg[j];
+      if (a.pout) a.pout[pos] = make_uint2(key, (uint32_t)vreg[j]);
+      else a.vout[pos] = vreg[j];
       // the last peer advances the running base after every peer has read it (same wave, LDS ops are in order)
       if ((peers >> lane) == 1ull) my_base[d] = pos + 1;
     }

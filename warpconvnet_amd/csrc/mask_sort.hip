@@ -15,17 +15,16 @@ SortPlan sort_plan(void* workspace, int64_t n, int num_bits) {
   SortPlan p;
   p.nblk = (int)ceil_div(n > 0 ? n : 1, kRsTile);
   char* ws = (char*)workspace;
-  const size_t seg = al256((size_t)(n > 0 ? n : 1) * 4);
-  p.kbuf[0] = (uint32_t*)ws;
-  p.kbuf[1] = (uint32_t*)(ws ? ws + seg : nullptr);
-  p.vtmp = (int32_t*)(ws ? ws + 2 * seg : nullptr);
-  p.counts = (int32_t*)(ws ? ws + 3 * seg : nullptr);
+  const size_t seg = al256((size_t)(n > 0 ? n : 1) * 8);
+  p.pbuf[0] = (uint2*)ws;
+  p.pbuf[1] = (uint2*)(ws ? ws + seg : nullptr);
+  p.counts = (int32_t*)(ws ? ws + 2 * seg : nullptr);
   p.totals = p.counts ? p.counts + (int64_t)kRsBins * p.nblk : nullptr;
   // only the low `num_bits` bits of word 0 can be set (num_bits = min(K, 32)): 3 passes for a 3x3x3 kernel
   if (num_bits > 32) num_bits = 32;
   if (num_bits < 1) num_bits = 1;
   p.passes = (num_bits + kRsBits - 1) / kRsBits;
-  p.bytes = 3 * seg + al256((size_t)kRsBins * (p.nblk + 1) * 4) + 256;
+  p.bytes = 2 * seg + al256((size_t)kRsBins * (p.nblk + 1) * 4) + 256;
   return p;
 }
 
@@ -35,23 +34,22 @@ int sort_launches(const SortPlan& p, const uint32_t* mask, int mask_words, int64
   RsArgs a;
   a.kin = mask;
   a.stride = mask_words;
-  a.vin = nullptr;
+  a.pin = nullptr;
   a.n = n;
   a.nblk = p.nblk;
   a.counts = p.counts;
   a.totals = p.totals;
   for (int pass = 0; pass < p.passes; ++pass) {
     a.shift = pass * kRsBits;
-    a.kout = p.kbuf[pass & 1];
-    a.vout = ((p.passes - 1 - pass) & 1) ? p.vtmp : perm;  // last pass writes perm
+    const bool last = pass == p.passes - 1;
+    a.pout = last ? nullptr : p.pbuf[pass & 1];
+    a.vout = last ? perm : nullptr;  // the last pass writes the permutation alone
     if (!(pass == 0 && first_counted)) {
       out[count++] = RsLaunch{kRsHist, p.nblk, a};
       out[count++] = RsLaunch{kRsScan, kRsBins, a};
     }
     out[count++] = RsLaunch{kRsScatter, p.nblk, a};
-    a.kin = a.kout;
-    a.stride = 1;
-    a.vin = a.vout;
+    a.pin = a.pout;
   }
   return count;
 }

@@ -129,6 +129,9 @@ def _first_half(full: IntSearchResult) -> IntSearchResult:
     return IntSearchResult(full.in_maps_device[:n].clone(), full.out_maps_device[:n].clone(), offs, identity_map_index=c)
 
 
+_SPIN_POLLS = int(os.environ.get("WARPCONVNET_AMD_KMAP_SPIN", "4000"))  # ~0.1 us each: up to ~0.4 ms of spinning
+
+
 # binned builder: does this process see scenes with >= 4 voxels per occupied 8^3 block?  (size of the first-try block table)
 _BINNED_HINT = {"dense": True}
 
@@ -265,7 +268,9 @@ def generate_kernel_map(
         # tally (pair counts per tile + first sort digit + duplicate repair) -> scans (offsets + status flags written to
         # pinned host memory by the kernel itself, no copy command) -> mask argsort; the sort does not depend on the pair
         # count and keeps the GPU busy during the host round trip
-        meta_host = torch.empty(K + 2, dtype=torch.int32, pin_memory=True)
+        meta_host = torch.empty(K + 3, dtype=torch.int32, pin_memory=True)
+        ready = ctypes.c_int32.from_address(meta_host.data_ptr() + 4 * (K + 2))
+        ready.value = 0
         sort_bytes = L.wcn_kmap_tally_sort_workspace(M)
         sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
         _lib.check(
@@ -279,7 +284,14 @@ def generate_kernel_map(
         event.record(torch.cuda.current_stream(dev))
         if async_ok:
             break
-        event.synchronize()
+        # the scan kernel raises the READY word of the pinned mirror behind a system-scope fence: spinning on it costs a
+        # few microseconds where the event wait costs a thread wake-up; bounded, then the ordinary wait (long queues, M = 0)
+        if M > 0:
+            for _ in range(_SPIN_POLLS):
+                if ready.value:
+                    break
+        if not ready.value:
+            event.synchronize()
         flags = int(meta_host[K + 1])
         if use_binned and (flags & _lib.WCN_FLAG_TABLE_FULL) and max_blocks < N:
             _BINNED_HINT["dense"] = False  # this process sees sparse scenes: start with the large table from now on

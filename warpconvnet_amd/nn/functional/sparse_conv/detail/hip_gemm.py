@@ -143,6 +143,33 @@ def _pack_weight_uncached(weight: Tensor, K: int, kin: int, kout: int, transpose
     return packed
 
 
+# ---- channel counts outside the MFMA tiles (C in {3, 7, 13, 23, 33, 65}, ...): zero-padded channels --------------------------
+# The reference covers them with scalar-load tile variants and a zero-filled K tail (`mask_gemm.py:495-541`,
+# `warpgemm_a_loader_precomputed.cuh:176-224`).  Here the operands are padded with zero channels to the next shape the
+# MFMA kernels take and the result is cut back: zeros contribute nothing to any of the three products, so the values are
+# those of the unpadded problem (same fp32 accumulation), at the cost of one padded copy of the operands.
+_MFMA_COUTS = (16, 32, 48, 64, 96, 128, 160, 192, 256, 384, 512)
+
+
+def _code16(dtype: torch.dtype) -> int:
+    return _lib.WCN_F16 if dtype == torch.float32 else _lib.dtype_code(dtype)
+
+
+def _pad_plan(kin: int, kout: int, K: int, dtype: torch.dtype):
+    """(kin_padded, kout_padded) of the smallest MFMA gather-GEMM shape that contains kin x kout, or None."""
+    if dtype not in (torch.float16, torch.bfloat16):
+        return None  # fp32 features keep full fp32 operands on the shapes the MFMA kernels do not take natively
+    kin_p = max(32, (kin + 31) // 32 * 32)
+    for kout_p in _MFMA_COUTS:
+        if kout_p >= kout and _gather_ok(kin_p, kout_p, K, _code16(dtype)):
+            return kin_p, kout_p
+    return None
+
+
+def _pad_cols(t: Tensor, width: int) -> Tensor:
+    return t if t.shape[-1] == width else torch.nn.functional.pad(t, (0, width - t.shape[-1]))
+
+
 def master_weight_ok(x_dtype: torch.dtype, weight: Tensor, algo: str, transposed: bool) -> bool:
     """May ``weight`` stay an fp32 master for 16-bit features?  Only when the MFMA kernel takes the shape: the packed
     image is then produced from fp32 directly; every other path multiplies in the storage dtype and needs the cast."""
@@ -196,6 +223,13 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
         raise RuntimeError(f"hip forward error: {_lib.status_string(-6)} ({x.dtype} vs {w.dtype})")
     K, cin, cout = w.shape
     assert K == len(kernel_map) and cin == x.shape[1]
+    if algo == "auto" and x.is_cuda and not _gather_ok(cin, cout, K, _code16(x.dtype)):
+        plan = _pad_plan(cin, cout, K, x.dtype)
+        if plan is not None:  # zero-padded channels on the MFMA kernels instead of one thread per output element
+            wp_ = torch.nn.functional.pad(w.to(x.dtype) if w.dtype != x.dtype else w, (0, plan[1] - cout, 0, plan[0] - cin))
+            y = hip_forward(_pad_cols(x, plan[0]), wp_, kernel_map, num_out_coords, algo,
+                            None if bias is None else _pad_cols(bias, plan[1]))
+            return y[:, :cout].contiguous()
     kernel_map.poll()
     attach_tables_from_csr(kernel_map, x.shape[0], num_out_coords)
     if _fp32_via_fp16(algo, cin, cout, K, x.dtype):
@@ -251,6 +285,11 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
     kernel_map.poll()
     if getattr(kernel_map, "_has_duplicates", False):
         return _dgrad_pair_lists(dy, w, kernel_map, num_in_coords)
+    if algo == "auto" and dy.is_cuda and not _gather_ok(cout, cin, K, _code16(dy.dtype)):
+        plan = _pad_plan(cout, cin, K, dy.dtype)  # kernel-side roles: reduce over cout, produce cin
+        if plan is not None:
+            wp_ = torch.nn.functional.pad(w.to(dy.dtype) if w.dtype != dy.dtype else w, (0, plan[0] - cout, 0, plan[1] - cin))
+            return hip_dgrad(_pad_cols(dy, plan[0]), wp_, kernel_map, num_in_coords, algo)[:, :cin].contiguous()
     attach_tables_from_csr(kernel_map, num_in_coords, dy.shape[0])
     if kernel_map._symmetric:
         tbl, mask, perm, flip = kernel_map._nbr, kernel_map._mask, kernel_map._perm, True
@@ -280,6 +319,13 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
         raise RuntimeError(f"hip wgrad error: {_lib.status_string(-6)} ({x.dtype} vs {dy.dtype})")
     K, cin, cout = weight_shape
     dev = x.device
+    if algo == "auto" and x.is_cuda and not _wgrad_ok(cin, cout, _code16(x.dtype)):
+        cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+        if x.dtype != torch.float32 and _wgrad_ok(cin_p, cout_p, _code16(x.dtype)):  # zero-padded channels: the padded rows / columns of dw are zero
+            r = hip_wgrad(_pad_cols(x, cin_p), _pad_cols(dy, cout_p), kernel_map, (K, cin_p, cout_p), algo, want_bias_grad)
+            dw_p, db = r if want_bias_grad else (r, None)
+            dw_c = dw_p[:, :cin, :cout].contiguous()
+            return (dw_c, None if db is None else db[:cout].contiguous()) if want_bias_grad else dw_c
     kernel_map.poll()
     scale = None
     if x.dtype == torch.float32 and algo != "hip_ref" and _wgrad_ok(cin, cout, _lib.WCN_F16):
