@@ -90,5 +90,17 @@ int main() {
   run<1, 4>("line-coalesced,  128 KB window", in, idx, npairs, out, 2048);
   run<2, 4>("16x16x32 operand order, 128 KB window", in, idx, npairs, out, 2048);
   run<3, 4>("row-shaped 64 B, 128 KB window", in, idx, npairs, out, 2048);
+  // window sweep: where the rate falls from the L2 figure to the fabric / Infinity Cache figure
+  for (long win : {1024L, 8192L, 32768L, 131072L, 524288L}) {  // rows of 128 B: 128 KB, 1 MB, 4 MB, 16 MB, 64 MB
+    for (long i = 0; i < npairs; ++i) h[i] = (int)(rng() % win);
+    hipMemcpy(idx, h.data(), npairs * 4, hipMemcpyHostToDevice);
+    char name[64];
+    snprintf(name, sizeof name, "fragment-shaped, %ld KB window", win / 8);
+    run<0, 4>(name, in, idx, npairs, out, 2048);
+    snprintf(name, sizeof name, "row-shaped 64 B, %ld KB window", win / 8);
+    run<3, 4>(name, in, idx, npairs, out, 2048);
+    snprintf(name, sizeof name, "line-coalesced 128 B, %ld KB window", win / 8);
+    run<1, 4>(name, in, idx, npairs, out, 2048);
+  }
   return 0;
 }
