@@ -239,3 +239,69 @@ def test_radius_grid_matches_reference_golden(golden_dir, tag):
         for j in set(got) & set(want):
             assert abs(got[j] ** 2 - want[j] ** 2) <= 3e-5
     assert mismatched <= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,cout,k,red,rel", [(5000, 32, 64, 16, "mean", False), (1234, 8, 16, 8, "sum", False),
+                                                  (3001, 16, 32, 4, "mean", False), (2000, 8, 19, 32, "mean", True),
+                                                  (700, 4, 8, 1, "sum", False), (4097, 24, 48, 2, "mean", False)])
+def test_pointconv_fused_edge_kernel_vs_fp64(n, cin, cout, k, red, rel):
+    """The one-pass edge pipeline (csrc/pointconv.hip: gather -> Linear -> LN -> ReLU -> Linear -> LN + shortcut ->
+    reduction, forward and backward) against the same module evaluated op by op in fp64 on the CPU from the same
+    neighbour lists: output rows, input-feature gradient, every parameter gradient."""
+    import copy
+
+    from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
+    from warpconvnet_amd.geometry.types.points import Points
+    from warpconvnet_amd.nn.functional import point_conv as fpc
+    from warpconvnet_amd.nn.modules import PointConv
+    from warpconvnet_amd.ops.reductions import row_reduction
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(n + k)
+    coords = torch.rand(n, 3, generator=g) * 4.0
+    feats = torch.randn(n, cin, generator=g)
+    cfg = RealSearchConfig(mode="knn", knn_k=k)
+    torch.manual_seed(1)
+    conv = PointConv(cin, cout, cfg, reductions=(red,), use_rel_pos=rel)
+    with torch.no_grad():  # non-trivial LayerNorm weights
+        for m in conv.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(conv).double()
+    conv = conv.to(dev)
+    x = feats.to(dev).requires_grad_(True)
+    pc = Points(coords.to(dev), x, offsets=torch.tensor([0, n // 3, n]))
+    nb = pc.neighbors(query_coords=pc.batched_coordinates, search_args=cfg)
+    assert fpc.fused_edge_supported(conv.edge_transform_mlp, x, x, 3 if rel else 0, k, red)
+    calls = []
+    orig = fpc._FusedEdge.apply
+    fpc._FusedEdge.apply = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        out = conv(pc).feature_tensor
+    finally:
+        fpc._FusedEdge.apply = orig
+    assert calls, "the fused edge kernel was not used"
+    dy = torch.randn(n, cout, generator=g)
+    out.backward(dy.to(dev))
+
+    idx = nb.neighbor_indices.cpu().view(-1)
+    xr = feats.double().requires_grad_(True)
+    edge = [xr[idx], xr.repeat_interleave(k, dim=0)]
+    if rel:
+        edge.append((coords[idx] - coords.repeat_interleave(k, dim=0)).double())
+    e = ref.edge_transform_mlp(torch.cat(edge, 1))
+    want = ref.out_transform_mlp(row_reduction(e, torch.arange(0, n * k + 1, k), reduction=red))
+    want.backward(dy.double())
+    torch.testing.assert_close(out.detach().cpu().double(), want.detach(), rtol=1e-4, atol=1e-4)
+    # input gradient: a ReLU whose pre-activation is within fp32 rounding of zero takes the other branch than in fp64 and
+    # moves the 64 gradient entries of that edge - a handful of the 10^7 activations; everything else must agree tightly
+    got, wantg = x.grad.cpu().double(), xr.grad
+    bad = (got - wantg).abs() > 1e-4 + 1e-3 * wantg.abs()
+    assert bad.double().mean() < 2e-3, f"{int(bad.sum())} of {bad.numel()} input-gradient entries off"
+    assert float((got - wantg).norm() / wantg.norm()) < 1e-3
+    for (name, p), (_, pr) in zip(conv.named_parameters(), ref.named_parameters()):
+        scale = float(pr.grad.abs().max()) + 1e-12
+        err = float((p.grad.cpu().double() - pr.grad).abs().max()) / scale
+        assert err < 1e-3, f"{name}: relative max error {err:.2e}"

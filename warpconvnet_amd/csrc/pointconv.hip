@@ -1,0 +1,762 @@
+// pointconv.hip - the PointConv edge pipeline in one pass (gfx950, fp32 on the matrix cores).
+//
+// Reference: warpconvnet/nn/modules/point_conv.py:231-273 (gather neighbour / query features, concatenate, edge MLP,
+// reduce over the neighbours of a query) with the edge MLP of warpconvnet/nn/modules/mlp.py:124-177
+// (Linear - LayerNorm - ReLU - Linear - LayerNorm, + identity shortcut).  The reference materialises the
+// [M*k, C] edge tensors in HBM between every one of those steps; here an edge never leaves the chip:
+//
+//   x_e = [in_feats[nbr[e]] | q_feats[q(e)] | in_xyz[nbr[e]] - q_xyz[q(e)]]          gathered into registers
+//   h   = ReLU(LN1(W1 x_e + b1)),  o = LN2(W2 h + b2) + x_e,  out[q] = sum|mean_e o   (forward)
+//   and the whole backward of that chain, recomputing the forward per tile               (backward)
+//
+// Work decomposition ("tensor parallel workgroup"): a workgroup of 4 waves walks 32-edge tiles (32 / k queries).  Every
+// wave holds the tile's x; wave w owns hidden channels [w*HID/4, (w+1)*HID/4) through the whole chain, so the weight
+// gradient blocks it accumulates (its rows of dW1 / dW2) live in registers for the lifetime of the kernel.  All GEMMs
+// are v_mfma_f32_32x32x2_f32 in the TRANSPOSED form (rows = channels, columns = the 32 edges):
+//   * a result tile puts edge e in lane e / e+32 and 16 channels in registers, channel sigma(r, h) = 8*(r/4) + 4*h + r%4;
+//   * that is exactly a B operand (k-pair = channels sigma(r,0), sigma(r,1)) of the next GEMM, so GEMM1 -> LN -> ReLU ->
+//     GEMM2 and the whole data-gradient chain run register to register, the permutation folded into the packed weights;
+//   * LayerNorm reduces over registers + one lane swap + a 1-KiB exchange between the waves;
+//   * only the weight-gradient GEMMs (reduction over edges) need the other orientation: the operands take one trip
+//     through a wave-private LDS tile [channel][edge].
+// Weights are read as A operands straight from a packed image in global memory (L1/L2 resident, 16 B per lane).
+#include "wcn_common.h"
+
+namespace wcn {
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kPcWaves = 4;
+constexpr int kPitch = 36;  // floats per row of the [channel][32 edges] LDS tiles: b128 reads of 8 lanes hit 32 banks
+
+__host__ __device__ constexpr int sigma(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float half_swap(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float half_sum32(float v) {  // sum over the 32 lanes of a half
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// Compile-time shape of one kernel instance (channel counts padded with zeros up to it) and the packed-image layout.
+template <int EIN_, int HID_, int CO_>
+struct PC {
+  static constexpr int EIN = EIN_, HID = HID_, CO = CO_;
+  static constexpr int KS1 = EIN / 2;   // x registers per lane: lane half h holds channels [h*KS1, (h+1)*KS1)
+  static constexpr int HB = HID / 128;  // hidden 32-blocks per wave
+  static constexpr int NB1 = HID / 32, NB2 = CO / 32, NBX = EIN / 32;
+  static constexpr int NBP = NB2 > NBX ? NB2 : NBX;
+  static_assert(EIN % 32 == 0 && HID % 128 == 0 && CO % 32 == 0, "tile shape");
+  // packed image (floats)
+  static constexpr int OFF_P1 = 0;                    // [NB1][KS1/4][64][4]      GEMM1 A: W1[c = h*KS1+s][hid = 32blk+i]
+  static constexpr int OFF_P2 = OFF_P1 + EIN * HID;   // [NB1][NB2][4][64][4]     GEMM2 A: W2[hid = 32blk+sigma(r,h)][out = 32b+i]
+  static constexpr int OFF_P2T = OFF_P2 + HID * CO;   // [NB1][NB2][4][64][4]     dH A:    W2[hid = 32blk+i][out = 32b+sigma(r,h)]
+  static constexpr int OFF_P1T = OFF_P2T + HID * CO;  // [NB1][NBX][4][64][4]     dX A:    W1[c = 32cb+i][hid = 32blk+sigma(r,h)]
+  static constexpr int OFF_T1 = OFF_P1T + EIN * HID;  // [NB1][3][2][16]          b1, g1, be1 at channel 32blk+sigma(r,h)
+  static constexpr int OFF_T2 = OFF_T1 + NB1 * 96;    // [NB2][3][2][16]          b2, g2, be2
+  static constexpr int PACKED = OFF_T2 + NB2 * 96;
+  // LDS (floats)
+  static constexpr int L_TX = 0;                              // [EIN][kPitch]      x, channel-major (identity shortcut, dW1 A)
+  static constexpr int L_TH = L_TX + EIN * kPitch;            // [HID][kPitch]      per wave: H, later dHpre, channel-major
+  static constexpr int L_TB = L_TH + HID * kPitch;            // [CO][kPitch]       dOpre channel-major / forward output tile
+  static constexpr int L_PO = L_TB + CO * kPitch;             // [4][NBP][16][64]   partial tiles exchanged between the waves
+  static constexpr int L_ST = L_PO + kPcWaves * NBP * 1024;   // [2][4][32][2]      LayerNorm partial sums
+  static constexpr int L_DXT = L_ST + 2 * kPcWaves * 64;      // [32][EIN+1]        dX, edge-major
+  static constexpr int L_DOUT = L_DXT + 32 * (EIN + 1);       // [32][CO]           grad_out rows of the tile's queries
+  static constexpr int L_JT = L_DOUT + 32 * CO;               // [32] int           neighbour ids
+  static constexpr int LDS_FLOATS = L_JT + 32;
+};
+
+struct PcArgs {
+  const float* in_feats;  // [n_in][cin]
+  const float* q_feats;   // [n_query][cq]
+  const float* in_xyz;    // [n_in][3]     (nrel == 3)
+  const float* q_xyz;     // [n_query][3]
+  const int32_t* nbr;     // [n_query * k]
+  int64_t n_query;
+  int32_t log2k, cin, cq, nrel;
+  const float* packed;
+  int32_t ein_t, hid_t, co_t;  // true channel counts
+  float eps1, eps2, scale;     // scale: 1 (sum) or 1/k (mean)
+  float* out;                  // forward:  [n_query][co_t]
+  const float* grad_out;       // backward: [n_query][co_t]
+  float* d_in;                 //           [n_in][cin], zero-filled by the caller (accumulated with atomics)
+  float* d_q;                  //           [n_query][cq]
+  float* partial;              //           [grid][grad floats] per-workgroup parameter-gradient partials
+};
+
+// gradient blob (floats, torch layouts): dW1 [hid][ein] | db1 | dg1 | dbe1 | dW2 [co][hid] | db2 | dg2 | dbe2
+__host__ __device__ inline int64_t grad_floats(int ein_t, int hid_t, int co_t) {
+  return (int64_t)hid_t * ein_t + 3 * hid_t + (int64_t)co_t * hid_t + 3 * co_t;
+}
+
+template <int EIN, int HID, int CO, bool BWD>
+__global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const PcArgs a) {
+  typedef PC<EIN, HID, CO> P;
+  constexpr int KS1 = P::KS1, HB = P::HB, NB2 = P::NB2, NBX = P::NBX, NBP = P::NBP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tX = smem + P::L_TX;
+  float* tH = smem + P::L_TH;
+  float* tB = smem + P::L_TB;
+  float* po = smem + P::L_PO;
+  float* st = smem + P::L_ST;
+  float* dxt = smem + P::L_DXT;
+  float* dout = smem + P::L_DOUT;
+  int32_t* jt = reinterpret_cast<int32_t*>(smem + P::L_JT);
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, e = lane & 31;
+  const int k = 1 << a.log2k, nq = 32 >> a.log2k;
+  const int64_t n_edges = a.n_query << a.log2k;
+  const int64_t ntiles = (n_edges + 31) >> 5;
+  const float inv_hid = 1.f / (float)a.hid_t, inv_co = 1.f / (float)a.co_t;
+  const f32x4* pk4 = reinterpret_cast<const f32x4*>(a.packed);
+  float* thw = tH + w * HB * 32 * kPitch;  // this wave's rows of tH
+
+  // persistent parameter-gradient accumulators (backward)
+  f32x16 dW1a[NBX][HB], dW2a[HB][NB2];
+  float dg1a[HB][16], dbe1a[HB][16], db1a[HB][16];
+  float dg2a[NB2 * 4], dbe2a[NB2 * 4], db2a[NB2 * 4];  // this wave's quarter: items (b*16 + r) with (b*16+r) % 4 == w
+  if (BWD) {
+#pragma unroll
+    for (int cb = 0; cb < NBX; ++cb)
+#pragma unroll
+      for (int t = 0; t < HB; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dW1a[cb][t][q] = 0.f;
+#pragma unroll
+    for (int t = 0; t < HB; ++t)
+#pragma unroll
+      for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dW2a[t][b][q] = 0.f;
+#pragma unroll
+    for (int t = 0; t < HB; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dg1a[t][r] = dbe1a[t][r] = db1a[t][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB2 * 4; ++i) dg2a[i] = dbe2a[i] = db2a[i] = 0.f;
+  }
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- A. stage the tile: neighbour ids, grad_out rows, x ----
+    const int64_t E = tile * 32 + e;
+    const bool valid = E < n_edges;
+    const int64_t q = valid ? (E >> a.log2k) : 0;
+    const int32_t j = valid ? a.nbr[E] : 0;
+    if (BWD) {
+      if (w == 0 && h == 0) jt[e] = valid ? j : -1;
+      for (int i = tid; i < nq * CO; i += 256) {
+        const int ql = i / CO, ch = i - ql * CO;
+        const int64_t qq = tile * nq + ql;
+        dout[i] = (qq < a.n_query && ch < a.co_t) ? a.grad_out[qq * a.co_t + ch] * a.scale : 0.f;
+      }
+    }
+    float x[KS1];
+    {
+      const float* fi = a.in_feats + (int64_t)j * a.cin;
+      const float* fq = a.q_feats + q * a.cq;
+      const bool vec = ((a.cin | a.cq) & 3) == 0;
+#pragma unroll
+      for (int u = 0; u < KS1 / 4; ++u) {
+        const int c4 = h * KS1 + 4 * u;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+          if (vec && c4 + 4 <= a.cin) {
+            v = *reinterpret_cast<const f32x4*>(fi + c4);
+          } else if (vec && c4 >= a.cin && c4 + 4 <= a.cin + a.cq) {
+            v = *reinterpret_cast<const f32x4*>(fq + (c4 - a.cin));
+          } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const int c = c4 + d;
+              float s = 0.f;
+              if (c < a.cin) s = fi[c];
+              else if (c < a.cin + a.cq) s = fq[c - a.cin];
+              else if (c < a.cin + a.cq + a.nrel) s = a.in_xyz[(int64_t)j * 3 + (c - a.cin - a.cq)] - a.q_xyz[q * 3 + (c - a.cin - a.cq)];
+              v[d] = s;
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) x[4 * u + d] = v[d];
+      }
+      // channel-major copy of x (every wave writes a quarter of the registers)
+#pragma unroll
+      for (int s = 0; s < KS1; ++s)
+        if ((s & 3) == w) tX[(h * KS1 + s) * kPitch + e] = x[s];
+    }
+
+    // ---- GEMM1 (this wave's hidden blocks): Hpre^T = W1^T x^T + b1 ----
+    f32x16 acc1[HB];
+#pragma unroll
+    for (int t = 0; t < HB; ++t) {
+      const int blk = w * HB + t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+      const f32x4* pa = pk4 + P::OFF_P1 / 4 + (blk * (KS1 / 4)) * 64 + lane;
+#pragma unroll
+      for (int s4 = 0; s4 < KS1 / 4; ++s4) {
+        const f32x4 av = pa[s4 * 64];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc1[t] = mfma(av[d], x[4 * s4 + d], acc1[t]);
+      }
+    }
+    float g1v[HB][16], be1v[HB][16];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < HB; ++t) {
+      const float* t1 = a.packed + P::OFF_T1 + (w * HB + t) * 96 + h * 16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc1[t][r] += t1[r];
+        g1v[t][r] = t1[32 + r];
+        be1v[t][r] = t1[64 + r];
+        s1 += acc1[t][r];
+        s2 += acc1[t][r] * acc1[t][r];
+      }
+    }
+    s1 += half_swap(s1);
+    s2 += half_swap(s2);
+    if (h == 0) {
+      st[(w * 32 + e) * 2 + 0] = s1;
+      st[(w * 32 + e) * 2 + 1] = s2;
+    }
+    __syncthreads();  // 1: tX, st[0], (jt, dout)
+
+    float mu1, rstd1;
+    {
+      float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < kPcWaves; ++ww) {
+        S1 += st[(ww * 32 + e) * 2 + 0];
+        S2 += st[(ww * 32 + e) * 2 + 1];
+      }
+      mu1 = S1 * inv_hid;
+      rstd1 = rsqrtf(fmaxf(S2 * inv_hid - mu1 * mu1, 0.f) + a.eps1);
+    }
+    float xh1[HB][16], H[HB][16];
+#pragma unroll
+    for (int t = 0; t < HB; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        xh1[t][r] = (acc1[t][r] - mu1) * rstd1;
+        H[t][r] = fmaxf(xh1[t][r] * g1v[t][r] + be1v[t][r], 0.f);
+        if (BWD) thw[(t * 32 + sigma(r, h)) * kPitch + e] = H[t][r];
+      }
+
+    // ---- GEMM2, partial over this wave's hidden channels; the waves exchange partial tiles through LDS ----
+    {
+      f32x16 o[NB2];
+#pragma unroll
+      for (int b = 0; b < NB2; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < HB; ++t) {
+          const f32x4* pa = pk4 + P::OFF_P2 / 4 + (((w * HB + t) * NB2 + b) * 4) * 64 + lane;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 av = pa[r4 * 64];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[b] = mfma(av[d], H[t][4 * r4 + d], o[b]);
+          }
+        }
+        f32x4* pw = reinterpret_cast<f32x4*>(po) + ((w * NBP + b) * 4) * 64 + lane;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          f32x4 v = {o[b][4 * r4], o[b][4 * r4 + 1], o[b][4 * r4 + 2], o[b][4 * r4 + 3]};
+          pw[r4 * 64] = v;
+        }
+      }
+    }
+    __syncthreads();  // 2: po
+
+    float xh2[NB2][16], g2v[NB2][16];
+    float y[NB2][16];
+    float mu2, rstd2;
+    {
+      float s1b = 0.f, s2b = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB2; ++b) {
+        const float* t2 = a.packed + P::OFF_T2 + b * 96 + h * 16;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ww = 0; ww < kPcWaves; ++ww) v += reinterpret_cast<const f32x4*>(po)[((ww * NBP + b) * 4 + r4) * 64 + lane];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int r = 4 * r4 + d;
+            const float ov = v[d] + t2[r];
+            xh2[b][r] = ov;
+            s1b += ov;
+            s2b += ov * ov;
+          }
+        }
+      }
+      s1b += half_swap(s1b);
+      s2b += half_swap(s2b);
+      mu2 = s1b * inv_co;
+      rstd2 = rsqrtf(fmaxf(s2b * inv_co - mu2 * mu2, 0.f) + a.eps2);
+#pragma unroll
+      for (int b = 0; b < NB2; ++b) {
+        const float* t2 = a.packed + P::OFF_T2 + b * 96 + h * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          xh2[b][r] = (xh2[b][r] - mu2) * rstd2;
+          g2v[b][r] = t2[32 + r];
+          y[b][r] = xh2[b][r] * g2v[b][r] + t2[64 + r];
+        }
+      }
+    }
+
+    if (!BWD) {
+      // ---- forward tail: + identity shortcut, reduce over the k edges of every query ----
+#pragma unroll
+      for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (((b * 16 + r) & 3) == w) {
+            const int ch = 32 * b + sigma(r, h);
+            tB[ch * kPitch + e] = y[b][r] + (ch < EIN ? tX[ch * kPitch + e] : 0.f);
+          }
+      __syncthreads();  // 3: tB
+      for (int i = tid; i < nq * CO; i += 256) {
+        const int ql = i / CO, ch = i - ql * CO;
+        const int64_t qq = tile * nq + ql;
+        float s = 0.f;
+        for (int kk = 0; kk < k; ++kk) s += tB[ch * kPitch + ql * k + kk];
+        if (qq < a.n_query && ch < a.co_t) a.out[qq * a.co_t + ch] = s * a.scale;
+      }
+      __syncthreads();  // 4: LDS is rewritten by the next tile
+      continue;
+    }
+
+    // ---- backward: dy -> LayerNorm2 -> dOpre ----
+    float dOpre[NB2][16], dy[NB2][16];
+    {
+      const int ql = e >> a.log2k;
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dy[b][r] = valid ? dout[ql * CO + 32 * b + sigma(r, h)] : 0.f;
+          const float gd = dy[b][r] * g2v[b][r];
+          m1 += gd;
+          m2 += gd * xh2[b][r];
+        }
+      m1 += half_swap(m1);
+      m2 += half_swap(m2);
+      m1 *= inv_co;
+      m2 *= inv_co;
+#pragma unroll
+      for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dOpre[b][r] = rstd2 * (dy[b][r] * g2v[b][r] - m1 - xh2[b][r] * m2);
+          if (((b * 16 + r) & 3) == w) {
+            const int i = (b * 16 + r) >> 2;
+            dg2a[i] += dy[b][r] * xh2[b][r];
+            dbe2a[i] += dy[b][r];
+            db2a[i] += dOpre[b][r];
+            tB[(32 * b + sigma(r, h)) * kPitch + e] = dOpre[b][r];
+          }
+        }
+    }
+    // ---- dH (this wave's hidden blocks) = W2 dOpre, ReLU mask, LayerNorm1 backward (sums exchanged between the waves) ----
+    float gg[HB][16];
+    {
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HB; ++t) {
+        f32x16 dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB2; ++b) {
+          const f32x4* pa = pk4 + P::OFF_P2T / 4 + (((w * HB + t) * NB2 + b) * 4) * 64 + lane;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 av = pa[r4 * 64];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dh = mfma(av[d], dOpre[b][4 * r4 + d], dh);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float g = H[t][r] > 0.f ? dh[r] : 0.f;
+          dg1a[t][r] += g * xh1[t][r];
+          dbe1a[t][r] += g;
+          gg[t][r] = g * g1v[t][r];
+          p1 += gg[t][r];
+          p2 += gg[t][r] * xh1[t][r];
+        }
+      }
+      p1 += half_swap(p1);
+      p2 += half_swap(p2);
+      if (h == 0) {
+        st[256 + (w * 32 + e) * 2 + 0] = p1;
+        st[256 + (w * 32 + e) * 2 + 1] = p2;
+      }
+    }
+    __syncthreads();  // 3: st[1], tB
+
+    float dHpre[HB][16];
+    {
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < kPcWaves; ++ww) {
+        m1 += st[256 + (ww * 32 + e) * 2 + 0];
+        m2 += st[256 + (ww * 32 + e) * 2 + 1];
+      }
+      m1 *= inv_hid;
+      m2 *= inv_hid;
+#pragma unroll
+      for (int t = 0; t < HB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dHpre[t][r] = rstd1 * (gg[t][r] - m1 - xh1[t][r] * m2);
+          db1a[t][r] += dHpre[t][r];
+        }
+    }
+    // ---- dW2 (rows of this wave) += H^T dOpre: the reduction runs over edges, operands channel-major from LDS ----
+#pragma unroll
+    for (int t = 0; t < HB; ++t)
+#pragma unroll
+      for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(thw + (t * 32 + e) * kPitch + 16 * h + 4 * s4);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(tB + (32 * b + e) * kPitch + 16 * h + 4 * s4);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) dW2a[t][b] = mfma(av[d], bv[d], dW2a[t][b]);
+        }
+    // the wave's tile now takes dHpre (LDS operations of one wave execute in order)
+#pragma unroll
+    for (int t = 0; t < HB; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) thw[(t * 32 + sigma(r, h)) * kPitch + e] = dHpre[t][r];
+    // ---- dX partial = W1 dHpre over this wave's hidden channels ----
+#pragma unroll
+    for (int cb = 0; cb < NBX; ++cb) {
+      f32x16 dx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < HB; ++t) {
+        const f32x4* pa = pk4 + P::OFF_P1T / 4 + (((w * HB + t) * NBX + cb) * 4) * 64 + lane;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 av = pa[r4 * 64];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) dx = mfma(av[d], dHpre[t][4 * r4 + d], dx);
+        }
+      }
+      f32x4* pw = reinterpret_cast<f32x4*>(po) + ((w * NBP + cb) * 4) * 64 + lane;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        f32x4 v = {dx[4 * r4], dx[4 * r4 + 1], dx[4 * r4 + 2], dx[4 * r4 + 3]};
+        pw[r4 * 64] = v;
+      }
+    }
+    // ---- dW1 (columns of this wave) += x^T dHpre ----
+#pragma unroll
+    for (int cb = 0; cb < NBX; ++cb)
+#pragma unroll
+      for (int t = 0; t < HB; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(tX + (32 * cb + e) * kPitch + 16 * h + 4 * s4);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(thw + (t * 32 + e) * kPitch + 16 * h + 4 * s4);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) dW1a[cb][t] = mfma(av[d], bv[d], dW1a[cb][t]);
+        }
+    __syncthreads();  // 4: po (dX partials)
+
+    // ---- dX: sum the partials (+ dy through the identity shortcut), edge-major tile, then scatter ----
+#pragma unroll
+    for (int cb = 0; cb < NBX; ++cb)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        if (((cb * 4 + r4) & 3) == w) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ww = 0; ww < kPcWaves; ++ww) v += reinterpret_cast<const f32x4*>(po)[((ww * NBP + cb) * 4 + r4) * 64 + lane];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int r = 4 * r4 + d;
+            float s = v[d];
+            if (cb < NB2) s += dy[cb < NB2 ? cb : 0][r];  // identity shortcut: output channel c is x channel c
+            dxt[e * (EIN + 1) + 32 * cb + sigma(r, h)] = s;
+          }
+        }
+    __syncthreads();  // 5: dxt
+    for (int i = tid; i < 32 * a.cin; i += 256) {
+      const int ee = i / a.cin, c = i - ee * a.cin;
+      const int32_t jj = jt[ee];
+      if (jj >= 0) unsafeAtomicAdd(a.d_in + (int64_t)jj * a.cin + c, dxt[ee * (EIN + 1) + c]);  // hardware fp32 add, no CAS loop
+    }
+    for (int i = tid; i < nq * a.cq; i += 256) {
+      const int ql = i / a.cq, c = i - ql * a.cq;
+      const int64_t qq = tile * nq + ql;
+      float s = 0.f;
+      for (int kk = 0; kk < k; ++kk) s += dxt[(ql * k + kk) * (EIN + 1) + a.cin + c];
+      if (qq < a.n_query) a.d_q[qq * a.cq + c] = s;
+    }
+    __syncthreads();  // 6: LDS is rewritten by the next tile
+  }
+
+  if (BWD) {
+    // ---- this workgroup's parameter-gradient partials (every true element is written: the reduce kernel sums them) ----
+    float* base = a.partial + (int64_t)blockIdx.x * grad_floats(a.ein_t, a.hid_t, a.co_t);
+    float* pW1 = base;
+    float* pb1 = pW1 + (int64_t)a.hid_t * a.ein_t;
+    float* pg1 = pb1 + a.hid_t;
+    float* pbe1 = pg1 + a.hid_t;
+    float* pW2 = pbe1 + a.hid_t;
+    float* pb2 = pW2 + (int64_t)a.co_t * a.hid_t;
+    float* pg2 = pb2 + a.co_t;
+    float* pbe2 = pg2 + a.co_t;
+#pragma unroll
+    for (int t = 0; t < HB; ++t) {
+      const int hid0 = 32 * (w * HB + t);
+#pragma unroll
+      for (int cb = 0; cb < NBX; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // dW1a[cb][t][r] at lane (h, e): W1 grad (c = 32cb + sigma(r,h), hid = hid0 + e)
+          const int c = 32 * cb + sigma(r, h), hid = hid0 + e;
+          if (c < a.ein_t && hid < a.hid_t) pW1[(int64_t)hid * a.ein_t + c] = dW1a[cb][t][r];
+        }
+#pragma unroll
+      for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // dW2a[t][b][r] at lane (h, e): W2 grad (hid = hid0 + sigma(r,h), out = 32b + e)
+          const int hid = hid0 + sigma(r, h), oc = 32 * b + e;
+          if (hid < a.hid_t && oc < a.co_t) pW2[(int64_t)oc * a.hid_t + hid] = dW2a[t][b][r];
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float vg = half_sum32(dg1a[t][r]), vb = half_sum32(dbe1a[t][r]), vc = half_sum32(db1a[t][r]);
+        const int hid = hid0 + sigma(r, h);
+        if (e == 0 && hid < a.hid_t) {
+          pg1[hid] = vg;
+          pbe1[hid] = vb;
+          pb1[hid] = vc;
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (((b * 16 + r) & 3) == w) {
+          const int i = (b * 16 + r) >> 2;
+          const float vg = half_sum32(dg2a[i]), vb = half_sum32(dbe2a[i]), vc = half_sum32(db2a[i]);
+          const int oc = 32 * b + sigma(r, h);
+          if (e == 0 && oc < a.co_t) {
+            pg2[oc] = vg;
+            pbe2[oc] = vb;
+            pb2[oc] = vc;
+          }
+        }
+  }
+}
+
+// packs the torch-layout parameters into the operand images of PC<EIN, HID, CO>
+struct PackArgs {
+  const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2;  // w1 [hid][ein], w2 [co][hid]
+  int ein_t, hid_t, co_t;
+  float* packed;
+};
+template <int EIN, int HID, int CO>
+__global__ void pointconv_pack_kernel(const PackArgs p) {
+  typedef PC<EIN, HID, CO> P;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P::PACKED) return;
+  auto W1 = [&](int c, int hid) { return (c < p.ein_t && hid < p.hid_t) ? p.w1[(int64_t)hid * p.ein_t + c] : 0.f; };
+  auto W2 = [&](int hid, int oc) { return (hid < p.hid_t && oc < p.co_t) ? p.w2[(int64_t)oc * p.hid_t + hid] : 0.f; };
+  float v = 0.f;
+  if (idx < P::OFF_P2) {  // P1 [blk][s4][lane][4]
+    const int d = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+    const int s4 = rest % (P::KS1 / 4), blk = rest / (P::KS1 / 4);
+    v = W1((lane >> 5) * P::KS1 + 4 * s4 + d, 32 * blk + (lane & 31));
+  } else if (idx < P::OFF_P2T) {  // P2 [blk][b][r4][lane][4]
+    const int i2 = idx - P::OFF_P2;
+    const int d = i2 & 3, lane = (i2 >> 2) & 63, r4 = (i2 >> 8) & 3, rest = i2 >> 10;
+    const int b = rest % P::NB2, blk = rest / P::NB2;
+    v = W2(32 * blk + sigma(4 * r4 + d, lane >> 5), 32 * b + (lane & 31));
+  } else if (idx < P::OFF_P1T) {  // P2T
+    const int i2 = idx - P::OFF_P2T;
+    const int d = i2 & 3, lane = (i2 >> 2) & 63, r4 = (i2 >> 8) & 3, rest = i2 >> 10;
+    const int b = rest % P::NB2, blk = rest / P::NB2;
+    v = W2(32 * blk + (lane & 31), 32 * b + sigma(4 * r4 + d, lane >> 5));
+  } else if (idx < P::OFF_T1) {  // P1T [blk][cb][r4][lane][4]
+    const int i2 = idx - P::OFF_P1T;
+    const int d = i2 & 3, lane = (i2 >> 2) & 63, r4 = (i2 >> 8) & 3, rest = i2 >> 10;
+    const int cb = rest % P::NBX, blk = rest / P::NBX;
+    v = W1(32 * cb + (lane & 31), 32 * blk + sigma(4 * r4 + d, lane >> 5));
+  } else if (idx < P::OFF_T2) {  // T1 [blk][3][2][16]
+    const int i2 = idx - P::OFF_T1;
+    const int r = i2 & 15, hh = (i2 >> 4) & 1, which = (i2 >> 5) % 3, blk = i2 / 96;
+    const int ch = 32 * blk + sigma(r, hh);
+    const float* src = which == 0 ? p.b1 : which == 1 ? p.g1 : p.be1;
+    v = (ch < p.hid_t && src) ? src[ch] : 0.f;
+  } else {
+    const int i2 = idx - P::OFF_T2;
+    const int r = i2 & 15, hh = (i2 >> 4) & 1, which = (i2 >> 5) % 3, b = i2 / 96;
+    const int ch = 32 * b + sigma(r, hh);
+    const float* src = which == 0 ? p.b2 : which == 1 ? p.g2 : p.be2;
+    v = (ch < p.co_t && src) ? src[ch] : 0.f;
+  }
+  p.packed[idx] = v;
+}
+
+__global__ void pointconv_grad_reduce_kernel(const float* __restrict__ partial, int grid, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int g = 0; g < grid; ++g) s += partial[(int64_t)g * n + i];  // fixed order: deterministic
+  out[i] = s;
+}
+
+// instantiated shapes: (EIN, HID, CO); channel counts are zero-padded up to the smallest one that fits
+struct Shape { int ein, hid, co; };
+constexpr Shape kShapes[] = {{64, 128, 64}};
+
+int pick_shape(int ein_t, int hid_t, int co_t) {
+  for (int i = 0; i < (int)(sizeof(kShapes) / sizeof(kShapes[0])); ++i)
+    if (ein_t <= kShapes[i].ein && hid_t <= kShapes[i].hid && co_t <= kShapes[i].co) return i;
+  return -1;
+}
+int log2_exact(int k) {
+  for (int l = 0; l <= 5; ++l)
+    if ((1 << l) == k) return l;
+  return -1;
+}
+int bwd_grid(int64_t n_query, int k) {
+  const int64_t tiles = (n_query * k + 31) / 32;
+  return (int)(tiles < 256 ? tiles : 256);  // one persistent workgroup per CU
+}
+
+template <int EIN, int HID, int CO, bool BWD>
+int launch_edge(const PcArgs& a, int grid, hipStream_t s) {
+  typedef PC<EIN, HID, CO> P;
+  static unsigned long long attr_done = 0ull;
+  const int rc = once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_edge_kernel<EIN, HID, CO, BWD>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_FLOATS * 4) == hipSuccess;
+  });
+  if (rc != WCN_SUCCESS) return rc;
+  hipLaunchKernelGGL((pointconv_edge_kernel<EIN, HID, CO, BWD>), dim3(grid), dim3(256), P::LDS_FLOATS * 4, s, a);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace wcn
+
+using namespace wcn;
+
+extern "C" {
+
+int wcn_pointconv_supported(int32_t cin, int32_t cq, int32_t nrel, int32_t hidden, int32_t cout, int32_t k) {
+  if (cin < 1 || cq < 0 || (nrel != 0 && nrel != 3) || hidden < 1 || cout < 1) return 0;
+  if (cin + cq + nrel != cout) return 0;  // identity shortcut only (mlp.py:141: Linear shortcut when the widths differ)
+  return (log2_exact(k) >= 0 && pick_shape(cin + cq + nrel, hidden, cout) >= 0) ? 1 : 0;
+}
+
+int64_t wcn_pointconv_packed_floats(int32_t ein, int32_t hidden, int32_t cout) {
+  switch (pick_shape(ein, hidden, cout)) {
+    case 0: return PC<64, 128, 64>::PACKED;
+    default: return 0;
+  }
+}
+
+int64_t wcn_pointconv_grad_floats(int32_t ein, int32_t hidden, int32_t cout) { return grad_floats(ein, hidden, cout); }
+
+size_t wcn_pointconv_backward_workspace(int64_t n_query, int32_t k, int32_t ein, int32_t hidden, int32_t cout) {
+  return (size_t)bwd_grid(n_query, k) * (size_t)grad_floats(ein, hidden, cout) * sizeof(float);
+}
+
+int wcn_pointconv_pack(const float* w1, const float* b1, const float* g1, const float* be1, const float* w2,
+                       const float* b2, const float* g2, const float* be2, int32_t ein, int32_t hidden, int32_t cout,
+                       float* packed, void* stream) {
+  if (!w1 || !w2 || !packed) return WCN_ERROR_INVALID_PARAMETERS;
+  const PackArgs p{w1, b1, g1, be1, w2, b2, g2, be2, ein, hidden, cout, packed};
+  hipStream_t s = (hipStream_t)stream;
+  switch (pick_shape(ein, hidden, cout)) {
+    case 0:
+      hipLaunchKernelGGL((pointconv_pack_kernel<64, 128, 64>), dim3((PC<64, 128, 64>::PACKED + 255) / 256), dim3(256), 0, s, p);
+      break;
+    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
+  }
+  return launch_status();
+}
+
+static int fill_args(PcArgs& a, const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                     const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
+                     const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean) {
+  if (!wcn_pointconv_supported(cin, cq, nrel, hidden, cout, k)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (!in_feats || (cq > 0 && !q_feats) || !nbr || !packed || (nrel && (!in_xyz || !q_xyz)) || n_query < 0)
+    return WCN_ERROR_INVALID_PARAMETERS;
+  a = PcArgs{};
+  a.in_feats = in_feats; a.q_feats = q_feats; a.in_xyz = in_xyz; a.q_xyz = q_xyz; a.nbr = nbr;
+  a.n_query = n_query; a.log2k = log2_exact(k); a.cin = cin; a.cq = cq; a.nrel = nrel;
+  a.packed = packed; a.ein_t = cin + cq + nrel; a.hid_t = hidden; a.co_t = cout;
+  a.eps1 = eps1; a.eps2 = eps2; a.scale = mean ? 1.f / (float)k : 1.f;
+  return WCN_SUCCESS;
+}
+
+int wcn_pointconv_edge_forward(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                               const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
+                               const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
+                               float* out, void* stream) {
+  PcArgs a;
+  const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, k, cin, cq, nrel, packed, hidden, cout, eps1,
+                           eps2, mean);
+  if (rc != WCN_SUCCESS) return rc;
+  if (!out) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n_query == 0) return WCN_SUCCESS;
+  a.out = out;
+  const int64_t tiles = (n_query * k + 31) / 32;
+  const int grid = (int)(tiles < 1024 ? tiles : 1024);
+  switch (pick_shape(a.ein_t, hidden, cout)) {
+    case 0: return launch_edge<64, 128, 64, false>(a, grid, (hipStream_t)stream);
+    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
+  }
+}
+
+int wcn_pointconv_edge_backward(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                                const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
+                                const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
+                                const float* grad_out, float* d_in, float* d_q, float* d_params, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  PcArgs a;
+  const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, k, cin, cq, nrel, packed, hidden, cout, eps1,
+                           eps2, mean);
+  if (rc != WCN_SUCCESS) return rc;
+  if (!grad_out || !d_in || (cq > 0 && !d_q) || !d_params || !workspace ||
+      workspace_bytes < wcn_pointconv_backward_workspace(n_query, k, a.ein_t, hidden, cout))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t gf = grad_floats(a.ein_t, hidden, cout);
+  if (n_query == 0) return hipMemsetAsync(d_params, 0, gf * sizeof(float), s) == hipSuccess ? WCN_SUCCESS : WCN_ERROR_KERNEL_EXECUTION;
+  a.grad_out = grad_out; a.d_in = d_in; a.d_q = d_q; a.partial = (float*)workspace;
+  const int grid = bwd_grid(n_query, k);
+  int rc2;
+  switch (pick_shape(a.ein_t, hidden, cout)) {
+    case 0: rc2 = launch_edge<64, 128, 64, true>(a, grid, s); break;
+    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
+  }
+  if (rc2 != WCN_SUCCESS) return rc2;
+  hipLaunchKernelGGL(pointconv_grad_reduce_kernel, dim3((unsigned)((gf + 255) / 256)), dim3(256), 0, s,
+                     (const float*)workspace, grid, gf, d_params);
+  return launch_status();
+}
+
+}  // extern "C"

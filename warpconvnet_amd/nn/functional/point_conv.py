@@ -1,0 +1,131 @@
+"""PointConv edge pipeline in one pass: gather -> edge MLP -> reduction over the neighbours (``csrc/pointconv.hip``).
+
+Takes the place of the op sequence in the reference's ``PointConv.forward``
+(`warpconvnet/nn/modules/point_conv.py:231-273`: ``features[neighbors]`` / ``repeat_interleave`` / ``cat`` ->
+``edge_transform_mlp`` -> ``row_reduction``) when the edge MLP is the default ``MLPBlock`` with an identity shortcut
+(`warpconvnet/nn/modules/mlp.py:124-177`), the neighbour lists have a uniform power-of-two length (kNN) and the reduction
+is ``mean`` or ``sum``.  Forward and backward are single HIP kernels; no ``[M*k, C]`` tensor exists in HBM.
+"""
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from warpconvnet_amd import _lib
+
+_ENABLED = os.environ.get("WARPCONVNET_AMD_POINTCONV_FUSED", "1") != "0"
+
+
+def _mlp_parts(mlp: nn.Module):
+    """(lin1, ln1, lin2, ln2) of a default MLPBlock with ReLU and identity shortcut, else None."""
+    block, shortcut = getattr(mlp, "block", None), getattr(mlp, "shortcut", None)
+    if not isinstance(block, nn.Sequential) or len(block) != 5 or not isinstance(shortcut, nn.Identity):
+        return None
+    lin1, ln1, act, lin2, ln2 = block
+    if not (isinstance(lin1, nn.Linear) and isinstance(ln1, nn.LayerNorm) and type(act) is nn.ReLU
+            and isinstance(lin2, nn.Linear) and isinstance(ln2, nn.LayerNorm)):
+        return None
+    if not (ln1.elementwise_affine and ln2.elementwise_affine):
+        return None
+    return lin1, ln1, lin2, ln2
+
+
+def fused_edge_supported(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nrel: int, k: int, reduction: str) -> bool:
+    if not _ENABLED or not in_feats.is_cuda or reduction not in ("mean", "sum"):
+        return False
+    parts = _mlp_parts(mlp)
+    if parts is None:
+        return False
+    lin1, _, lin2, _ = parts
+    cin, cq = in_feats.shape[1], q_feats.shape[1]
+    if lin1.in_features != cin + cq + nrel or lin1.weight.dtype != torch.float32:
+        return False
+    return bool(_lib.lib().wcn_pointconv_supported(cin, cq, nrel, lin1.out_features, lin2.out_features, k))
+
+
+def _packed_params(mlp: nn.Module, parts) -> Tensor:
+    """Operand images of the edge MLP, cached on the module per parameter version."""
+    lin1, ln1, lin2, ln2 = parts
+    ps = (lin1.weight, lin1.bias, ln1.weight, ln1.bias, lin2.weight, lin2.bias, ln2.weight, ln2.bias)
+    key = tuple((p.data_ptr(), p._version) if p is not None else None for p in ps)
+    hit = getattr(mlp, "_wcn_pc_packed", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    L = _lib.lib()
+    ein, hid, co = lin1.in_features, lin1.out_features, lin2.out_features
+    dev = lin1.weight.device
+    packed = torch.empty(L.wcn_pointconv_packed_floats(ein, hid, co), dtype=torch.float32, device=dev)
+    c = [p.detach().contiguous() if p is not None else None for p in ps]
+    _lib.check(L.wcn_pointconv_pack(*[_lib.ptr(t) for t in c], ein, hid, co, _lib.ptr(packed), _lib.stream_handle(dev)),
+               "wcn_pointconv_pack")
+    mlp._wcn_pc_packed = (key, packed)
+    return packed
+
+
+class _FusedEdge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, in_feats, q_feats, w1, b1, g1, be1, w2, b2, g2, be2, packed, in_xyz, q_xyz, nbr, k, eps1, eps2, mean):
+        L = _lib.lib()
+        dev = in_feats.device
+        in_feats, q_feats = in_feats.contiguous(), q_feats.contiguous()
+        M, cin, cq = q_feats.shape[0], in_feats.shape[1], q_feats.shape[1]
+        nrel = 0 if in_xyz is None else 3
+        hid, co = w1.shape[0], w2.shape[0]
+        out = torch.empty(M, co, dtype=torch.float32, device=dev)
+        _lib.check(L.wcn_pointconv_edge_forward(
+            _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
+            _lib.ptr(packed), hid, co, eps1, eps2, int(mean), _lib.ptr(out), _lib.stream_handle(dev)),
+            "wcn_pointconv_edge_forward")
+        ctx.save_for_backward(in_feats, q_feats, packed, in_xyz, q_xyz, nbr)
+        ctx.dims = (M, k, cin, cq, nrel, hid, co, eps1, eps2, int(mean))
+        ctx.has = (b1 is not None, b2 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L = _lib.lib()
+        in_feats, q_feats, packed, in_xyz, q_xyz, nbr = ctx.saved_tensors
+        M, k, cin, cq, nrel, hid, co, eps1, eps2, mean = ctx.dims
+        dev = in_feats.device
+        ein = cin + cq + nrel
+        grad_out = grad_out.contiguous().float()
+        d_in = torch.zeros_like(in_feats)
+        d_q = torch.empty_like(q_feats)
+        grads = torch.empty(L.wcn_pointconv_grad_floats(ein, hid, co), dtype=torch.float32, device=dev)
+        ws_bytes = L.wcn_pointconv_backward_workspace(M, k, ein, hid, co)
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        _lib.check(L.wcn_pointconv_edge_backward(
+            _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
+            _lib.ptr(packed), hid, co, eps1, eps2, mean, _lib.ptr(grad_out), _lib.ptr(d_in), _lib.ptr(d_q), _lib.ptr(grads),
+            _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)), "wcn_pointconv_edge_backward")
+        o = 0
+
+        def take(n, shape):
+            nonlocal o
+            v = grads[o:o + n].view(shape)
+            o += n
+            return v
+
+        dw1, db1, dg1, dbe1 = take(hid * ein, (hid, ein)), take(hid, (hid,)), take(hid, (hid,)), take(hid, (hid,))
+        dw2, db2, dg2, dbe2 = take(co * hid, (co, hid)), take(co, (co,)), take(co, (co,)), take(co, (co,))
+        has_b1, has_b2 = ctx.has
+        return (d_in, d_q, dw1, db1 if has_b1 else None, dg1, dbe1, dw2, db2 if has_b2 else None, dg2, dbe2,
+                None, None, None, None, None, None, None, None)
+
+
+def fused_point_conv_edge(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nbr: Tensor, k: int, reduction: str,
+                          in_xyz: Optional[Tensor] = None, q_xyz: Optional[Tensor] = None) -> Tensor:
+    """``row_reduction(edge_mlp(cat([in_feats[nbr], q_feats.repeat(k), in_xyz[nbr] - q_xyz.repeat(k)])), reduction)``
+    for ``nbr`` [M, k] / [M*k] row indices into ``in_feats``; fp32."""
+    parts = _mlp_parts(mlp)
+    assert parts is not None, "fused_point_conv_edge needs the default MLPBlock (see fused_edge_supported)"
+    lin1, ln1, lin2, ln2 = parts
+    packed = _packed_params(mlp, parts)
+    nbr32 = nbr.reshape(-1).to(torch.int32).contiguous()
+    if in_xyz is not None:
+        in_xyz, q_xyz = in_xyz.float().contiguous(), q_xyz.float().contiguous()
+    return _FusedEdge.apply(in_feats.float(), q_feats.float(), lin1.weight, lin1.bias, ln1.weight, ln1.bias, lin2.weight,
+                            lin2.bias, ln2.weight, ln2.bias, packed, in_xyz, q_xyz, nbr32, int(k), float(ln1.eps),
+                            float(ln2.eps), reduction == "mean")

@@ -1,8 +1,10 @@
 """``PointConv``: edge MLP over the k nearest (or provided / down-sampled) neighbours, row reduction, output MLP.
 
-Constructor, checks and ``forward`` of the reference (`warpconvnet/nn/modules/point_conv.py:36-282`).  What is native here:
-the neighbour search (``wcn_knn_grid``, exact grid kNN instead of O(M*N) cdist + topk) and the per-query reduction of the
-edge features (``wcn_segment_reduce``); the two MLPs are dense GEMMs and go through the vendor library.
+Constructor and checks of the reference (`warpconvnet/nn/modules/point_conv.py:36-282`).  What is native here: the neighbour
+search (``wcn_knn_grid``, exact grid kNN instead of O(M*N) cdist + topk), and for the default configuration the whole edge
+pipeline - gather, edge MLP, reduction over the neighbours - as one HIP kernel per direction (``csrc/pointconv.hip``), so no
+``[M*k, C]`` edge tensor exists.  Other configurations (custom edge MLPs, max / several reductions, ragged radius lists,
+sinusoidal encodings) compose the same result from ``wcn_segment_reduce`` and library GEMMs.
 """
 import warnings
 from typing import List, Literal, Optional
@@ -14,6 +16,7 @@ from warpconvnet_amd.geometry.base.coords import Coords
 from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig, RealSearchMode
 from warpconvnet_amd.geometry.types.points import Points
 from warpconvnet_amd.nn.encodings import SinusoidalEncoding
+from warpconvnet_amd.nn.functional.point_conv import fused_edge_supported, fused_point_conv_edge
 from warpconvnet_amd.nn.modules.base_module import BaseSpatialModule
 from warpconvnet_amd.nn.modules.mlp import MLPBlock
 from warpconvnet_amd.ops.reductions import REDUCTIONS, row_reduction
@@ -113,6 +116,24 @@ class PointConv(BaseSpatialModule):
             s += f" neighbor={self.neighbor_search_args}"
         return s + ")"
 
+    def _fused_edge(self, in_pc: Points, query_pc: Points, neighbors):
+        """gather -> edge MLP -> reduction as ONE HIP kernel (`nn/functional/point_conv.py`) when the configuration allows it:
+        kNN lists of uniform power-of-two length, default edge MLP with identity shortcut, one mean / sum reduction, no
+        sinusoidal encoding.  None = take the composed path below (same result, edge tensors in HBM)."""
+        nidx = neighbors.neighbor_indices
+        if nidx.ndim != 2 or len(self.reductions) != 1 or self.use_rel_pos_encode:
+            return None
+        k = nidx.shape[1]
+        fin, fq = in_pc.feature_tensor, query_pc.feature_tensor.view(-1, query_pc.num_channels)
+        nrel = 3 if self.use_rel_pos else 0
+        if not fused_edge_supported(self.edge_transform_mlp, fin, fq, nrel, k, self.reductions[0]):
+            return None
+        counts = in_pc.offsets[1:] - in_pc.offsets[:-1]
+        if int(counts.min()) < k:  # lists padded with -1 (fewer than k points in a batch element): composed path
+            return None
+        xyz = (in_pc.coordinate_tensor.view(-1, 3), query_pc.coordinate_tensor.view(-1, 3)) if nrel else (None, None)
+        return fused_point_conv_edge(self.edge_transform_mlp, fin, fq, nidx, k, self.reductions[0], *xyz)
+
     def forward(self, in_pc: Points, query_pc: Optional[Points] = None) -> Points:
         if self.out_point_feature_type == "provided":
             assert query_pc is not None, "query_point_features must be provided for the provided type"
@@ -129,6 +150,13 @@ class PointConv(BaseSpatialModule):
             f"does not match the edge_transform_mlp input channels {self.edge_mlp_in_channels}"
         )
         neighbors = in_pc.neighbors(query_coords=query_pc.batched_coordinates, search_args=self.neighbor_search_args)
+        fused = self._fused_edge(in_pc, query_pc, neighbors)
+        if fused is not None:
+            return Points(
+                batched_coordinates=Coords(batched_tensor=query_pc.coordinate_tensor, offsets=query_pc.offsets),
+                batched_features=self.out_transform_mlp(fused),
+                **query_pc.extra_attributes,
+            )
         idx = neighbors.neighbor_indices.long().view(-1)
         splits = neighbors.neighbor_row_splits
         num_reps = splits[1:] - splits[:-1]
