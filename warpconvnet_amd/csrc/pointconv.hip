@@ -29,6 +29,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kPcWaves = 4;
+constexpr bool kWRegs = false;  // backward: the transposed weight operands (dH, dX GEMMs) in registers too
 constexpr int kPitch = 36;  // floats per row of the [channel][32 edges] LDS tiles: b128 reads of 8 lanes hit 32 banks
 
 __host__ __device__ constexpr int sigma(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }
@@ -61,7 +62,8 @@ struct PC {
   static constexpr int OFF_T2 = OFF_T1 + NB1 * 96;    // [NB2][3][2][16]          b2, g2, be2
   static constexpr int PACKED = OFF_T2 + NB2 * 96;
   // LDS (floats)
-  static constexpr int L_TX = 0;                              // [EIN][kPitch]      x, channel-major (identity shortcut, dW1 A)
+  static constexpr int L_TAB = 0;                             // [NB1 + NB2][3][2][16] bias / LayerNorm tables (copy of T1, T2)
+  static constexpr int L_TX = (NB1 + NB2) * 96;               // [EIN][kPitch]      x, channel-major (identity shortcut, dW1 A)
   static constexpr int L_TH = L_TX + EIN * kPitch;            // [HID][kPitch]      per wave: H, later dHpre, channel-major
   static constexpr int L_TB = L_TH + HID * kPitch;            // [CO][kPitch]       dOpre channel-major / forward output tile
   static constexpr int L_PO = L_TB + CO * kPitch;             // [4][NBP][16][64]   partial tiles exchanged between the waves
@@ -69,7 +71,10 @@ struct PC {
   static constexpr int L_DXT = L_ST + 2 * kPcWaves * 64;      // [32][EIN+1]        dX, edge-major
   static constexpr int L_DOUT = L_DXT + 32 * (EIN + 1);       // [32][CO]           grad_out rows of the tile's queries
   static constexpr int L_JT = L_DOUT + 32 * CO;               // [32] int           neighbour ids
-  static constexpr int LDS_FLOATS = L_JT + 32;
+  static constexpr int L_WT = L_JT + 32;                      // [HID*CO + EIN*HID]  backward: P2T | P1T operand images
+  static constexpr int LDS_FLOATS = L_WT + HID * CO + EIN * HID;
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+  static constexpr int LDS_FLOATS_FWD = L_DXT - HID * kPitch;  // the forward kernel stops at the LayerNorm sums
 };
 
 struct PcArgs {
@@ -102,9 +107,9 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tX = smem + P::L_TX;
   float* tH = smem + P::L_TH;
-  float* tB = smem + P::L_TB;
-  float* po = smem + P::L_PO;
-  float* st = smem + P::L_ST;
+  float* tB = smem + (BWD ? P::L_TB : P::L_TH);                      // forward: no tH, everything moves up
+  float* po = smem + (BWD ? P::L_PO : P::L_PO - HID * kPitch);
+  float* st = smem + (BWD ? P::L_ST : P::L_ST - HID * kPitch);
   float* dxt = smem + P::L_DXT;
   float* dout = smem + P::L_DOUT;
   int32_t* jt = reinterpret_cast<int32_t*>(smem + P::L_JT);
@@ -116,6 +121,13 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
   const float inv_hid = 1.f / (float)a.hid_t, inv_co = 1.f / (float)a.co_t;
   const f32x4* pk4 = reinterpret_cast<const f32x4*>(a.packed);
   float* thw = tH + w * HB * 32 * kPitch;  // this wave's rows of tH
+  const float* tab = smem + P::L_TAB;
+  for (int i = tid; i < (P::NB1 + NB2) * 96; i += 256) smem[P::L_TAB + i] = a.packed[P::OFF_T1 + i];
+  if (BWD)  // the transposed weight images (A operands of the dH and dX GEMMs) live in LDS: no global round trip per tile
+    for (int i = tid; i < (P::OFF_T1 - P::OFF_P2T) / 4; i += 256)
+      reinterpret_cast<f32x4*>(smem + P::L_WT)[i] = pk4[P::OFF_P2T / 4 + i];
+  __syncthreads();
+  const f32x4* pkT4 = reinterpret_cast<const f32x4*>(smem + P::L_WT) - P::OFF_P2T / 4;  // same indexing as pk4
 
   // persistent parameter-gradient accumulators (backward)
   f32x16 dW1a[NBX][HB], dW2a[HB][NB2];
@@ -142,80 +154,125 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
     for (int i = 0; i < NB2 * 4; ++i) dg2a[i] = dbe2a[i] = db2a[i] = 0.f;
   }
 
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- A. stage the tile: neighbour ids, grad_out rows, x ----
+  // ---- this wave's weight operands never change: they stay in registers for the whole kernel ----
+  float wA1[HB][KS1], wA2[HB][NB2][16];
+  float wA2T[BWD && kWRegs ? HB : 1][NB2][16], wA1T[BWD && kWRegs ? HB : 1][NBX][16];
+#pragma unroll
+  for (int t = 0; t < HB; ++t) {
+    const int blk = w * HB + t;
+    const f32x4* pa = pk4 + P::OFF_P1 / 4 + (blk * (KS1 / 4)) * 64 + lane;
+#pragma unroll
+    for (int s4 = 0; s4 < KS1 / 4; ++s4) {
+      const f32x4 av = pa[s4 * 64];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) wA1[t][4 * s4 + d] = av[d];
+    }
+#pragma unroll
+    for (int b = 0; b < NB2; ++b)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 av = pk4[P::OFF_P2 / 4 + ((blk * NB2 + b) * 4 + r4) * 64 + lane];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wA2[t][b][4 * r4 + d] = av[d];
+        if (BWD && kWRegs) {
+          const f32x4 tv = pk4[P::OFF_P2T / 4 + ((blk * NB2 + b) * 4 + r4) * 64 + lane];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) wA2T[t][b][4 * r4 + d] = tv[d];
+        }
+      }
+    if (BWD && kWRegs) {
+#pragma unroll
+      for (int cb = 0; cb < NBX; ++cb)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 tv = pk4[P::OFF_P1T / 4 + ((blk * NBX + cb) * 4 + r4) * 64 + lane];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) wA1T[t][cb][4 * r4 + d] = tv[d];
+        }
+    }
+  }
+
+  // ---- software pipeline over tiles: the rows of tile i+1 are requested right after GEMM1 of tile i has consumed x,
+  // the neighbour ids of tile i+2 with them ----
+  auto load_ids = [&](int64_t tile, bool& valid, int64_t& q, int32_t& j) {
     const int64_t E = tile * 32 + e;
-    const bool valid = E < n_edges;
-    const int64_t q = valid ? (E >> a.log2k) : 0;
-    const int32_t j = valid ? a.nbr[E] : 0;
+    valid = tile < ntiles && E < n_edges;
+    q = valid ? (E >> a.log2k) : 0;
+    j = valid ? a.nbr[E] : 0;
+  };
+  float x[KS1];
+  auto gather_x = [&](bool valid, int64_t q, int32_t j) {
+    const float* fi = a.in_feats + (int64_t)j * a.cin;
+    const float* fq = a.q_feats + q * a.cq;
+    const bool vec = ((a.cin | a.cq) & 3) == 0;
+#pragma unroll
+    for (int u = 0; u < KS1 / 4; ++u) {
+      const int c4 = h * KS1 + 4 * u;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        if (vec && c4 + 4 <= a.cin) {
+          v = *reinterpret_cast<const f32x4*>(fi + c4);
+        } else if (vec && c4 >= a.cin && c4 + 4 <= a.cin + a.cq) {
+          v = *reinterpret_cast<const f32x4*>(fq + (c4 - a.cin));
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int c = c4 + d;
+            float sv = 0.f;
+            if (c < a.cin) sv = fi[c];
+            else if (c < a.cin + a.cq) sv = fq[c - a.cin];
+            else if (c < a.cin + a.cq + a.nrel) sv = a.in_xyz[(int64_t)j * 3 + (c - a.cin - a.cq)] - a.q_xyz[q * 3 + (c - a.cin - a.cq)];
+            v[d] = sv;
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) x[4 * u + d] = v[d];
+    }
+  };
+  bool v_cur, v_nxt;
+  int64_t q_cur, q_nxt;
+  int32_t j_cur, j_nxt;
+  load_ids(blockIdx.x, v_cur, q_cur, j_cur);
+  gather_x(v_cur, q_cur, j_cur);
+  load_ids((int64_t)blockIdx.x + gridDim.x, v_nxt, q_nxt, j_nxt);
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- A. stage the tile: neighbour ids, grad_out rows, channel-major copy of x ----
+    const bool valid = v_cur;
     if (BWD) {
-      if (w == 0 && h == 0) jt[e] = valid ? j : -1;
+      if (w == 0 && h == 0) jt[e] = valid ? j_cur : -1;
       for (int i = tid; i < nq * CO; i += 256) {
         const int ql = i / CO, ch = i - ql * CO;
         const int64_t qq = tile * nq + ql;
         dout[i] = (qq < a.n_query && ch < a.co_t) ? a.grad_out[qq * a.co_t + ch] * a.scale : 0.f;
       }
     }
-    float x[KS1];
-    {
-      const float* fi = a.in_feats + (int64_t)j * a.cin;
-      const float* fq = a.q_feats + q * a.cq;
-      const bool vec = ((a.cin | a.cq) & 3) == 0;
 #pragma unroll
-      for (int u = 0; u < KS1 / 4; ++u) {
-        const int c4 = h * KS1 + 4 * u;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (valid) {
-          if (vec && c4 + 4 <= a.cin) {
-            v = *reinterpret_cast<const f32x4*>(fi + c4);
-          } else if (vec && c4 >= a.cin && c4 + 4 <= a.cin + a.cq) {
-            v = *reinterpret_cast<const f32x4*>(fq + (c4 - a.cin));
-          } else {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-              const int c = c4 + d;
-              float s = 0.f;
-              if (c < a.cin) s = fi[c];
-              else if (c < a.cin + a.cq) s = fq[c - a.cin];
-              else if (c < a.cin + a.cq + a.nrel) s = a.in_xyz[(int64_t)j * 3 + (c - a.cin - a.cq)] - a.q_xyz[q * 3 + (c - a.cin - a.cq)];
-              v[d] = s;
-            }
-          }
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) x[4 * u + d] = v[d];
-      }
-      // channel-major copy of x (every wave writes a quarter of the registers)
-#pragma unroll
-      for (int s = 0; s < KS1; ++s)
-        if ((s & 3) == w) tX[(h * KS1 + s) * kPitch + e] = x[s];
-    }
+    for (int s = 0; s < KS1; ++s)  // every wave writes a quarter of the registers
+      if ((s & 3) == w) tX[(h * KS1 + s) * kPitch + e] = x[s];
 
     // ---- GEMM1 (this wave's hidden blocks): Hpre^T = W1^T x^T + b1 ----
     f32x16 acc1[HB];
 #pragma unroll
     for (int t = 0; t < HB; ++t) {
-      const int blk = w * HB + t;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
-      const f32x4* pa = pk4 + P::OFF_P1 / 4 + (blk * (KS1 / 4)) * 64 + lane;
 #pragma unroll
-      for (int s4 = 0; s4 < KS1 / 4; ++s4) {
-        const f32x4 av = pa[s4 * 64];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) acc1[t] = mfma(av[d], x[4 * s4 + d], acc1[t]);
-      }
+      for (int s = 0; s < KS1; ++s) acc1[t] = mfma(wA1[t][s], x[s], acc1[t]);
     }
-    float g1v[HB][16], be1v[HB][16];
+    // x is consumed: next tile's rows, and the ids of the tile after it
+    v_cur = v_nxt; q_cur = q_nxt; j_cur = j_nxt;
+    gather_x(v_cur, q_cur, j_cur);
+    load_ids(tile + 2 * (int64_t)gridDim.x, v_nxt, q_nxt, j_nxt);
+
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int t = 0; t < HB; ++t) {
-      const float* t1 = a.packed + P::OFF_T1 + (w * HB + t) * 96 + h * 16;
+      const float* t1 = tab + (w * HB + t) * 96 + h * 16;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         acc1[t][r] += t1[r];
-        g1v[t][r] = t1[32 + r];
-        be1v[t][r] = t1[64 + r];
         s1 += acc1[t][r];
         s2 += acc1[t][r] * acc1[t][r];
       }
@@ -241,13 +298,15 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
     }
     float xh1[HB][16], H[HB][16];
 #pragma unroll
-    for (int t = 0; t < HB; ++t)
+    for (int t = 0; t < HB; ++t) {
+      const float* t1 = tab + (w * HB + t) * 96 + h * 16;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         xh1[t][r] = (acc1[t][r] - mu1) * rstd1;
-        H[t][r] = fmaxf(xh1[t][r] * g1v[t][r] + be1v[t][r], 0.f);
+        H[t][r] = fmaxf(xh1[t][r] * t1[32 + r] + t1[64 + r], 0.f);
         if (BWD) thw[(t * 32 + sigma(r, h)) * kPitch + e] = H[t][r];
       }
+    }
 
     // ---- GEMM2, partial over this wave's hidden channels; the waves exchange partial tiles through LDS ----
     {
@@ -257,15 +316,9 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < HB; ++t) {
-          const f32x4* pa = pk4 + P::OFF_P2 / 4 + (((w * HB + t) * NB2 + b) * 4) * 64 + lane;
+        for (int t = 0; t < HB; ++t)
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 av = pa[r4 * 64];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) o[b] = mfma(av[d], H[t][4 * r4 + d], o[b]);
-          }
-        }
+          for (int r = 0; r < 16; ++r) o[b] = mfma(wA2[t][b][r], H[t][r], o[b]);
         f32x4* pw = reinterpret_cast<f32x4*>(po) + ((w * NBP + b) * 4) * 64 + lane;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -276,14 +329,13 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
     }
     __syncthreads();  // 2: po
 
-    float xh2[NB2][16], g2v[NB2][16];
-    float y[NB2][16];
+    float xh2[NB2][16];  // normalised GEMM2 output; the forward turns it into y in place
     float mu2, rstd2;
     {
       float s1b = 0.f, s2b = 0.f;
 #pragma unroll
       for (int b = 0; b < NB2; ++b) {
-        const float* t2 = a.packed + P::OFF_T2 + b * 96 + h * 16;
+        const float* t2 = tab + (P::NB1 + b) * 96 + h * 16;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -304,15 +356,9 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
       mu2 = s1b * inv_co;
       rstd2 = rsqrtf(fmaxf(s2b * inv_co - mu2 * mu2, 0.f) + a.eps2);
 #pragma unroll
-      for (int b = 0; b < NB2; ++b) {
-        const float* t2 = a.packed + P::OFF_T2 + b * 96 + h * 16;
+      for (int b = 0; b < NB2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          xh2[b][r] = (xh2[b][r] - mu2) * rstd2;
-          g2v[b][r] = t2[32 + r];
-          y[b][r] = xh2[b][r] * g2v[b][r] + t2[64 + r];
-        }
-      }
+        for (int r = 0; r < 16; ++r) xh2[b][r] = (xh2[b][r] - mu2) * rstd2;
     }
 
     if (!BWD) {
@@ -323,7 +369,8 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
         for (int r = 0; r < 16; ++r)
           if (((b * 16 + r) & 3) == w) {
             const int ch = 32 * b + sigma(r, h);
-            tB[ch * kPitch + e] = y[b][r] + (ch < EIN ? tX[ch * kPitch + e] : 0.f);
+            const float* t2 = tab + (P::NB1 + b) * 96 + h * 16;
+            tB[ch * kPitch + e] = xh2[b][r] * t2[32 + r] + t2[64 + r] + (ch < EIN ? tX[ch * kPitch + e] : 0.f);
           }
       __syncthreads();  // 3: tB
       for (int i = tid; i < nq * CO; i += 256) {
@@ -347,7 +394,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           dy[b][r] = valid ? dout[ql * CO + 32 * b + sigma(r, h)] : 0.f;
-          const float gd = dy[b][r] * g2v[b][r];
+          const float gd = dy[b][r] * tab[(P::NB1 + b) * 96 + 32 + h * 16 + r];
           m1 += gd;
           m2 += gd * xh2[b][r];
         }
@@ -359,7 +406,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
       for (int b = 0; b < NB2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          dOpre[b][r] = rstd2 * (dy[b][r] * g2v[b][r] - m1 - xh2[b][r] * m2);
+          dOpre[b][r] = rstd2 * (dy[b][r] * tab[(P::NB1 + b) * 96 + 32 + h * 16 + r] - m1 - xh2[b][r] * m2);
           if (((b * 16 + r) & 3) == w) {
             const int i = (b * 16 + r) >> 2;
             dg2a[i] += dy[b][r] * xh2[b][r];
@@ -380,12 +427,17 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
         for (int r = 0; r < 16; ++r) dh[r] = 0.f;
 #pragma unroll
         for (int b = 0; b < NB2; ++b) {
-          const f32x4* pa = pk4 + P::OFF_P2T / 4 + (((w * HB + t) * NB2 + b) * 4) * 64 + lane;
+          const f32x4* pa = pkT4 + P::OFF_P2T / 4 + (((w * HB + t) * NB2 + b) * 4) * 64 + lane;
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 av = pa[r4 * 64];
+            if (kWRegs) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) dh = mfma(av[d], dOpre[b][4 * r4 + d], dh);
+              for (int d = 0; d < 4; ++d) dh = mfma(wA2T[t][b][4 * r4 + d], dOpre[b][4 * r4 + d], dh);
+            } else {
+              const f32x4 av = pa[r4 * 64];
+#pragma unroll
+              for (int d = 0; d < 4; ++d) dh = mfma(av[d], dOpre[b][4 * r4 + d], dh);
+            }
           }
         }
 #pragma unroll
@@ -393,7 +445,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
           const float g = H[t][r] > 0.f ? dh[r] : 0.f;
           dg1a[t][r] += g * xh1[t][r];
           dbe1a[t][r] += g;
-          gg[t][r] = g * g1v[t][r];
+          gg[t][r] = g * tab[(w * HB + t) * 96 + 32 + h * 16 + r];
           p1 += gg[t][r];
           p2 += gg[t][r] * xh1[t][r];
         }
@@ -450,12 +502,17 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
       for (int r = 0; r < 16; ++r) dx[r] = 0.f;
 #pragma unroll
       for (int t = 0; t < HB; ++t) {
-        const f32x4* pa = pk4 + P::OFF_P1T / 4 + (((w * HB + t) * NBX + cb) * 4) * 64 + lane;
+        const f32x4* pa = pkT4 + P::OFF_P1T / 4 + (((w * HB + t) * NBX + cb) * 4) * 64 + lane;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const f32x4 av = pa[r4 * 64];
+          if (kWRegs) {
 #pragma unroll
-          for (int d = 0; d < 4; ++d) dx = mfma(av[d], dHpre[t][4 * r4 + d], dx);
+            for (int d = 0; d < 4; ++d) dx = mfma(wA1T[t][cb][4 * r4 + d], dHpre[t][4 * r4 + d], dx);
+          } else {
+            const f32x4 av = pa[r4 * 64];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dx = mfma(av[d], dHpre[t][4 * r4 + d], dx);
+          }
         }
       }
       f32x4* pw = reinterpret_cast<f32x4*>(po) + ((w * NBP + cb) * 4) * 64 + lane;
@@ -650,10 +707,11 @@ int launch_edge(const PcArgs& a, int grid, hipStream_t s) {
   static unsigned long long attr_done = 0ull;
   const int rc = once_per_device(attr_done, [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_edge_kernel<EIN, HID, CO, BWD>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_FLOATS * 4) == hipSuccess;
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (BWD ? P::LDS_FLOATS : P::LDS_FLOATS_FWD) * 4) == hipSuccess;
   });
   if (rc != WCN_SUCCESS) return rc;
-  hipLaunchKernelGGL((pointconv_edge_kernel<EIN, HID, CO, BWD>), dim3(grid), dim3(256), P::LDS_FLOATS * 4, s, a);
+  hipLaunchKernelGGL((pointconv_edge_kernel<EIN, HID, CO, BWD>), dim3(grid), dim3(256),
+                     (BWD ? P::LDS_FLOATS : P::LDS_FLOATS_FWD) * 4, s, a);
   return launch_status();
 }
 
