@@ -127,7 +127,7 @@ int wcn_morton_code(const int32_t* coords, int64_t n, int32_t num_dims, const in
  *               (the caller then rebuilds with strict = 1: atomicMin, ~2.5x the store cost)
  *   mask        rows that no block has enumerated yet (duplicates) carry 0x80000000 in their LAST mask word until
  *               wcn_kmap_tally_sort repairs them, which is why K % 32 == 0 is not supported here
- * Returns WCN_ERROR_PROBLEM_NOT_SUPPORTED when the kernel halo exceeds 4 cells or K % 32 == 0
+ * Returns WCN_ERROR_PROBLEM_NOT_SUPPORTED when the kernel halo (max |offset| per axis, dilation included) exceeds 8 cells or K % 32 == 0
  * (wcn_kmap_binned_supported == 0): the caller then uses the hash path.
  * reference being replaced: cuhash_hash_table.cu:179-220 + cuhash_kernel_map.cu:93-134. */
 size_t wcn_kmap_binned_workspace(int64_t n, int64_t max_blocks);

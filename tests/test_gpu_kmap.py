@@ -296,3 +296,27 @@ def test_offset_method_and_skip_symmetric_return_the_first_half():
         generate_kernel_map(c, c, (1, 1, 1), (2, 2, 2), skip_symmetric_kernel_map=True)  # even kernel
     with pytest.raises(ValueError):
         generate_kernel_map(c, c, (1, 1, 1), (3, 3, 3), method="hash")
+
+
+@pytest.mark.parametrize("n,ksize,dil", [(1500, (9, 9, 9), (1, 1, 1)), (2500, (7, 7, 7), (2, 2, 2)), (4000, (3, 3, 3), (8, 8, 8)),
+                                         (3000, (5, 3, 5), (2, 5, 1)), (2000, (3, 3, 3), (6, 1, 3))])
+def test_large_halo_maps_bit_exact(n, ksize, dil):
+    """Halos of 4..8 cells (9^3, dilated 7^3 / 5^3 / 3^3) stay on the cell-table builder: LDS grid up to 24^3 cells, the
+    neighbour cells of a probe still lie in the 26 adjacent blocks.  Both builders against the oracle."""
+    import os
+
+    from warpconvnet_amd import _lib
+
+    s = np.concatenate([scene_u(n, 11, 0), scene_u(n // 3, 12, 1)], 0)
+    s[:, 1:] -= 13
+    import ctypes
+    arr = ctypes.c_int32 * 3
+    assert _lib.lib().wcn_kmap_binned_supported(arr(*ksize), arr(*dil)) == 1
+    for method in ("binned", "hash"):
+        os.environ["WARPCONVNET_AMD_KMAP_METHOD"] = method
+        try:
+            km = _gen(s, s, ksize, dilation=dil, same=True)
+            _check_against_oracle(km, s, s, ksize, dilation=dil)
+        finally:
+            os.environ.pop("WARPCONVNET_AMD_KMAP_METHOD", None)
+    assert _lib.lib().wcn_kmap_binned_supported(arr(3, 3, 3), arr(9, 1, 1)) == 0  # halo 9: hash path

@@ -173,17 +173,17 @@ __global__ __launch_bounds__(256) void morton_code_kernel(const int32_t* __restr
 
 // nbr [m][kp] -> pair_table [K][m]
 __global__ __launch_bounds__(kThreads) void kmap_transpose_kernel(const int32_t* __restrict__ nbr, int64_t m, int K,
-                                                                  int kp, int32_t* __restrict__ pair_table) {
-  extern __shared__ int s_tile[];  // [64][kp+1]
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
+                                                                  int kp, int tr, int32_t* __restrict__ pair_table) {
+  extern __shared__ int s_tile[];  // [tr][kp+1], tr rows per workgroup (64, fewer for large kernel volumes)
+  const int64_t row0 = (int64_t)blockIdx.x * tr;
   const int pitch = kp + 1;
-  for (int e = threadIdx.x; e < 64 * kp; e += kThreads) {
+  for (int e = threadIdx.x; e < tr * kp; e += kThreads) {
     const int r = e / kp, k = e % kp;
     s_tile[r * pitch + k] = (row0 + r < m) ? nbr[(row0 + r) * kp + k] : -1;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 64 * K; e += kThreads) {
-    const int k = e / 64, r = e % 64;
+  for (int e = threadIdx.x; e < tr * K; e += kThreads) {
+    const int k = e / tr, r = e % tr;
     if (row0 + r < m) pair_table[(int64_t)k * m + row0 + r] = s_tile[r * pitch + k];
   }
 }
@@ -346,8 +346,10 @@ int wcn_kmap_transpose(const int32_t* nbr, int64_t m, int32_t num_offsets, int32
   if (m == 0) return WCN_SUCCESS;
   if (!nbr || !pair_table) return WCN_ERROR_INVALID_PARAMETERS;
   const int kp = wcn_kmap_row_pitch(num_offsets);
-  hipLaunchKernelGGL(kmap_transpose_kernel, dim3((unsigned)ceil_div(m, 64)), dim3(kThreads),
-                     (size_t)64 * (kp + 1) * sizeof(int), (hipStream_t)stream, nbr, m, (int)num_offsets, kp, pair_table);
+  int tr = 64;  // rows per workgroup: the LDS tile stays within 64 KB
+  while (tr > 1 && (size_t)tr * (kp + 1) * sizeof(int) > 64 * 1024) tr >>= 1;
+  hipLaunchKernelGGL(kmap_transpose_kernel, dim3((unsigned)ceil_div(m, tr)), dim3(kThreads),
+                     (size_t)tr * (kp + 1) * sizeof(int), (hipStream_t)stream, nbr, m, (int)num_offsets, kp, tr, pair_table);
   return launch_status();
 }
 

@@ -34,7 +34,7 @@ namespace wcn {
 
 constexpr int kInsertSample = 16;  // cell_insert<0>: 1 voxel in 16 goes first (see the kernel)
 constexpr int kInsertThreads = 512;
-constexpr int kNbThreads = 256;    // cell_neighbors: 4 independent waves per workgroup
+constexpr int kNbThreads = 256;    // cell_neighbors: up to 4 independent waves per workgroup (fewer when the LDS grid is large)
 
 __device__ __forceinline__ int wrap_blk(int v) {  // wrap to the signed range of the block coordinate field
   const int bits = kBlkCoordBits;
@@ -281,14 +281,14 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
   // behind the grid that holds -1, so the probe loop needs no bounds checks (row -1 = nothing stored)
   unsigned short* s_own = reinterpret_cast<unsigned short*>(s_grid + g.cells + 4);
   const int null_cell = g.cells;
-  for (int h = threadIdx.x; h < halo_pad; h += kNbThreads) s_halo[h] = h < g.halo_cells ? halo[h] : 0xFFFFFFFFu;
+  for (int h = threadIdx.x; h < halo_pad; h += blockDim.x) s_halo[h] = h < g.halo_cells ? halo[h] : 0xFFFFFFFFu;
   if (lane == 0) s_grid[null_cell] = -1;
   __syncthreads();  // the only workgroup barrier: the waves are independent from here on
 
   int nblocks = t.ctr[0];
   if (nblocks > t.max_blocks) nblocks = (int)t.max_blocks;
-  const int gwave = blockIdx.x * (kNbThreads / 64) + wave;
-  const int nwaves = gridDim.x * (kNbThreads / 64);
+  const int gwave = blockIdx.x * (blockDim.x / 64) + wave;
+  const int nwaves = gridDim.x * (blockDim.x / 64);
   constexpr int kVoxPerIter = 64 / LPR;
   const int sub = lane % LPR, vsel = lane / LPR;
   const int num_chunks = (kp + LPR - 1) / LPR;
@@ -504,14 +504,32 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
                        (const int4*)coords, n, t, g, mw, (const uint32_t*)mask, (int)strict);
   }
   const int halo_pad = (g.halo_cells + 63) & ~63;
-  const size_t shm = ((size_t)halo_pad + (size_t)(kNbThreads / 64) * (g.cells + 4 + kCells / 2 + 8)) * 4;
+  // waves per workgroup: 4, fewer when halo list + one LDS grid per wave would not fit (halo 6..8: 20^3..24^3 cells)
+  int nb_waves = kNbThreads / 64;
+  auto shm_for = [&](int waves) { return ((size_t)halo_pad + (size_t)waves * (g.cells + 4 + kCells / 2 + 8)) * 4; };
+  while (nb_waves > 1 && shm_for(nb_waves) > 156 * 1024) nb_waves >>= 1;
+  const size_t shm = shm_for(nb_waves);
+  if (shm > 160 * 1024) return WCN_ERROR_PROBLEM_NOT_SUPPORTED;
   // resident waves only (the loop strides over the blocks): LDS allows 160 KB / shm workgroups per CU
   int per_cu = (int)((160 * 1024) / (shm + 512));
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
-  int64_t want = ceil_div(max_blocks < n ? max_blocks : n, kNbThreads / 64);  // never more waves than blocks
+  int64_t want = ceil_div(max_blocks < n ? max_blocks : n, nb_waves);  // never more waves than blocks
   if (want > 256 * per_cu) want = 256 * per_cu;
-  const dim3 grid((unsigned)want), block(kNbThreads);
+  const dim3 grid((unsigned)want), block(nb_waves * 64);
+  if (shm > 64 * 1024) {  // above the default dynamic-LDS limit: raise it once per device for every instance
+    static unsigned long long attr_done = 0ull;
+    const int rc = once_per_device(attr_done, [] {
+      bool ok = true;
+      for (const void* f : {reinterpret_cast<const void*>(cell_neighbors_kernel<8, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<8, false>),
+                            reinterpret_cast<const void*>(cell_neighbors_kernel<16, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<16, false>),
+                            reinterpret_cast<const void*>(cell_neighbors_kernel<32, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<32, false>),
+                            reinterpret_cast<const void*>(cell_neighbors_kernel<64, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<64, false>)})
+        ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      return ok;
+    });
+    if (rc != WCN_SUCCESS) return rc;
+  }
   const bool fast = n < (1ll << 24) && n * kp * 4 < (1ll << 31);
 #define WCN_CELL_NB(L)                                                                                                 \
   do {                                                                                                                 \

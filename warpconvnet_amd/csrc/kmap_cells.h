@@ -9,7 +9,7 @@ namespace wcn {
 constexpr int kBlkShift = 3;
 constexpr int kBlk = 1 << kBlkShift;    // 8 cells per axis
 constexpr int kCells = kBlk * kBlk * kBlk;  // 512 row ids = 2 KB per occupied block
-constexpr int kMaxHalo = 4;
+constexpr int kMaxHalo = 8;  // one block width: the 26 adjacent blocks still cover every probe
 constexpr int kBlkCoordBits = kCoordBits - kBlkShift;  // 15-bit signed block coordinates
 constexpr uint32_t kMaskUnwritten = 0x80000000u;       // top bit of a row's LAST mask word: no block has written the row
 constexpr uint32_t kMaskDeferred = 0x80000001u;        // ... and its cell is not stored yet (block created by the 2nd insert pass)
@@ -60,7 +60,7 @@ static inline CellTable carve_cells(void* ws, int64_t n, int64_t max_blocks) {
   t.max_blocks = max_blocks;
   t.capacity = cell_capacity(max_blocks);
   t.ctr = (int32_t*)take(256);
-  t.halo = (uint32_t*)take((size_t)4096 * 4);  // (8 + 2*4)^3 - 512 = 3584 entries at most
+  t.halo = (uint32_t*)take((size_t)16384 * 4);  // (8 + 2*8)^3 - 512 = 13312 entries at most
   t.slots = (BSlot*)take((size_t)t.capacity * sizeof(BSlot));
   t.blk_key = (uint64_t*)take((size_t)max_blocks * 8);
   t.nbtab = (int32_t*)take((size_t)max_blocks * 32 * 4);

@@ -227,7 +227,7 @@ def generate_kernel_map(
     )
     if method_env == "binned" and not use_binned and N > 0:
         raise RuntimeError("WARPCONVNET_AMD_KMAP_METHOD=binned needs a submanifold map (same coordinate tensor, stride 1, "
-                           "halo <= 4, K % 32 != 0)")
+                           "halo <= 8, K % 32 != 0)")
     table_capacity = _next_power_of_2(max(16, 2 * N))
     # binned path: capacity of the block table.  Most scenes have >= 4 voxels per occupied 8^3 block; sparser ones raise
     # TABLE_FULL on the device and are rebuilt with one block per voxel (always enough).  `strict`: see wcn.h.
