@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 KSIZES = [(3, 3, 3), (3, 3, 3), (2, 2, 2), (5, 5, 5), (1, 1, 1), (3, 1, 3), (1, 3, 5), (2, 3, 2), (5, 3, 1), (4, 4, 4)]
 STRIDES = [(1, 1, 1), (1, 1, 1), (2, 2, 2), (2, 1, 2), (3, 3, 3), (4, 4, 4)]
-DILATIONS = [(1, 1, 1), (1, 1, 1), (2, 2, 2), (1, 2, 3)]
+DILATIONS = [(1, 1, 1), (1, 1, 1), (2, 2, 2), (1, 2, 3), (4, 1, 2)]  # halos up to 8 cells stay on the cell-table builder
 
 
 def _draw_scene(rng, duplicates=False):
