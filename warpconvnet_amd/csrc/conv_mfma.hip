@@ -567,8 +567,18 @@ int conv_gather_gemm16(const void* in, const void* wp, void* out, const int32_t*
 int pack_weight16(const void* w, int w_is_f32, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                   hipStream_t s);
 
-int mfma_chunk_for(int cin) {
-  if (cin % 64 == 0) return 64;
+// reduction chunk per step.  128 when the output is narrow (accumulators <= 64 registers leave room for two 64-register
+// row buffers): a 128 -> 64 dgrad then runs one step per offset instead of two - half the drains and barriers.
+static int chunk128_mode() {
+  static const int v = [] {
+    const char* e = getenv("WARPCONVNET_AMD_GEMM_CIC128");
+    return e ? atoi(e) : 0;  // measured: 128 -> 64 dgrad 317 vs 265 us in-step - more loads in flight per step stall the issue
+  }();
+  return v;
+}
+int mfma_chunk_for(int cin, int cout, int K) {
+  if (cin % 128 == 0 && cout <= 64 && K <= 32 && chunk128_mode() > 0) return 128;  // (the multi-word-mask instance spills)
+  if (cin % 64 == 0 && chunk128_mode() >= 0) return 64;  // (-1: dev switch, 32-channel steps)
   if (cin % 32 == 0) return 32;
   if (cin % 16 == 0) return 16;
   return 0;
@@ -576,7 +586,7 @@ int mfma_chunk_for(int cin) {
 
 // channel shapes of the 32x32x16 kernels in this file
 bool mfma32_shape(int cin, int cout) {
-  if (mfma_chunk_for(cin) == 0) return false;
+  if (mfma_chunk_for(cin, cout, 1) == 0) return false;
   return cout == 32 || cout == 64 || cout == 96 || cout == 128 || cout == 192 || cout == 256;
 }
 
@@ -591,7 +601,10 @@ template <typename T>
 static int dispatch_cic(int cin, int cout, const void* in, const void* wp, void* out, const int32_t* nbr,
                         const uint32_t* mask, const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int K, float* out32,
                         hipStream_t s, int groups = 1) {
-  switch (mfma_chunk_for(cin)) {
+  switch (mfma_chunk_for(cin, cout, K)) {
+    case 128:
+      if (cout == 32) return launch_gather_gemm<T, 128, 32, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+      return launch_gather_gemm<T, 128, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
@@ -632,7 +645,7 @@ int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, in
   // the layout of the packed image follows the kernel that will consume it (a pure function of the shape)
   if (!gather_gemm_lds_supported(cin, cout, K, dtype) && mfma16_supported(cin, cout, K, dtype))
     return pack_weight16(w, 1, K, cin, cout, dtype, transpose, flip, packed, s);
-  const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin);
+  const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin, cout, K);
   if (cic == 0 || cout % 32 != 0 || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   const int64_t total = (int64_t)K * cin * cout;
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
@@ -648,7 +661,7 @@ int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int tra
                      hipStream_t s) {
   if (!gather_gemm_lds_supported(cin, cout, K, dtype) && mfma16_supported(cin, cout, K, dtype))
     return pack_weight16(w, 0, K, cin, cout, dtype, transpose, flip, packed, s);
-  const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin);
+  const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin, cout, K);
   if (cic == 0 || cout % 32 != 0 || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   const int64_t total = (int64_t)K * cin * cout;
   // bf16 and f16 are both 2-byte moves
@@ -659,7 +672,7 @@ int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int tra
 
 int pack_weight_grouped(const void* w, int w_is_f32, int K, int groups, int cin, int cout, int dtype, int transpose, int flip,
                         void* packed, hipStream_t s) {
-  const int cic = mfma_chunk_for(cin);
+  const int cic = mfma_chunk_for(cin, cout, K);
   if (groups < 1 || cic == 0 || !mfma32_shape(cin, cout) || (dtype != WCN_F16 && dtype != WCN_BF16))
     return WCN_ERROR_UNSUPPORTED_CONFIG;
   const int64_t total = (int64_t)groups * K * cin * cout;
