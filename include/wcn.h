@@ -342,35 +342,38 @@ int wcn_segment_reduce(const void* in, const int64_t* row_splits, int64_t num_se
 /* ---- PointConv edge pipeline in one pass ----------------------------------------------------------------------------
  * Replaces the op sequence of warpconvnet/nn/modules/point_conv.py:231-273 (features[neighbors] / repeat_interleave / cat
  * -> edge_transform_mlp -> row_reduction) for the default edge MLP of warpconvnet/nn/modules/mlp.py:124-177
- * (Linear - LayerNorm - ReLU - Linear - LayerNorm + identity shortcut): for query q and its k neighbours j (uniform k, a
+ * (Linear - LayerNorm - ReLU - Linear - LayerNorm + identity or Linear shortcut): for query q and its k neighbours j (uniform k, a
  * power of two <= 32, `nbr` [n_query * k] int32 rows of in_feats):
  *     x = [in_feats[j] | q_feats[q] | in_xyz[j] - q_xyz[q] (nrel = 3, else 0)],   out[q] = sum or mean over j of
- *     LN2(W2 ReLU(LN1(W1 x + b1)) + b2) + x                      fp32, matrix cores (v_mfma_f32_32x32x2_f32).
+ *     LN2(W2 ReLU(LN1(W1 x + b1)) + b2) + (x  or  Ws x + bs)     fp32, matrix cores (v_mfma_f32_32x32x2_f32).
  * No [n_query * k, C] tensor is written to HBM in either direction; the backward recomputes the chain per 32-edge tile.
- * wcn_pointconv_supported: cin + cq + nrel == cout (identity shortcut) and the widths fit an instantiated tile
+ * wcn_pointconv_supported: cin + cq + nrel == cout unless linear_shortcut, and the widths fit an instantiated tile
  *   (edge-in <= 64, hidden <= 128, cout <= 64; smaller widths run zero-padded).
  * wcn_pointconv_pack: torch-layout parameters (w1 [hidden][ein], w2 [cout][hidden], biases / LayerNorm weights may be
- *   NULL = 0) -> operand images, wcn_pointconv_packed_floats floats.
+ *   NULL = 0; ws [cout][ein] / bs = the Linear shortcut or NULL) -> operand images, wcn_pointconv_packed_floats floats.
  * wcn_pointconv_edge_backward: d_in [n_in][cin] must be ZERO-FILLED by the caller (neighbour rows are accumulated with
  *   hardware fp32 atomics: the one non-deterministic sum of the path, like index_add in the reference's autograd);
  *   d_q [n_query][cq] is written; d_params (wcn_pointconv_grad_floats floats) = dW1 [hidden][ein] | db1 | dLN1.weight |
- *   dLN1.bias | dW2 [cout][hidden] | db2 | dLN2.weight | dLN2.bias, reduced over the workgroups in fixed order. */
-int wcn_pointconv_supported(int32_t cin, int32_t cq, int32_t nrel, int32_t hidden, int32_t cout, int32_t k);
+ *   dLN1.bias | dW2 [cout][hidden] | db2 | dLN2.weight | dLN2.bias (| dWs [cout][ein] | dbs with a Linear shortcut),
+ *   reduced over the workgroups in fixed order. */
+int wcn_pointconv_supported(int32_t cin, int32_t cq, int32_t nrel, int32_t hidden, int32_t cout, int32_t k,
+                            int32_t linear_shortcut);
 int64_t wcn_pointconv_packed_floats(int32_t ein, int32_t hidden, int32_t cout);
-int64_t wcn_pointconv_grad_floats(int32_t ein, int32_t hidden, int32_t cout);
-size_t wcn_pointconv_backward_workspace(int64_t n_query, int32_t k, int32_t ein, int32_t hidden, int32_t cout);
+int64_t wcn_pointconv_grad_floats(int32_t ein, int32_t hidden, int32_t cout, int32_t linear_shortcut);
+size_t wcn_pointconv_backward_workspace(int64_t n_query, int32_t k, int32_t ein, int32_t hidden, int32_t cout,
+                                        int32_t linear_shortcut);
 int wcn_pointconv_pack(const float* w1, const float* b1, const float* g1, const float* be1, const float* w2,
-                       const float* b2, const float* g2, const float* be2, int32_t ein, int32_t hidden, int32_t cout,
-                       float* packed, wcn_stream_t stream);
+                       const float* b2, const float* g2, const float* be2, const float* ws, const float* bs, int32_t ein,
+                       int32_t hidden, int32_t cout, float* packed, wcn_stream_t stream);
 int wcn_pointconv_edge_forward(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
                                const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
                                const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
-                               float* out, wcn_stream_t stream);
+                               int32_t linear_shortcut, float* out, wcn_stream_t stream);
 int wcn_pointconv_edge_backward(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
                                 const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
                                 const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
-                                const float* grad_out, float* d_in, float* d_q, float* d_params, void* workspace,
-                                size_t workspace_bytes, wcn_stream_t stream);
+                                int32_t linear_shortcut, const float* grad_out, float* d_in, float* d_q, float* d_params,
+                                void* workspace, size_t workspace_bytes, wcn_stream_t stream);
 
 /* Sparse pooling over a kernel map (REDUCE_AND_STRIDE, SparsePool / SparseMaxPool / SparseUnpool): out[m][c] =
  * reduce over the present neighbours k of in[tbl[m][k]][c]; `tbl` is the row-major neighbour table [n_out][row pitch of

@@ -45,7 +45,11 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_mfma_wgrad_supported(48, 64, _lib.WCN_F16) == 0 and L.wcn_mfma_wgrad_supported(64, 64, _lib.WCN_F32) == 0
     assert L.wcn_mfma_gather_supported(64, 192, 27, _lib.WCN_BF16) == 1
     assert L.wcn_kmap_binned_supported(_lib.i3((3, 3, 3)), _lib.i3((1, 1, 1))) == 1
-    assert L.wcn_kmap_binned_supported(_lib.i3((3, 3, 3)), _lib.i3((8, 8, 8))) == 0
+    assert L.wcn_kmap_binned_supported(_lib.i3((3, 3, 3)), _lib.i3((8, 8, 8))) == 1  # halo 8 = one block width
+    assert L.wcn_kmap_binned_supported(_lib.i3((3, 3, 3)), _lib.i3((9, 1, 1))) == 0  # beyond: hash path
+    assert L.wcn_pointconv_supported(32, 32, 0, 128, 64, 16, 0) == 1 and L.wcn_pointconv_supported(24, 24, 0, 128, 64, 16, 0) == 0
+    assert L.wcn_pointconv_supported(24, 24, 0, 128, 64, 16, 1) == 1 and L.wcn_pointconv_supported(32, 32, 0, 128, 64, 12, 0) == 0
+    assert L.wcn_pointconv_grad_floats(64, 128, 64, 1) - L.wcn_pointconv_grad_floats(64, 128, 64, 0) == 64 * 64 + 64
     assert L.wcn_packed_weight_bytes(27, 64, 128, _lib.WCN_BF16, 0) == 27 * 64 * 128 * 2
     assert L.wcn_conv_wgrad_workspace(27, 64, 128, _lib.WCN_ALGO_MFMA) > 27 * 64 * 128 * 4
     assert L.wcn_mask_argsort_workspace(1000) > 3 * 4000 and L.wcn_kmap_binned_workspace(1000, 250) > 250 * 2048

@@ -244,10 +244,13 @@ def test_radius_grid_matches_reference_golden(golden_dir, tag):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,cin,cout,k,red,rel", [(5000, 32, 64, 16, "mean", False), (1234, 8, 16, 8, "sum", False),
                                                   (3001, 16, 32, 4, "mean", False), (2000, 8, 19, 32, "mean", True),
-                                                  (700, 4, 8, 1, "sum", False), (4097, 24, 48, 2, "mean", False)])
+                                                  (700, 4, 8, 1, "sum", False), (4097, 24, 48, 2, "mean", False),
+                                                  # widths that differ -> Linear shortcut of the MLPBlock
+                                                  (3000, 24, 64, 16, "mean", False), (2500, 16, 16, 8, "sum", False),
+                                                  (2000, 16, 32, 4, "mean", True), (1500, 30, 12, 8, "mean", False)])
 def test_pointconv_fused_edge_kernel_vs_fp64(n, cin, cout, k, red, rel):
     """The one-pass edge pipeline (csrc/pointconv.hip: gather -> Linear -> LN -> ReLU -> Linear -> LN + shortcut ->
-    reduction, forward and backward) against the same module evaluated op by op in fp64 on the CPU from the same
+    reduction, forward and backward; identity and Linear shortcut) against the same module evaluated op by op in fp64 on the CPU from the same
     neighbour lists: output rows, input-feature gradient, every parameter gradient."""
     import copy
 

@@ -11,6 +11,7 @@ grep -h '"metric"' gpurun_out/prof/${R}_trace.log | tail -1 > gpurun_out/prof/${
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof -o ${R}_fetch -- $CMD > gpurun_out/prof/${R}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof -o ${R}_write -- $CMD > gpurun_out/prof/${R}_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d gpurun_out/prof -o ${R}_mfma -- $CMD > gpurun_out/prof/${R}_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d gpurun_out/prof -o ${R}_sq -- $CMD > gpurun_out/prof/${R}_sq.log 2>&1
 # secondary workloads (MinkUNet-14 at 200 k / 1 M voxels, PointConv + depthwise): kernel trace of the full default command
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${R}_secondary -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/${R}_secondary.log 2>&1
 python tools/rocpd_stats.py gpurun_out/prof/${R}_trace_results.db > gpurun_out/prof/${R}_kernel_trace_stats.md
@@ -18,6 +19,7 @@ python tools/rocpd_stats.py gpurun_out/prof/${R}_secondary_results.db > gpurun_o
 python tools/rocpd_stats.py gpurun_out/prof/${R}_fetch_results.db pmc > gpurun_out/prof/${R}_pmc_fetch_size.md
 python tools/rocpd_stats.py gpurun_out/prof/${R}_write_results.db pmc > gpurun_out/prof/${R}_pmc_write_size.md
 python tools/rocpd_stats.py gpurun_out/prof/${R}_mfma_results.db mfma > gpurun_out/prof/${R}_pmc_mfma_busy.md
+python tools/rocpd_stats.py gpurun_out/prof/${R}_sq_results.db sq > gpurun_out/prof/${R}_pmc_wave_cycles.md
 python tools/rocpd_stats.py traffic gpurun_out/prof/${R}_fetch_results.db gpurun_out/prof/${R}_write_results.db > gpurun_out/prof/${R}_pmc_traffic.json
 rm -f gpurun_out/prof/*_results.db   # the summaries travel back, the databases do not fit the 64 MiB return budget
 head -30 gpurun_out/prof/${R}_kernel_trace_stats.md

@@ -124,7 +124,35 @@ def mfma(db):
             print(f"| `{name}` | {agg[(k, 'SQ_BUSY_CU_CYCLES')][0]} | {m:,.0f} | {b:,.0f} | {m / (4 * b):.3f} |")
 
 
+def sq(db):
+    """Where the wave-cycles go, per kernel, from a `--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+    SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT` pass (values in quad-cycles, summed over all waves of a dispatch)."""
+    rows = sqlite3.connect(db).execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+    agg = {}
+    for k, c, v in rows:
+        a = agg.setdefault((k, c), [0, 0.0])
+        a[0] += 1
+        a[1] += v
+    avg = {kc: t / n for kc, (n, t) in agg.items()}
+    names = sorted({k for k, _ in avg}, key=lambda k: -avg.get((k, "SQ_WAVE_CYCLES"), 0) * agg.get((k, "SQ_WAVE_CYCLES"), [0])[0])
+    print(f"# rocprofv3 PMC summary: wave-cycle breakdown ({db})\n")
+    print("Per dispatch, quad-cycles summed over all waves.  parked = `SQ_WAIT_ANY` (waves in `s_waitcnt` / `s_barrier`), issue stall =")
+    print("`SQ_WAIT_INST_ANY` (an instruction is ready but cannot issue), executing = `SQ_ACTIVE_INST_ANY`; LDS bank conflict cycles on the right.\n")
+    print("| kernel | dispatches | wave quad-cycles | parked | issue stall | executing | of which LDS | LDS bank conflicts |\n|---|---:|---:|---:|---:|---:|---:|---:|")
+    for k in names[:16]:
+        wv = avg.get((k, "SQ_WAVE_CYCLES"), 0.0)
+        if wv <= 0:
+            continue
+        f = lambda c: avg.get((k, c), 0.0) / wv
+        name = k if len(k) < 100 else k[:97] + "..."
+        print(f"| `{name}` | {agg[(k, 'SQ_WAVE_CYCLES')][0]} | {wv:,.0f} | {f('SQ_WAIT_ANY'):.2f} | {f('SQ_WAIT_INST_ANY'):.2f} | "
+              f"{f('SQ_ACTIVE_INST_ANY'):.2f} | {f('SQ_ACTIVE_INST_LDS'):.2f} | {f('SQ_LDS_BANK_CONFLICT'):.2f} |")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "sq":
+        sq(sys.argv[1])
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "mfma":
         mfma(sys.argv[1])
         sys.exit(0)

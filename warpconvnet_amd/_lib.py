@@ -156,20 +156,21 @@ SIGNATURES = {
          c_void_p, c_void_p],
     ),
     "wcn_segment_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
-    "wcn_pointconv_supported": (c_int, [c_int32] * 6),
+    "wcn_pointconv_supported": (c_int, [c_int32] * 7),
     "wcn_pointconv_packed_floats": (c_int64, [c_int32] * 3),
-    "wcn_pointconv_grad_floats": (c_int64, [c_int32] * 3),
-    "wcn_pointconv_backward_workspace": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),
-    "wcn_pointconv_pack": (c_int, [c_void_p] * 8 + [c_int32] * 3 + [c_void_p, c_void_p]),
+    "wcn_pointconv_grad_floats": (c_int64, [c_int32] * 4),
+    "wcn_pointconv_backward_workspace": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "wcn_pointconv_pack": (c_int, [c_void_p] * 10 + [c_int32] * 3 + [c_void_p, c_void_p]),
     "wcn_pointconv_edge_forward": (
         c_int,
         [c_void_p] * 5 + [c_int64] + [c_int32] * 4 + [c_void_p, c_int32, c_int32, ctypes.c_float, ctypes.c_float, c_int32,
-                                                      c_void_p, c_void_p],
+                                                      c_int32, c_void_p, c_void_p],
     ),
     "wcn_pointconv_edge_backward": (
         c_int,
         [c_void_p] * 5 + [c_int64] + [c_int32] * 4 + [c_void_p, c_int32, c_int32, ctypes.c_float, ctypes.c_float, c_int32,
-                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+                                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                      c_void_p],
     ),
     "wcn_mfma_wgrad_bias_supported": (c_int, [c_int32, c_int32, c_int32]),
     "wcn_conv_wgrad_bias": (

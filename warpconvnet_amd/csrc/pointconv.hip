@@ -60,7 +60,14 @@ struct PC {
   static constexpr int OFF_P1T = OFF_P2T + HID * CO;  // [NB1][NBX][4][64][4]     dX A:    W1[c = 32cb+i][hid = 32blk+sigma(r,h)]
   static constexpr int OFF_T1 = OFF_P1T + EIN * HID;  // [NB1][3][2][16]          b1, g1, be1 at channel 32blk+sigma(r,h)
   static constexpr int OFF_T2 = OFF_T1 + NB1 * 96;    // [NB2][3][2][16]          b2, g2, be2
-  static constexpr int PACKED = OFF_T2 + NB2 * 96;
+  static constexpr int OFF_PS = OFF_T2 + NB2 * 96;    // [NB2][KS1/4][64][4]      shortcut A: Ws[c = h*KS1+s][out = 32b+i]
+  static constexpr int OFF_PST = OFF_PS + EIN * CO;   // [NBX][NB2][4][64][4]     dX A:       Ws[c = 32cb+i][out = 32b+sigma(r,h)]
+  static constexpr int OFF_TS = OFF_PST + EIN * CO;   // [NB2][2][16]             bs
+  static constexpr int PACKED = OFF_TS + NB2 * 32;
+  // Linear shortcut: wave w computes output block w % NB2 over its 1/PARTS of the reduction
+  static constexpr int PARTS = kPcWaves / NB2, SPW = KS1 / PARTS;
+  static_assert(NB2 == 1 || NB2 == 2 || NB2 == 4, "shortcut split");
+  static constexpr int WSB = (NBX * NB2 + kPcWaves - 1) / kPcWaves;  // dWs blocks per wave
   // LDS (floats)
   static constexpr int L_TAB = 0;                             // [NB1 + NB2][3][2][16] bias / LayerNorm tables (copy of T1, T2)
   static constexpr int L_TX = (NB1 + NB2) * 96;               // [EIN][kPitch]      x, channel-major (identity shortcut, dW1 A)
@@ -68,13 +75,14 @@ struct PC {
   static constexpr int L_TB = L_TH + HID * kPitch;            // [CO][kPitch]       dOpre channel-major / forward output tile
   static constexpr int L_PO = L_TB + CO * kPitch;             // [4][NBP][16][64]   partial tiles exchanged between the waves
   static constexpr int L_ST = L_PO + kPcWaves * NBP * 1024;   // [2][4][32][2]      LayerNorm partial sums
-  static constexpr int L_DXT = L_ST + 2 * kPcWaves * 64;      // [32][EIN+1]        dX, edge-major
-  static constexpr int L_DOUT = L_DXT + 32 * (EIN + 1);       // [32][CO]           grad_out rows of the tile's queries
+  static constexpr int L_DXT = L_ST + 2 * kPcWaves * 64;      // [32][EIN+1]        dX, edge-major; before that dy channel-major [CO][kPitch]
+  static constexpr int DXT_FLOATS = ((32 * (EIN + 1) > CO * kPitch ? 32 * (EIN + 1) : CO * kPitch) + 3) & ~3;
+  static constexpr int L_DOUT = L_DXT + DXT_FLOATS;           // [32][CO]           grad_out rows of the tile's queries
   static constexpr int L_JT = L_DOUT + 32 * CO;               // [32] int           neighbour ids
   static constexpr int L_WT = L_JT + 32;                      // [HID*CO + EIN*HID]  backward: P2T | P1T operand images
   static constexpr int LDS_FLOATS = L_WT + HID * CO + EIN * HID;
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-  static constexpr int LDS_FLOATS_FWD = L_DXT - HID * kPitch;  // the forward kernel stops at the LayerNorm sums
+  static constexpr int LDS_FLOATS_FWD = L_DXT - HID * kPitch + PARTS * CO * kPitch;  // forward: ... + shortcut partial tiles
 };
 
 struct PcArgs {
@@ -88,6 +96,7 @@ struct PcArgs {
   const float* packed;
   int32_t ein_t, hid_t, co_t;  // true channel counts
   float eps1, eps2, scale;     // scale: 1 (sum) or 1/k (mean)
+  int32_t lin_sc;              // 0: identity shortcut (ein == cout), 1: Linear shortcut
   float* out;                  // forward:  [n_query][co_t]
   const float* grad_out;       // backward: [n_query][co_t]
   float* d_in;                 //           [n_in][cin], zero-filled by the caller (accumulated with atomics)
@@ -96,11 +105,12 @@ struct PcArgs {
 };
 
 // gradient blob (floats, torch layouts): dW1 [hid][ein] | db1 | dg1 | dbe1 | dW2 [co][hid] | db2 | dg2 | dbe2
-__host__ __device__ inline int64_t grad_floats(int ein_t, int hid_t, int co_t) {
-  return (int64_t)hid_t * ein_t + 3 * hid_t + (int64_t)co_t * hid_t + 3 * co_t;
+//                                         (+ dWs [co][ein] | dbs with a Linear shortcut)
+__host__ __device__ inline int64_t grad_floats(int ein_t, int hid_t, int co_t, int lin_sc) {
+  return (int64_t)hid_t * ein_t + 3 * hid_t + (int64_t)co_t * hid_t + 3 * co_t + (lin_sc ? (int64_t)co_t * ein_t + co_t : 0);
 }
 
-template <int EIN, int HID, int CO, bool BWD>
+template <int EIN, int HID, int CO, bool BWD, bool LIN>
 __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const PcArgs a) {
   typedef PC<EIN, HID, CO> P;
   constexpr int KS1 = P::KS1, HB = P::HB, NB2 = P::NB2, NBX = P::NBX, NBP = P::NBP;
@@ -111,6 +121,8 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
   float* po = smem + (BWD ? P::L_PO : P::L_PO - HID * kPitch);
   float* st = smem + (BWD ? P::L_ST : P::L_ST - HID * kPitch);
   float* dxt = smem + P::L_DXT;
+  float* tD = dxt;                                                    // backward: dy channel-major, dead before dxt is written
+  float* tS = smem + P::L_DXT - HID * kPitch;                         // forward: [PARTS][CO][kPitch] shortcut partial tiles
   float* dout = smem + P::L_DOUT;
   int32_t* jt = reinterpret_cast<int32_t*>(smem + P::L_JT);
 
@@ -133,6 +145,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
   f32x16 dW1a[NBX][HB], dW2a[HB][NB2];
   float dg1a[HB][16], dbe1a[HB][16], db1a[HB][16];
   float dg2a[NB2 * 4], dbe2a[NB2 * 4], db2a[NB2 * 4];  // this wave's quarter: items (b*16 + r) with (b*16+r) % 4 == w
+  f32x16 dWsa[LIN ? P::WSB : 1];                                 // Linear shortcut: blocks (cb, b) with (cb*NB2 + b) % 4 == w
   if (BWD) {
 #pragma unroll
     for (int cb = 0; cb < NBX; ++cb)
@@ -152,6 +165,10 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
       for (int r = 0; r < 16; ++r) dg1a[t][r] = dbe1a[t][r] = db1a[t][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < NB2 * 4; ++i) dg2a[i] = dbe2a[i] = db2a[i] = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < (LIN ? P::WSB : 1); ++jb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dWsa[jb][q] = 0.f;
   }
 
   // ---- this wave's weight operands never change: they stay in registers for the whole kernel ----
@@ -189,6 +206,17 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
 #pragma unroll
           for (int d = 0; d < 4; ++d) wA1T[t][cb][4 * r4 + d] = tv[d];
         }
+    }
+  }
+
+  // Linear shortcut (forward): this wave's slice of Ws^T, output block sc_b, reduction steps [sc_p*SPW, +SPW)
+  const int sc_b = w % NB2, sc_p = w / NB2;
+  float wS[LIN ? P::SPW : 1];
+  if (!BWD && LIN) {
+#pragma unroll
+    for (int i = 0; i < P::SPW; ++i) {
+      const int sI = sc_p * P::SPW + i;
+      wS[i] = a.packed[P::OFF_PS + ((sc_b * (KS1 / 4) + (sI >> 2)) * 64 + lane) * 4 + (sI & 3)];
     }
   }
 
@@ -260,6 +288,23 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
       for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < KS1; ++s) acc1[t] = mfma(wA1[t][s], x[s], acc1[t]);
+    }
+    if (!BWD && LIN) {  // Linear shortcut partial: Os^T[block sc_b] over this wave's reduction steps
+      f32x16 osc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) osc[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < P::SPW; ++i) {
+        // x[sc_p * SPW + i]: the index is wave-uniform but not a constant -> select over the (few) parts
+        float xv = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < P::PARTS; ++pp) xv = (sc_p == pp) ? x[pp * P::SPW + i] : xv;
+        osc = mfma(wS[i], xv, osc);
+      }
+      const float* tsb = a.packed + P::OFF_TS + sc_b * 32 + h * 16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tS[(sc_p * CO + 32 * sc_b + sigma(r, h)) * kPitch + e] = osc[r] + (sc_p == 0 ? tsb[r] : 0.f);
     }
     // x is consumed: next tile's rows, and the ids of the tile after it
     v_cur = v_nxt; q_cur = q_nxt; j_cur = j_nxt;
@@ -370,7 +415,14 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
           if (((b * 16 + r) & 3) == w) {
             const int ch = 32 * b + sigma(r, h);
             const float* t2 = tab + (P::NB1 + b) * 96 + h * 16;
-            tB[ch * kPitch + e] = xh2[b][r] * t2[32 + r] + t2[64 + r] + (ch < EIN ? tX[ch * kPitch + e] : 0.f);
+            float sc = 0.f;
+            if (LIN) {
+#pragma unroll
+              for (int pp = 0; pp < P::PARTS; ++pp) sc += tS[(pp * CO + ch) * kPitch + e];
+            } else if (ch < EIN) {
+              sc = tX[ch * kPitch + e];
+            }
+            tB[ch * kPitch + e] = xh2[b][r] * t2[32 + r] + t2[64 + r] + sc;
           }
       __syncthreads();  // 3: tB
       for (int i = tid; i < nq * CO; i += 256) {
@@ -413,6 +465,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
             dbe2a[i] += dy[b][r];
             db2a[i] += dOpre[b][r];
             tB[(32 * b + sigma(r, h)) * kPitch + e] = dOpre[b][r];
+            if (LIN) tD[(32 * b + sigma(r, h)) * kPitch + e] = dy[b][r];
           }
         }
     }
@@ -515,6 +568,18 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
           }
         }
       }
+      if (LIN) {  // + Ws dy: the (cb, b) blocks are spread over the waves, the partial-tile sum adds them up
+#pragma unroll
+        for (int b = 0; b < NB2; ++b)
+          if (((cb * NB2 + b) & 3) == w) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const f32x4 av = pk4[P::OFF_PST / 4 + ((cb * NB2 + b) * 4 + r4) * 64 + lane];
+#pragma unroll
+              for (int d = 0; d < 4; ++d) dx = mfma(av[d], dy[b][4 * r4 + d], dx);
+            }
+          }
+      }
       f32x4* pw = reinterpret_cast<f32x4*>(po) + ((w * NBP + cb) * 4) * 64 + lane;
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
@@ -534,7 +599,23 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
 #pragma unroll
           for (int d = 0; d < 4; ++d) dW1a[cb][t] = mfma(av[d], bv[d], dW1a[cb][t]);
         }
-    __syncthreads();  // 4: po (dX partials)
+    if (LIN) {  // dWs (this wave's blocks) += x^T dy
+#pragma unroll
+      for (int jb = 0; jb < P::WSB; ++jb) {
+        const int id = jb * kPcWaves + w;
+        if (id < NBX * NB2) {
+          const int cb = id / NB2, b = id - cb * NB2;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(tX + (32 * cb + e) * kPitch + 16 * h + 4 * s4);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(tD + (32 * b + e) * kPitch + 16 * h + 4 * s4);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dWsa[jb] = mfma(av[d], bv[d], dWsa[jb]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // 4: po (dX partials); tD is dead
 
     // ---- dX: sum the partials (+ dy through the identity shortcut), edge-major tile, then scatter ----
 #pragma unroll
@@ -549,7 +630,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
           for (int d = 0; d < 4; ++d) {
             const int r = 4 * r4 + d;
             float s = v[d];
-            if (cb < NB2) s += dy[cb < NB2 ? cb : 0][r];  // identity shortcut: output channel c is x channel c
+            if (!LIN && cb < NB2) s += dy[cb < NB2 ? cb : 0][r];  // identity shortcut: output channel c is x channel c
             dxt[e * (EIN + 1) + 32 * cb + sigma(r, h)] = s;
           }
         }
@@ -571,7 +652,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
 
   if (BWD) {
     // ---- this workgroup's parameter-gradient partials (every true element is written: the reduce kernel sums them) ----
-    float* base = a.partial + (int64_t)blockIdx.x * grad_floats(a.ein_t, a.hid_t, a.co_t);
+    float* base = a.partial + (int64_t)blockIdx.x * grad_floats(a.ein_t, a.hid_t, a.co_t, LIN);
     float* pW1 = base;
     float* pb1 = pW1 + (int64_t)a.hid_t * a.ein_t;
     float* pg1 = pb1 + a.hid_t;
@@ -580,6 +661,8 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
     float* pb2 = pW2 + (int64_t)a.co_t * a.hid_t;
     float* pg2 = pb2 + a.co_t;
     float* pbe2 = pg2 + a.co_t;
+    float* pWs = pbe2 + a.co_t;  // [co][ein], then dbs [co]  (Linear shortcut)
+    float* pbs = pWs + (int64_t)a.co_t * a.ein_t;
 #pragma unroll
     for (int t = 0; t < HB; ++t) {
       const int hid0 = 32 * (w * HB + t);
@@ -620,14 +703,30 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
             pg2[oc] = vg;
             pbe2[oc] = vb;
             pb2[oc] = vc;
+            if (LIN) pbs[oc] = vb;  // d bs = sum of dy = d LN2.bias
           }
         }
+    if (LIN) {
+#pragma unroll
+      for (int jb = 0; jb < P::WSB; ++jb) {
+        const int id = jb * kPcWaves + w;
+        if (id < NBX * NB2) {
+          const int cb = id / NB2, b = id - cb * NB2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {  // dWsa[jb][r] at lane (h, e): Ws grad (c = 32cb + sigma(r,h), out = 32b + e)
+            const int c = 32 * cb + sigma(r, h), oc = 32 * b + e;
+            if (c < a.ein_t && oc < a.co_t) pWs[(int64_t)oc * a.ein_t + c] = dWsa[jb][r];
+          }
+        }
+      }
+    }
   }
 }
 
 // packs the torch-layout parameters into the operand images of PC<EIN, HID, CO>
 struct PackArgs {
   const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2;  // w1 [hid][ein], w2 [co][hid]
+  const float *ws, *bs;                                  // Linear shortcut [co][ein] / bias, or NULL
   int ein_t, hid_t, co_t;
   float* packed;
 };
@@ -638,6 +737,7 @@ __global__ void pointconv_pack_kernel(const PackArgs p) {
   if (idx >= P::PACKED) return;
   auto W1 = [&](int c, int hid) { return (c < p.ein_t && hid < p.hid_t) ? p.w1[(int64_t)hid * p.ein_t + c] : 0.f; };
   auto W2 = [&](int hid, int oc) { return (hid < p.hid_t && oc < p.co_t) ? p.w2[(int64_t)oc * p.hid_t + hid] : 0.f; };
+  auto WS = [&](int c, int oc) { return (p.ws && c < p.ein_t && oc < p.co_t) ? p.ws[(int64_t)oc * p.ein_t + c] : 0.f; };
   float v = 0.f;
   if (idx < P::OFF_P2) {  // P1 [blk][s4][lane][4]
     const int d = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
@@ -664,12 +764,27 @@ __global__ void pointconv_pack_kernel(const PackArgs p) {
     const int ch = 32 * blk + sigma(r, hh);
     const float* src = which == 0 ? p.b1 : which == 1 ? p.g1 : p.be1;
     v = (ch < p.hid_t && src) ? src[ch] : 0.f;
-  } else {
+  } else if (idx < P::OFF_PS) {
     const int i2 = idx - P::OFF_T2;
     const int r = i2 & 15, hh = (i2 >> 4) & 1, which = (i2 >> 5) % 3, b = i2 / 96;
     const int ch = 32 * b + sigma(r, hh);
     const float* src = which == 0 ? p.b2 : which == 1 ? p.g2 : p.be2;
     v = (ch < p.co_t && src) ? src[ch] : 0.f;
+  } else if (idx < P::OFF_PST) {  // PS [b][s4][lane][4]
+    const int i2 = idx - P::OFF_PS;
+    const int d = i2 & 3, lane = (i2 >> 2) & 63, rest = i2 >> 8;
+    const int s4 = rest % (P::KS1 / 4), b = rest / (P::KS1 / 4);
+    v = WS((lane >> 5) * P::KS1 + 4 * s4 + d, 32 * b + (lane & 31));
+  } else if (idx < P::OFF_TS) {  // PST [cb][b][r4][lane][4]
+    const int i2 = idx - P::OFF_PST;
+    const int d = i2 & 3, lane = (i2 >> 2) & 63, r4 = (i2 >> 8) & 3, rest = i2 >> 10;
+    const int b = rest % P::NB2, cb = rest / P::NB2;
+    v = WS(32 * cb + (lane & 31), 32 * b + sigma(4 * r4 + d, lane >> 5));
+  } else {  // TS [b][2][16]
+    const int i2 = idx - P::OFF_TS;
+    const int r = i2 & 15, hh = (i2 >> 4) & 1, b = i2 >> 5;
+    const int ch = 32 * b + sigma(r, hh);
+    v = (ch < p.co_t && p.bs) ? p.bs[ch] : 0.f;
   }
   p.packed[idx] = v;
 }
@@ -701,18 +816,23 @@ int bwd_grid(int64_t n_query, int k) {
   return (int)(tiles < 256 ? tiles : 256);  // one persistent workgroup per CU
 }
 
-template <int EIN, int HID, int CO, bool BWD>
-int launch_edge(const PcArgs& a, int grid, hipStream_t s) {
+template <int EIN, int HID, int CO, bool BWD, bool LIN>
+int launch_edge_lin(const PcArgs& a, int grid, hipStream_t s) {
   typedef PC<EIN, HID, CO> P;
   static unsigned long long attr_done = 0ull;
   const int rc = once_per_device(attr_done, [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_edge_kernel<EIN, HID, CO, BWD>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_edge_kernel<EIN, HID, CO, BWD, LIN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (BWD ? P::LDS_FLOATS : P::LDS_FLOATS_FWD) * 4) == hipSuccess;
   });
   if (rc != WCN_SUCCESS) return rc;
-  hipLaunchKernelGGL((pointconv_edge_kernel<EIN, HID, CO, BWD>), dim3(grid), dim3(256),
+  hipLaunchKernelGGL((pointconv_edge_kernel<EIN, HID, CO, BWD, LIN>), dim3(grid), dim3(256),
                      (BWD ? P::LDS_FLOATS : P::LDS_FLOATS_FWD) * 4, s, a);
   return launch_status();
+}
+
+template <int EIN, int HID, int CO, bool BWD>
+int launch_edge(const PcArgs& a, int grid, hipStream_t s) {
+  return a.lin_sc ? launch_edge_lin<EIN, HID, CO, BWD, true>(a, grid, s) : launch_edge_lin<EIN, HID, CO, BWD, false>(a, grid, s);
 }
 
 }  // namespace
@@ -722,9 +842,10 @@ using namespace wcn;
 
 extern "C" {
 
-int wcn_pointconv_supported(int32_t cin, int32_t cq, int32_t nrel, int32_t hidden, int32_t cout, int32_t k) {
+int wcn_pointconv_supported(int32_t cin, int32_t cq, int32_t nrel, int32_t hidden, int32_t cout, int32_t k,
+                            int32_t linear_shortcut) {
   if (cin < 1 || cq < 0 || (nrel != 0 && nrel != 3) || hidden < 1 || cout < 1) return 0;
-  if (cin + cq + nrel != cout) return 0;  // identity shortcut only (mlp.py:141: Linear shortcut when the widths differ)
+  if (!linear_shortcut && cin + cq + nrel != cout) return 0;  // identity shortcut needs equal widths (mlp.py:141)
   return (log2_exact(k) >= 0 && pick_shape(cin + cq + nrel, hidden, cout) >= 0) ? 1 : 0;
 }
 
@@ -735,17 +856,20 @@ int64_t wcn_pointconv_packed_floats(int32_t ein, int32_t hidden, int32_t cout) {
   }
 }
 
-int64_t wcn_pointconv_grad_floats(int32_t ein, int32_t hidden, int32_t cout) { return grad_floats(ein, hidden, cout); }
+int64_t wcn_pointconv_grad_floats(int32_t ein, int32_t hidden, int32_t cout, int32_t linear_shortcut) {
+  return grad_floats(ein, hidden, cout, linear_shortcut);
+}
 
-size_t wcn_pointconv_backward_workspace(int64_t n_query, int32_t k, int32_t ein, int32_t hidden, int32_t cout) {
-  return (size_t)bwd_grid(n_query, k) * (size_t)grad_floats(ein, hidden, cout) * sizeof(float);
+size_t wcn_pointconv_backward_workspace(int64_t n_query, int32_t k, int32_t ein, int32_t hidden, int32_t cout,
+                                        int32_t linear_shortcut) {
+  return (size_t)bwd_grid(n_query, k) * (size_t)grad_floats(ein, hidden, cout, linear_shortcut) * sizeof(float);
 }
 
 int wcn_pointconv_pack(const float* w1, const float* b1, const float* g1, const float* be1, const float* w2,
-                       const float* b2, const float* g2, const float* be2, int32_t ein, int32_t hidden, int32_t cout,
-                       float* packed, void* stream) {
+                       const float* b2, const float* g2, const float* be2, const float* ws, const float* bs, int32_t ein,
+                       int32_t hidden, int32_t cout, float* packed, void* stream) {
   if (!w1 || !w2 || !packed) return WCN_ERROR_INVALID_PARAMETERS;
-  const PackArgs p{w1, b1, g1, be1, w2, b2, g2, be2, ein, hidden, cout, packed};
+  const PackArgs p{w1, b1, g1, be1, w2, b2, g2, be2, ws, bs, ein, hidden, cout, packed};
   hipStream_t s = (hipStream_t)stream;
   switch (pick_shape(ein, hidden, cout)) {
     case 0:
@@ -758,25 +882,26 @@ int wcn_pointconv_pack(const float* w1, const float* b1, const float* g1, const 
 
 static int fill_args(PcArgs& a, const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
                      const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
-                     const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean) {
-  if (!wcn_pointconv_supported(cin, cq, nrel, hidden, cout, k)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+                     const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
+                     int32_t linear_shortcut) {
+  if (!wcn_pointconv_supported(cin, cq, nrel, hidden, cout, k, linear_shortcut)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   if (!in_feats || (cq > 0 && !q_feats) || !nbr || !packed || (nrel && (!in_xyz || !q_xyz)) || n_query < 0)
     return WCN_ERROR_INVALID_PARAMETERS;
   a = PcArgs{};
   a.in_feats = in_feats; a.q_feats = q_feats; a.in_xyz = in_xyz; a.q_xyz = q_xyz; a.nbr = nbr;
   a.n_query = n_query; a.log2k = log2_exact(k); a.cin = cin; a.cq = cq; a.nrel = nrel;
   a.packed = packed; a.ein_t = cin + cq + nrel; a.hid_t = hidden; a.co_t = cout;
-  a.eps1 = eps1; a.eps2 = eps2; a.scale = mean ? 1.f / (float)k : 1.f;
+  a.eps1 = eps1; a.eps2 = eps2; a.scale = mean ? 1.f / (float)k : 1.f; a.lin_sc = linear_shortcut ? 1 : 0;
   return WCN_SUCCESS;
 }
 
 int wcn_pointconv_edge_forward(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
                                const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
                                const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
-                               float* out, void* stream) {
+                               int32_t linear_shortcut, float* out, void* stream) {
   PcArgs a;
   const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, k, cin, cq, nrel, packed, hidden, cout, eps1,
-                           eps2, mean);
+                           eps2, mean, linear_shortcut);
   if (rc != WCN_SUCCESS) return rc;
   if (!out) return WCN_ERROR_INVALID_PARAMETERS;
   if (n_query == 0) return WCN_SUCCESS;
@@ -792,17 +917,17 @@ int wcn_pointconv_edge_forward(const float* in_feats, const float* q_feats, cons
 int wcn_pointconv_edge_backward(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
                                 const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
                                 const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
-                                const float* grad_out, float* d_in, float* d_q, float* d_params, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                int32_t linear_shortcut, const float* grad_out, float* d_in, float* d_q, float* d_params,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   PcArgs a;
   const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, k, cin, cq, nrel, packed, hidden, cout, eps1,
-                           eps2, mean);
+                           eps2, mean, linear_shortcut);
   if (rc != WCN_SUCCESS) return rc;
   if (!grad_out || !d_in || (cq > 0 && !d_q) || !d_params || !workspace ||
-      workspace_bytes < wcn_pointconv_backward_workspace(n_query, k, a.ein_t, hidden, cout))
+      workspace_bytes < wcn_pointconv_backward_workspace(n_query, k, a.ein_t, hidden, cout, linear_shortcut))
     return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t gf = grad_floats(a.ein_t, hidden, cout);
+  const int64_t gf = grad_floats(a.ein_t, hidden, cout, a.lin_sc);
   if (n_query == 0) return hipMemsetAsync(d_params, 0, gf * sizeof(float), s) == hipSuccess ? WCN_SUCCESS : WCN_ERROR_KERNEL_EXECUTION;
   a.grad_out = grad_out; a.d_in = d_in; a.d_q = d_q; a.partial = (float*)workspace;
   const int grid = bwd_grid(n_query, k);

@@ -2,8 +2,8 @@
 
 Takes the place of the op sequence in the reference's ``PointConv.forward``
 (`warpconvnet/nn/modules/point_conv.py:231-273`: ``features[neighbors]`` / ``repeat_interleave`` / ``cat`` ->
-``edge_transform_mlp`` -> ``row_reduction``) when the edge MLP is the default ``MLPBlock`` with an identity shortcut
-(`warpconvnet/nn/modules/mlp.py:124-177`), the neighbour lists have a uniform power-of-two length (kNN) and the reduction
+``edge_transform_mlp`` -> ``row_reduction``) when the edge MLP is the default ``MLPBlock`` (identity or Linear shortcut,
+`warpconvnet/nn/modules/mlp.py:124-177`), the neighbour lists have a uniform power-of-two length (kNN) and the reduction
 is ``mean`` or ``sum``.  Forward and backward are single HIP kernels; no ``[M*k, C]`` tensor exists in HBM.
 """
 import os
@@ -19,9 +19,9 @@ _ENABLED = os.environ.get("WARPCONVNET_AMD_POINTCONV_FUSED", "1") != "0"
 
 
 def _mlp_parts(mlp: nn.Module):
-    """(lin1, ln1, lin2, ln2) of a default MLPBlock with ReLU and identity shortcut, else None."""
+    """(lin1, ln1, lin2, ln2, shortcut Linear or None) of a default MLPBlock with ReLU, else None."""
     block, shortcut = getattr(mlp, "block", None), getattr(mlp, "shortcut", None)
-    if not isinstance(block, nn.Sequential) or len(block) != 5 or not isinstance(shortcut, nn.Identity):
+    if not isinstance(block, nn.Sequential) or len(block) != 5 or not isinstance(shortcut, (nn.Identity, nn.Linear)):
         return None
     lin1, ln1, act, lin2, ln2 = block
     if not (isinstance(lin1, nn.Linear) and isinstance(ln1, nn.LayerNorm) and type(act) is nn.ReLU
@@ -29,7 +29,7 @@ def _mlp_parts(mlp: nn.Module):
         return None
     if not (ln1.elementwise_affine and ln2.elementwise_affine):
         return None
-    return lin1, ln1, lin2, ln2
+    return lin1, ln1, lin2, ln2, (shortcut if isinstance(shortcut, nn.Linear) else None)
 
 
 def fused_edge_supported(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nrel: int, k: int, reduction: str) -> bool:
@@ -38,17 +38,18 @@ def fused_edge_supported(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nrel
     parts = _mlp_parts(mlp)
     if parts is None:
         return False
-    lin1, _, lin2, _ = parts
+    lin1, _, lin2, _, sc = parts
     cin, cq = in_feats.shape[1], q_feats.shape[1]
     if lin1.in_features != cin + cq + nrel or lin1.weight.dtype != torch.float32:
         return False
-    return bool(_lib.lib().wcn_pointconv_supported(cin, cq, nrel, lin1.out_features, lin2.out_features, k))
+    return bool(_lib.lib().wcn_pointconv_supported(cin, cq, nrel, lin1.out_features, lin2.out_features, k, int(sc is not None)))
 
 
 def _packed_params(mlp: nn.Module, parts) -> Tensor:
     """Operand images of the edge MLP, cached on the module per parameter version."""
-    lin1, ln1, lin2, ln2 = parts
-    ps = (lin1.weight, lin1.bias, ln1.weight, ln1.bias, lin2.weight, lin2.bias, ln2.weight, ln2.bias)
+    lin1, ln1, lin2, ln2, sc = parts
+    ps = (lin1.weight, lin1.bias, ln1.weight, ln1.bias, lin2.weight, lin2.bias, ln2.weight, ln2.bias,
+          sc.weight if sc is not None else None, sc.bias if sc is not None else None)
     key = tuple((p.data_ptr(), p._version) if p is not None else None for p in ps)
     hit = getattr(mlp, "_wcn_pc_packed", None)
     if hit is not None and hit[0] == key:
@@ -66,39 +67,41 @@ def _packed_params(mlp: nn.Module, parts) -> Tensor:
 
 class _FusedEdge(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, in_feats, q_feats, w1, b1, g1, be1, w2, b2, g2, be2, packed, in_xyz, q_xyz, nbr, k, eps1, eps2, mean):
+    def forward(ctx, in_feats, q_feats, w1, b1, g1, be1, w2, b2, g2, be2, ws, bs, packed, in_xyz, q_xyz, nbr, k, eps1, eps2,
+                mean):
         L = _lib.lib()
         dev = in_feats.device
         in_feats, q_feats = in_feats.contiguous(), q_feats.contiguous()
         M, cin, cq = q_feats.shape[0], in_feats.shape[1], q_feats.shape[1]
         nrel = 0 if in_xyz is None else 3
         hid, co = w1.shape[0], w2.shape[0]
+        lin = int(ws is not None)
         out = torch.empty(M, co, dtype=torch.float32, device=dev)
         _lib.check(L.wcn_pointconv_edge_forward(
             _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
-            _lib.ptr(packed), hid, co, eps1, eps2, int(mean), _lib.ptr(out), _lib.stream_handle(dev)),
+            _lib.ptr(packed), hid, co, eps1, eps2, int(mean), lin, _lib.ptr(out), _lib.stream_handle(dev)),
             "wcn_pointconv_edge_forward")
         ctx.save_for_backward(in_feats, q_feats, packed, in_xyz, q_xyz, nbr)
-        ctx.dims = (M, k, cin, cq, nrel, hid, co, eps1, eps2, int(mean))
-        ctx.has = (b1 is not None, b2 is not None)
+        ctx.dims = (M, k, cin, cq, nrel, hid, co, eps1, eps2, int(mean), lin)
+        ctx.has = (b1 is not None, b2 is not None, bs is not None)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         L = _lib.lib()
         in_feats, q_feats, packed, in_xyz, q_xyz, nbr = ctx.saved_tensors
-        M, k, cin, cq, nrel, hid, co, eps1, eps2, mean = ctx.dims
+        M, k, cin, cq, nrel, hid, co, eps1, eps2, mean, lin = ctx.dims
         dev = in_feats.device
         ein = cin + cq + nrel
         grad_out = grad_out.contiguous().float()
         d_in = torch.zeros_like(in_feats)
         d_q = torch.empty_like(q_feats)
-        grads = torch.empty(L.wcn_pointconv_grad_floats(ein, hid, co), dtype=torch.float32, device=dev)
-        ws_bytes = L.wcn_pointconv_backward_workspace(M, k, ein, hid, co)
+        grads = torch.empty(L.wcn_pointconv_grad_floats(ein, hid, co, lin), dtype=torch.float32, device=dev)
+        ws_bytes = L.wcn_pointconv_backward_workspace(M, k, ein, hid, co, lin)
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
         _lib.check(L.wcn_pointconv_edge_backward(
             _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
-            _lib.ptr(packed), hid, co, eps1, eps2, mean, _lib.ptr(grad_out), _lib.ptr(d_in), _lib.ptr(d_q), _lib.ptr(grads),
+            _lib.ptr(packed), hid, co, eps1, eps2, mean, lin, _lib.ptr(grad_out), _lib.ptr(d_in), _lib.ptr(d_q), _lib.ptr(grads),
             _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)), "wcn_pointconv_edge_backward")
         o = 0
 
@@ -110,9 +113,12 @@ class _FusedEdge(torch.autograd.Function):
 
         dw1, db1, dg1, dbe1 = take(hid * ein, (hid, ein)), take(hid, (hid,)), take(hid, (hid,)), take(hid, (hid,))
         dw2, db2, dg2, dbe2 = take(co * hid, (co, hid)), take(co, (co,)), take(co, (co,)), take(co, (co,))
-        has_b1, has_b2 = ctx.has
+        dws = dbs = None
+        if lin:
+            dws, dbs = take(co * ein, (co, ein)), take(co, (co,))
+        has_b1, has_b2, has_bs = ctx.has
         return (d_in, d_q, dw1, db1 if has_b1 else None, dg1, dbe1, dw2, db2 if has_b2 else None, dg2, dbe2,
-                None, None, None, None, None, None, None, None)
+                dws, dbs if has_bs else None, None, None, None, None, None, None, None, None)
 
 
 def fused_point_conv_edge(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nbr: Tensor, k: int, reduction: str,
@@ -121,11 +127,12 @@ def fused_point_conv_edge(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nbr
     for ``nbr`` [M, k] / [M*k] row indices into ``in_feats``; fp32."""
     parts = _mlp_parts(mlp)
     assert parts is not None, "fused_point_conv_edge needs the default MLPBlock (see fused_edge_supported)"
-    lin1, ln1, lin2, ln2 = parts
+    lin1, ln1, lin2, ln2, sc = parts
     packed = _packed_params(mlp, parts)
     nbr32 = nbr.reshape(-1).to(torch.int32).contiguous()
     if in_xyz is not None:
         in_xyz, q_xyz = in_xyz.float().contiguous(), q_xyz.float().contiguous()
     return _FusedEdge.apply(in_feats.float(), q_feats.float(), lin1.weight, lin1.bias, ln1.weight, ln1.bias, lin2.weight,
-                            lin2.bias, ln2.weight, ln2.bias, packed, in_xyz, q_xyz, nbr32, int(k), float(ln1.eps),
+                            lin2.bias, ln2.weight, ln2.bias, sc.weight if sc is not None else None,
+                            sc.bias if sc is not None else None, packed, in_xyz, q_xyz, nbr32, int(k), float(ln1.eps),
                             float(ln2.eps), reduction == "mean")

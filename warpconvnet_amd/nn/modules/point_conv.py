@@ -118,7 +118,7 @@ class PointConv(BaseSpatialModule):
 
     def _fused_edge(self, in_pc: Points, query_pc: Points, neighbors):
         """gather -> edge MLP -> reduction as ONE HIP kernel (`nn/functional/point_conv.py`) when the configuration allows it:
-        kNN lists of uniform power-of-two length, default edge MLP with identity shortcut, one mean / sum reduction, no
+        kNN lists of uniform power-of-two length, default edge MLP (identity or Linear shortcut), one mean / sum reduction, no
         sinusoidal encoding.  None = take the composed path below (same result, edge tensors in HBM)."""
         nidx = neighbors.neighbor_indices
         if nidx.ndim != 2 or len(self.reductions) != 1 or self.use_rel_pos_encode:
