@@ -308,3 +308,32 @@ def test_pointconv_fused_edge_kernel_vs_fp64(n, cin, cout, k, red, rel):
         scale = float(pr.grad.abs().max()) + 1e-12
         err = float((p.grad.cpu().double() - pr.grad).abs().max()) / scale
         assert err < 1e-3, f"{name}: relative max error {err:.2e}"
+
+
+@pytest.mark.parametrize("m,cin,cout,hid", [(5000, 64, 64, 128), (777, 16, 32, 48), (33, 7, 5, 9)])
+def test_mlp_block_one_kernel_vs_fp64(m, cin, cout, hid):
+    """MLPBlock on a plain [M, C] fp32 tensor runs as the edge kernel with k = 1 (identity and Linear shortcut)."""
+    import copy
+
+    from warpconvnet_amd.nn.functional import point_conv as fpc
+    from warpconvnet_amd.nn.modules.mlp import MLPBlock
+
+    dev = _dev()
+    torch.manual_seed(m)
+    mlp = MLPBlock(cin, cout, hid)
+    ref = copy.deepcopy(mlp).double()
+    mlp = mlp.to(dev)
+    x = torch.randn(m, cin)
+    xg = x.to(dev).requires_grad_(True)
+    assert fpc.fused_mlp_block_supported(mlp, xg)
+    y = mlp(xg)
+    dy = torch.randn(m, cout)
+    y.backward(dy.to(dev))
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double())
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=1e-4, atol=1e-4)
+    assert float((xg.grad.cpu().double() - xr.grad).norm() / xr.grad.norm()) < 1e-3
+    for (name, p), (_, pr) in zip(mlp.named_parameters(), ref.named_parameters()):
+        err = float((p.grad.cpu().double() - pr.grad).abs().max()) / (float(pr.grad.abs().max()) + 1e-12)
+        assert err < 1e-3, f"{name}: relative max error {err:.2e}"

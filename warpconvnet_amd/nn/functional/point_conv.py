@@ -136,3 +136,26 @@ def fused_point_conv_edge(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nbr
                             lin2.bias, ln2.weight, ln2.bias, sc.weight if sc is not None else None,
                             sc.bias if sc is not None else None, packed, in_xyz, q_xyz, nbr32, int(k), float(ln1.eps),
                             float(ln2.eps), reduction == "mean")
+
+
+_ARANGE = {}
+
+
+def fused_mlp_block_supported(mlp: nn.Module, x: Tensor) -> bool:
+    """A default ``MLPBlock`` on a plain [M, C] fp32 CUDA tensor = the edge pipeline with one "neighbour" per row."""
+    if x.ndim != 2 or x.dtype != torch.float32 or torch.is_autocast_enabled():
+        return False
+    return fused_edge_supported(mlp, x, x[:, :0], 0, 1, "sum")
+
+
+def fused_mlp_block(mlp: nn.Module, x: Tensor) -> Tensor:
+    """``mlp.block(x) + mlp.shortcut(x)`` (reference `warpconvnet/nn/modules/mlp.py:165-169`) in one kernel per direction:
+    the PointConv edge kernel with k = 1, no query features and the identity neighbour list."""
+    M = x.shape[0]
+    key = (M, x.device)
+    nbr = _ARANGE.get(key)
+    if nbr is None:
+        if len(_ARANGE) > 8:
+            _ARANGE.clear()
+        nbr = _ARANGE[key] = torch.arange(M, dtype=torch.int32, device=x.device)
+    return fused_point_conv_edge(mlp, x, x.new_empty((M, 0)), nbr, 1, "sum")

@@ -1,11 +1,14 @@
 """``MLPBlock``: Linear - LayerNorm - activation - Linear - LayerNorm plus a (projected) shortcut
-(reference `warpconvnet/nn/modules/mlp.py:124-177`).  The linears are plain library GEMMs (hipBLASLt through torch)."""
+(reference `warpconvnet/nn/modules/mlp.py:124-177`).  On fp32 CUDA features whose widths fit (in <= 64, hidden <= 128, out <= 64)
+the whole block runs as one HIP kernel per direction (the PointConv edge kernel with one row per "edge"); otherwise the
+linears are library GEMMs."""
 from typing import Union
 
 import torch.nn as nn
 from torch import Tensor
 
 from warpconvnet_amd.geometry.base.geometry import Geometry
+from warpconvnet_amd.nn.functional.point_conv import fused_mlp_block, fused_mlp_block_supported
 from warpconvnet_amd.nn.modules.base_module import BaseSpatialModule
 
 
@@ -26,6 +29,8 @@ class MLPBlock(BaseSpatialModule):
         self.shortcut = nn.Linear(in_channels, out_channels, bias=bias) if in_channels != out_channels else nn.Identity()
 
     def _forward_feature(self, x: Tensor) -> Tensor:
+        if x.is_cuda and fused_mlp_block_supported(self, x):  # one HIP kernel per direction (csrc/pointconv.hip, k = 1)
+            return fused_mlp_block(self, x)
         return self.block(x) + self.shortcut(x)
 
     def forward(self, x: Union[Tensor, Geometry]):
