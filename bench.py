@@ -109,7 +109,8 @@ def cpu_baseline(n_sample, seed):
 def secondary_configs(dev):
     """BASELINE configs 3 and 5 as secondary figures of the same run (never the headline): MinkUNet-14 forward + backward
     on surface scenes of 200 k and 1 M voxels, and PointConv(32->64, kNN 16) on 200 k points followed by voxelisation and
-    a depthwise k=3 convolution, forward + backward.  Milliseconds per iteration (HIP events, 3 warm-up + 5 timed)."""
+    a depthwise k=3 convolution, forward + backward (with the one-kernel edge pipeline, and composed from separate kernels).
+    Milliseconds per iteration (HIP events, 3 warm-up + 5 timed)."""
     from tests.minkunet14 import MinkUNet14
     from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
     from warpconvnet_amd.geometry.types.points import Points
@@ -150,6 +151,13 @@ def secondary_configs(dev):
 
     out["pointconv_dw_ms"] = round(time_events(point_step, 5, warmup=3), 3)
     out["pointconv_dw_points"] = n
+    # the same step with the edge pipeline composed from separate kernels (what the reference's op sequence costs here)
+    from warpconvnet_amd.nn.functional import point_conv as fpc
+    fpc._ENABLED = False
+    try:
+        out["pointconv_dw_composed_ms"] = round(time_events(point_step, 3, warmup=1), 3)
+    finally:
+        fpc._ENABLED = True
     return out
 
 
