@@ -375,6 +375,24 @@ int wcn_pointconv_edge_backward(const float* in_feats, const float* q_feats, con
                                 int32_t linear_shortcut, const float* grad_out, float* d_in, float* d_q, float* d_params,
                                 void* workspace, size_t workspace_bytes, wcn_stream_t stream);
 
+/* The same pipeline over RAGGED neighbour lists (radius search, warpconvnet/geometry/coords/search/radius.py): `nbr`
+ * [n_edges] = the lists of the queries behind each other, `edge_q` [n_edges] the query of every edge (non-decreasing, i.e.
+ * repeat_interleave(arange(n_query), list lengths)), `q_scale` [n_query] the reduction scale per query (1 / length for mean,
+ * NULL = sum).  `out` (forward) and `d_q` (backward) must be ZERO-FILLED by the caller: a list may straddle two 32-edge
+ * tiles, so list segments are added to their rows (hardware fp32 atomics).  Workspace: wcn_pointconv_backward_workspace
+ * (n_edges, 1, ...). */
+int wcn_pointconv_edge_forward_ragged(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                                      const int32_t* nbr, const int32_t* edge_q, const float* q_scale, int64_t n_edges,
+                                      int64_t n_query, int32_t cin, int32_t cq, int32_t nrel, const float* packed,
+                                      int32_t hidden, int32_t cout, float eps1, float eps2, int32_t linear_shortcut,
+                                      float* out, wcn_stream_t stream);
+int wcn_pointconv_edge_backward_ragged(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                                       const int32_t* nbr, const int32_t* edge_q, const float* q_scale, int64_t n_edges,
+                                       int64_t n_query, int32_t cin, int32_t cq, int32_t nrel, const float* packed,
+                                       int32_t hidden, int32_t cout, float eps1, float eps2, int32_t linear_shortcut,
+                                       const float* grad_out, float* d_in, float* d_q, float* d_params, void* workspace,
+                                       size_t workspace_bytes, wcn_stream_t stream);
+
 /* Sparse pooling over a kernel map (REDUCE_AND_STRIDE, SparsePool / SparseMaxPool / SparseUnpool): out[m][c] =
  * reduce over the present neighbours k of in[tbl[m][k]][c]; `tbl` is the row-major neighbour table [n_out][row pitch of
  * num_offsets] (-1 = absent) that wcn_kmap_probe / wcn_kmap_from_csr / wcn_kmap_reverse produce.  op: 0 sum, 1 mean,

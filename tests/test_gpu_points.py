@@ -337,3 +337,63 @@ def test_mlp_block_one_kernel_vs_fp64(m, cin, cout, hid):
     for (name, p), (_, pr) in zip(mlp.named_parameters(), ref.named_parameters()):
         err = float((p.grad.cpu().double() - pr.grad).abs().max()) / (float(pr.grad.abs().max()) + 1e-12)
         assert err < 1e-3, f"{name}: relative max error {err:.2e}"
+
+
+@pytest.mark.parametrize("n,cin,cout,mode,arg,red,rel", [(3000, 32, 64, "radius", 0.45, "mean", False),
+                                                         (2000, 16, 32, "radius", 0.6, "sum", False),
+                                                         (2500, 24, 64, "radius", 0.5, "mean", True),
+                                                         (1800, 32, 64, "knn", 20, "mean", False),
+                                                         (900, 8, 16, "radius", 0.05, "mean", False)])
+def test_pointconv_fused_edge_kernel_ragged_lists_vs_fp64(n, cin, cout, mode, arg, red, rel):
+    """Ragged neighbour lists (radius search; kNN with a list length that is not a power of two; queries with empty lists)
+    through the one-pass edge pipeline: list segments that straddle 32-edge tiles are added to their rows."""
+    import copy
+
+    from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
+    from warpconvnet_amd.geometry.types.points import Points
+    from warpconvnet_amd.nn.functional import point_conv as fpc
+    from warpconvnet_amd.nn.modules import PointConv
+    from warpconvnet_amd.ops.reductions import row_reduction
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(n)
+    coords = torch.rand(n, 3, generator=g) * 4.0
+    feats = torch.randn(n, cin, generator=g)
+    cfg = RealSearchConfig(mode="radius", radius=arg) if mode == "radius" else RealSearchConfig(mode="knn", knn_k=arg)
+    torch.manual_seed(2)
+    conv = PointConv(cin, cout, cfg, reductions=(red,), use_rel_pos=rel)
+    ref = copy.deepcopy(conv).double()
+    conv = conv.to(dev)
+    x = feats.to(dev).requires_grad_(True)
+    pc = Points(coords.to(dev), x, offsets=torch.tensor([0, n // 2, n]))
+    nb = pc.neighbors(query_coords=pc.batched_coordinates, search_args=cfg)
+    calls = []
+    orig = fpc._FusedEdge.apply
+    fpc._FusedEdge.apply = lambda *a: (calls.append(a[-2] is not None), orig(*a))[1]
+    try:
+        out = conv(pc).feature_tensor
+    finally:
+        fpc._FusedEdge.apply = orig
+    assert calls and calls[0], "the ragged form of the fused edge kernel was not used"
+    dy = torch.randn(n, cout, generator=g)
+    out.backward(dy.to(dev))
+
+    idx = nb.neighbor_indices.cpu().view(-1)
+    splits = nb.neighbor_row_splits.cpu()
+    counts = splits[1:] - splits[:-1]
+    if mode == "radius" and arg < 0.1:
+        assert (counts <= 1).any()  # (nearly) empty lists are part of the case
+    xr = feats.double().requires_grad_(True)
+    edge = [xr[idx], xr.repeat_interleave(counts, dim=0)]
+    if rel:
+        edge.append((coords[idx] - coords.repeat_interleave(counts, dim=0)).double())
+    e = ref.edge_transform_mlp(torch.cat(edge, 1))
+    want = ref.out_transform_mlp(row_reduction(e, splits, reduction=red))
+    want.backward(dy.double())
+    torch.testing.assert_close(out.detach().cpu().double(), want.detach(), rtol=1e-4, atol=1e-4)
+    got, wantg = x.grad.cpu().double(), xr.grad
+    bad = (got - wantg).abs() > 1e-4 + 1e-3 * wantg.abs()
+    assert bad.double().mean() < 2e-3 and float((got - wantg).norm() / wantg.norm()) < 1e-3
+    for (name, p), (_, pr) in zip(conv.named_parameters(), ref.named_parameters()):
+        err = float((p.grad.cpu().double() - pr.grad).abs().max()) / (float(pr.grad.abs().max()) + 1e-12)
+        assert err < 1e-3, f"{name}: relative max error {err:.2e}"

@@ -77,9 +77,9 @@ struct PC {
   static constexpr int L_ST = L_PO + kPcWaves * NBP * 1024;   // [2][4][32][2]      LayerNorm partial sums
   static constexpr int L_DXT = L_ST + 2 * kPcWaves * 64;      // [32][EIN+1]        dX, edge-major; before that dy channel-major [CO][kPitch]
   static constexpr int DXT_FLOATS = ((32 * (EIN + 1) > CO * kPitch ? 32 * (EIN + 1) : CO * kPitch) + 3) & ~3;
-  static constexpr int L_DOUT = L_DXT + DXT_FLOATS;           // [32][CO]           grad_out rows of the tile's queries
-  static constexpr int L_JT = L_DOUT + 32 * CO;               // [32] int           neighbour ids
-  static constexpr int L_WT = L_JT + 32;                      // [HID*CO + EIN*HID]  backward: P2T | P1T operand images
+  static constexpr int L_DOUT = L_DXT + DXT_FLOATS;           // [32][CO] grad_out rows of the tile's queries ([32][CO+1] per edge when ragged)
+  static constexpr int L_JT = L_DOUT + 32 * (CO + 1);         // [32] int           neighbour ids, then [32] int query ids (ragged lists)
+  static constexpr int L_WT = L_JT + 64;                      // [HID*CO + EIN*HID]  backward: P2T | P1T operand images
   static constexpr int LDS_FLOATS = L_WT + HID * CO + EIN * HID;
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
   static constexpr int LDS_FLOATS_FWD = L_DXT - HID * kPitch + PARTS * CO * kPitch;  // forward: ... + shortcut partial tiles
@@ -97,6 +97,11 @@ struct PcArgs {
   int32_t ein_t, hid_t, co_t;  // true channel counts
   float eps1, eps2, scale;     // scale: 1 (sum) or 1/k (mean)
   int32_t lin_sc;              // 0: identity shortcut (ein == cout), 1: Linear shortcut
+  // ragged neighbour lists (radius search): query id of every edge, per-query reduction scale (1 / count for mean, NULL = 1),
+  // number of edges; edge_q == NULL: uniform lists of 1 << log2k edges
+  const int32_t* edge_q;
+  const float* q_scale;
+  int64_t n_edges;
   float* out;                  // forward:  [n_query][co_t]
   const float* grad_out;       // backward: [n_query][co_t]
   float* d_in;                 //           [n_in][cin], zero-filled by the caller (accumulated with atomics)
@@ -110,7 +115,7 @@ __host__ __device__ inline int64_t grad_floats(int ein_t, int hid_t, int co_t, i
   return (int64_t)hid_t * ein_t + 3 * hid_t + (int64_t)co_t * hid_t + 3 * co_t + (lin_sc ? (int64_t)co_t * ein_t + co_t : 0);
 }
 
-template <int EIN, int HID, int CO, bool BWD, bool LIN>
+template <int EIN, int HID, int CO, bool BWD, bool LIN, bool RAG>
 __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const PcArgs a) {
   typedef PC<EIN, HID, CO> P;
   constexpr int KS1 = P::KS1, HB = P::HB, NB2 = P::NB2, NBX = P::NBX, NBP = P::NBP;
@@ -125,10 +130,12 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
   float* tS = smem + P::L_DXT - HID * kPitch;                         // forward: [PARTS][CO][kPitch] shortcut partial tiles
   float* dout = smem + P::L_DOUT;
   int32_t* jt = reinterpret_cast<int32_t*>(smem + P::L_JT);
+  int32_t* qt = BWD ? jt + 32 : reinterpret_cast<int32_t*>(smem + P::L_ST - HID * kPitch + 256);  // forward: the unused half of st
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, e = lane & 31;
   const int k = 1 << a.log2k, nq = 32 >> a.log2k;
-  const int64_t n_edges = a.n_query << a.log2k;
+  constexpr bool ragged = RAG;  // neighbour lists of any length (per-edge query ids) instead of uniform 1 << log2k
+  const int64_t n_edges = ragged ? a.n_edges : (a.n_query << a.log2k);
   const int64_t ntiles = (n_edges + 31) >> 5;
   const float inv_hid = 1.f / (float)a.hid_t, inv_co = 1.f / (float)a.co_t;
   const f32x4* pk4 = reinterpret_cast<const f32x4*>(a.packed);
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
   auto load_ids = [&](int64_t tile, bool& valid, int64_t& q, int32_t& j) {
     const int64_t E = tile * 32 + e;
     valid = tile < ntiles && E < n_edges;
-    q = valid ? (E >> a.log2k) : 0;
+    q = valid ? (ragged ? (int64_t)a.edge_q[E] : (E >> a.log2k)) : 0;
     j = valid ? a.nbr[E] : 0;
   };
   float x[KS1];
@@ -268,12 +275,26 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // ---- A. stage the tile: neighbour ids, grad_out rows, channel-major copy of x ----
     const bool valid = v_cur;
+    if (w == 0 && h == 0) qt[e] = valid ? (int32_t)q_cur : -1;
     if (BWD) {
       if (w == 0 && h == 0) jt[e] = valid ? j_cur : -1;
-      for (int i = tid; i < nq * CO; i += 256) {
-        const int ql = i / CO, ch = i - ql * CO;
-        const int64_t qq = tile * nq + ql;
-        dout[i] = (qq < a.n_query && ch < a.co_t) ? a.grad_out[qq * a.co_t + ch] * a.scale : 0.f;
+      if (ragged) {  // grad_out row of every edge's query, scaled (pitch CO + 1: lanes = edges read one column)
+        for (int i = tid; i < 32 * CO; i += 256) {
+          const int ee = i / CO, ch = i - ee * CO;
+          const int64_t Ee = tile * 32 + ee;
+          float v = 0.f;
+          if (Ee < n_edges && ch < a.co_t) {
+            const int64_t qv = a.edge_q[Ee];
+            v = a.grad_out[qv * a.co_t + ch] * (a.q_scale ? a.q_scale[qv] : a.scale);
+          }
+          dout[ee * (CO + 1) + ch] = v;
+        }
+      } else {
+        for (int i = tid; i < nq * CO; i += 256) {
+          const int ql = i / CO, ch = i - ql * CO;
+          const int64_t qq = tile * nq + ql;
+          dout[i] = (qq < a.n_query && ch < a.co_t) ? a.grad_out[qq * a.co_t + ch] * a.scale : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -425,12 +446,33 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
             tB[ch * kPitch + e] = xh2[b][r] * t2[32 + r] + t2[64 + r] + sc;
           }
       __syncthreads();  // 3: tB
-      for (int i = tid; i < nq * CO; i += 256) {
-        const int ql = i / CO, ch = i - ql * CO;
-        const int64_t qq = tile * nq + ql;
-        float s = 0.f;
-        for (int kk = 0; kk < k; ++kk) s += tB[ch * kPitch + ql * k + kk];
-        if (qq < a.n_query && ch < a.co_t) a.out[qq * a.co_t + ch] = s * a.scale;
+      if (ragged) {
+        // segments of equal query id inside the tile; a list may continue in the next tile, so every segment is ADDED to
+        // its (zero-filled) output row.  Thread (part, ch): 32 / parts consecutive edges, flush when the query changes.
+        constexpr int kParts = 256 / CO > 0 ? 256 / CO : 1, kEdges = 32 / kParts;
+        const int ch = tid % CO, part = tid / CO;
+        if (part < kParts && ch < a.co_t) {
+          float acc = 0.f;
+          int32_t qprev = -1;
+          for (int ee = part * kEdges; ee < (part + 1) * kEdges; ++ee) {
+            const int32_t qv = qt[ee];
+            if (qv != qprev) {
+              if (qprev >= 0) unsafeAtomicAdd(a.out + (int64_t)qprev * a.co_t + ch, acc * (a.q_scale ? a.q_scale[qprev] : a.scale));
+              acc = 0.f;
+              qprev = qv;
+            }
+            if (qv >= 0) acc += tB[ch * kPitch + ee];
+          }
+          if (qprev >= 0) unsafeAtomicAdd(a.out + (int64_t)qprev * a.co_t + ch, acc * (a.q_scale ? a.q_scale[qprev] : a.scale));
+        }
+      } else {
+        for (int i = tid; i < nq * CO; i += 256) {
+          const int ql = i / CO, ch = i - ql * CO;
+          const int64_t qq = tile * nq + ql;
+          float s = 0.f;
+          for (int kk = 0; kk < k; ++kk) s += tB[ch * kPitch + ql * k + kk];
+          if (qq < a.n_query && ch < a.co_t) a.out[qq * a.co_t + ch] = s * a.scale;
+        }
       }
       __syncthreads();  // 4: LDS is rewritten by the next tile
       continue;
@@ -445,7 +487,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
       for (int b = 0; b < NB2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          dy[b][r] = valid ? dout[ql * CO + 32 * b + sigma(r, h)] : 0.f;
+          dy[b][r] = !valid ? 0.f : ragged ? dout[e * (CO + 1) + 32 * b + sigma(r, h)] : dout[ql * CO + 32 * b + sigma(r, h)];
           const float gd = dy[b][r] * tab[(P::NB1 + b) * 96 + 32 + h * 16 + r];
           m1 += gd;
           m2 += gd * xh2[b][r];
@@ -640,12 +682,30 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
       const int32_t jj = jt[ee];
       if (jj >= 0) unsafeAtomicAdd(a.d_in + (int64_t)jj * a.cin + c, dxt[ee * (EIN + 1) + c]);  // hardware fp32 add, no CAS loop
     }
-    for (int i = tid; i < nq * a.cq; i += 256) {
-      const int ql = i / a.cq, c = i - ql * a.cq;
-      const int64_t qq = tile * nq + ql;
-      float s = 0.f;
-      for (int kk = 0; kk < k; ++kk) s += dxt[(ql * k + kk) * (EIN + 1) + a.cin + c];
-      if (qq < a.n_query) a.d_q[qq * a.cq + c] = s;
+    if (ragged) {  // query-side gradient: segments as in the forward reduction, added to the (zero-filled) rows
+      for (int i = tid; i < 4 * a.cq; i += 256) {
+        const int part = i / a.cq, c = i - part * a.cq;
+        float acc = 0.f;
+        int32_t qprev = -1;
+        for (int ee = part * 8; ee < part * 8 + 8; ++ee) {
+          const int32_t qv = qt[ee];
+          if (qv != qprev) {
+            if (qprev >= 0) unsafeAtomicAdd(a.d_q + (int64_t)qprev * a.cq + c, acc);
+            acc = 0.f;
+            qprev = qv;
+          }
+          if (qv >= 0) acc += dxt[ee * (EIN + 1) + a.cin + c];
+        }
+        if (qprev >= 0) unsafeAtomicAdd(a.d_q + (int64_t)qprev * a.cq + c, acc);
+      }
+    } else {
+      for (int i = tid; i < nq * a.cq; i += 256) {
+        const int ql = i / a.cq, c = i - ql * a.cq;
+        const int64_t qq = tile * nq + ql;
+        float s = 0.f;
+        for (int kk = 0; kk < k; ++kk) s += dxt[(ql * k + kk) * (EIN + 1) + a.cin + c];
+        if (qq < a.n_query) a.d_q[qq * a.cq + c] = s;
+      }
     }
     __syncthreads();  // 6: LDS is rewritten by the next tile
   }
@@ -816,23 +876,27 @@ int bwd_grid(int64_t n_query, int k) {
   return (int)(tiles < 256 ? tiles : 256);  // one persistent workgroup per CU
 }
 
-template <int EIN, int HID, int CO, bool BWD, bool LIN>
+template <int EIN, int HID, int CO, bool BWD, bool LIN, bool RAG>
 int launch_edge_lin(const PcArgs& a, int grid, hipStream_t s) {
   typedef PC<EIN, HID, CO> P;
   static unsigned long long attr_done = 0ull;
   const int rc = once_per_device(attr_done, [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_edge_kernel<EIN, HID, CO, BWD, LIN>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_edge_kernel<EIN, HID, CO, BWD, LIN, RAG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (BWD ? P::LDS_FLOATS : P::LDS_FLOATS_FWD) * 4) == hipSuccess;
   });
   if (rc != WCN_SUCCESS) return rc;
-  hipLaunchKernelGGL((pointconv_edge_kernel<EIN, HID, CO, BWD, LIN>), dim3(grid), dim3(256),
+  hipLaunchKernelGGL((pointconv_edge_kernel<EIN, HID, CO, BWD, LIN, RAG>), dim3(grid), dim3(256),
                      (BWD ? P::LDS_FLOATS : P::LDS_FLOATS_FWD) * 4, s, a);
   return launch_status();
 }
 
 template <int EIN, int HID, int CO, bool BWD>
 int launch_edge(const PcArgs& a, int grid, hipStream_t s) {
-  return a.lin_sc ? launch_edge_lin<EIN, HID, CO, BWD, true>(a, grid, s) : launch_edge_lin<EIN, HID, CO, BWD, false>(a, grid, s);
+  if (a.edge_q)
+    return a.lin_sc ? launch_edge_lin<EIN, HID, CO, BWD, true, true>(a, grid, s)
+                    : launch_edge_lin<EIN, HID, CO, BWD, false, true>(a, grid, s);
+  return a.lin_sc ? launch_edge_lin<EIN, HID, CO, BWD, true, false>(a, grid, s)
+                  : launch_edge_lin<EIN, HID, CO, BWD, false, false>(a, grid, s);
 }
 
 }  // namespace
@@ -895,6 +959,41 @@ static int fill_args(PcArgs& a, const float* in_feats, const float* q_feats, con
   return WCN_SUCCESS;
 }
 
+static int run_forward(PcArgs& a, float* out, hipStream_t s) {
+  if (!out) return WCN_ERROR_INVALID_PARAMETERS;
+  const int64_t edges = a.edge_q ? a.n_edges : (a.n_query << a.log2k);
+  if (a.n_query == 0 || edges == 0) return WCN_SUCCESS;
+  a.out = out;
+  const int64_t tiles = (edges + 31) / 32;
+  const int grid = (int)(tiles < 1024 ? tiles : 1024);
+  switch (pick_shape(a.ein_t, a.hid_t, a.co_t)) {
+    case 0: return launch_edge<64, 128, 64, false>(a, grid, s);
+    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
+  }
+}
+
+static int run_backward(PcArgs& a, const float* grad_out, float* d_in, float* d_q, float* d_params, void* workspace,
+                        size_t workspace_bytes, hipStream_t s) {
+  const int64_t edges = a.edge_q ? a.n_edges : (a.n_query << a.log2k);
+  if (!grad_out || !d_in || (a.cq > 0 && !d_q) || !d_params || !workspace ||
+      workspace_bytes < wcn_pointconv_backward_workspace(edges, 1, a.ein_t, a.hid_t, a.co_t, a.lin_sc))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  const int64_t gf = grad_floats(a.ein_t, a.hid_t, a.co_t, a.lin_sc);
+  if (a.n_query == 0 || edges == 0)
+    return hipMemsetAsync(d_params, 0, gf * sizeof(float), s) == hipSuccess ? WCN_SUCCESS : WCN_ERROR_KERNEL_EXECUTION;
+  a.grad_out = grad_out; a.d_in = d_in; a.d_q = d_q; a.partial = (float*)workspace;
+  const int grid = bwd_grid(edges, 1);
+  int rc2;
+  switch (pick_shape(a.ein_t, a.hid_t, a.co_t)) {
+    case 0: rc2 = launch_edge<64, 128, 64, true>(a, grid, s); break;
+    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
+  }
+  if (rc2 != WCN_SUCCESS) return rc2;
+  hipLaunchKernelGGL(pointconv_grad_reduce_kernel, dim3((unsigned)((gf + 255) / 256)), dim3(256), 0, s,
+                     (const float*)workspace, grid, gf, d_params);
+  return launch_status();
+}
+
 int wcn_pointconv_edge_forward(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
                                const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
                                const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
@@ -903,15 +1002,7 @@ int wcn_pointconv_edge_forward(const float* in_feats, const float* q_feats, cons
   const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, k, cin, cq, nrel, packed, hidden, cout, eps1,
                            eps2, mean, linear_shortcut);
   if (rc != WCN_SUCCESS) return rc;
-  if (!out) return WCN_ERROR_INVALID_PARAMETERS;
-  if (n_query == 0) return WCN_SUCCESS;
-  a.out = out;
-  const int64_t tiles = (n_query * k + 31) / 32;
-  const int grid = (int)(tiles < 1024 ? tiles : 1024);
-  switch (pick_shape(a.ein_t, hidden, cout)) {
-    case 0: return launch_edge<64, 128, 64, false>(a, grid, (hipStream_t)stream);
-    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
-  }
+  return run_forward(a, out, (hipStream_t)stream);
 }
 
 int wcn_pointconv_edge_backward(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
@@ -923,23 +1014,40 @@ int wcn_pointconv_edge_backward(const float* in_feats, const float* q_feats, con
   const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, k, cin, cq, nrel, packed, hidden, cout, eps1,
                            eps2, mean, linear_shortcut);
   if (rc != WCN_SUCCESS) return rc;
-  if (!grad_out || !d_in || (cq > 0 && !d_q) || !d_params || !workspace ||
-      workspace_bytes < wcn_pointconv_backward_workspace(n_query, k, a.ein_t, hidden, cout, linear_shortcut))
-    return WCN_ERROR_INVALID_PARAMETERS;
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t gf = grad_floats(a.ein_t, hidden, cout, a.lin_sc);
-  if (n_query == 0) return hipMemsetAsync(d_params, 0, gf * sizeof(float), s) == hipSuccess ? WCN_SUCCESS : WCN_ERROR_KERNEL_EXECUTION;
-  a.grad_out = grad_out; a.d_in = d_in; a.d_q = d_q; a.partial = (float*)workspace;
-  const int grid = bwd_grid(n_query, k);
-  int rc2;
-  switch (pick_shape(a.ein_t, hidden, cout)) {
-    case 0: rc2 = launch_edge<64, 128, 64, true>(a, grid, s); break;
-    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
-  }
-  if (rc2 != WCN_SUCCESS) return rc2;
-  hipLaunchKernelGGL(pointconv_grad_reduce_kernel, dim3((unsigned)((gf + 255) / 256)), dim3(256), 0, s,
-                     (const float*)workspace, grid, gf, d_params);
-  return launch_status();
+  return run_backward(a, grad_out, d_in, d_q, d_params, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Ragged neighbour lists (radius search): `nbr` [n_edges] with the lists of the queries behind each other, `edge_q`
+// [n_edges] the query of every edge (non-decreasing), `q_scale` [n_query] the reduction scale per query (1 / list length for
+// mean; NULL = sum).  `out` (forward) and `d_q` (backward) must be ZERO-FILLED: a list may straddle two 32-edge tiles, so
+// list segments are added to their rows.
+int wcn_pointconv_edge_forward_ragged(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                                      const int32_t* nbr, const int32_t* edge_q, const float* q_scale, int64_t n_edges,
+                                      int64_t n_query, int32_t cin, int32_t cq, int32_t nrel, const float* packed,
+                                      int32_t hidden, int32_t cout, float eps1, float eps2, int32_t linear_shortcut,
+                                      float* out, void* stream) {
+  PcArgs a;
+  const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, 1, cin, cq, nrel, packed, hidden, cout, eps1,
+                           eps2, 0, linear_shortcut);
+  if (rc != WCN_SUCCESS) return rc;
+  if (!edge_q || n_edges < 0) return WCN_ERROR_INVALID_PARAMETERS;
+  a.edge_q = edge_q; a.q_scale = q_scale; a.n_edges = n_edges;
+  return run_forward(a, out, (hipStream_t)stream);
+}
+
+int wcn_pointconv_edge_backward_ragged(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                                       const int32_t* nbr, const int32_t* edge_q, const float* q_scale, int64_t n_edges,
+                                       int64_t n_query, int32_t cin, int32_t cq, int32_t nrel, const float* packed,
+                                       int32_t hidden, int32_t cout, float eps1, float eps2, int32_t linear_shortcut,
+                                       const float* grad_out, float* d_in, float* d_q, float* d_params, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  PcArgs a;
+  const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, 1, cin, cq, nrel, packed, hidden, cout, eps1,
+                           eps2, 0, linear_shortcut);
+  if (rc != WCN_SUCCESS) return rc;
+  if (!edge_q || n_edges < 0) return WCN_ERROR_INVALID_PARAMETERS;
+  a.edge_q = edge_q; a.q_scale = q_scale; a.n_edges = n_edges;
+  return run_backward(a, grad_out, d_in, d_q, d_params, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -4,7 +4,8 @@ Takes the place of the op sequence in the reference's ``PointConv.forward``
 (`warpconvnet/nn/modules/point_conv.py:231-273`: ``features[neighbors]`` / ``repeat_interleave`` / ``cat`` ->
 ``edge_transform_mlp`` -> ``row_reduction``) when the edge MLP is the default ``MLPBlock`` (identity or Linear shortcut,
 `warpconvnet/nn/modules/mlp.py:124-177`), the neighbour lists have a uniform power-of-two length (kNN) and the reduction
-is ``mean`` or ``sum``.  Forward and backward are single HIP kernels; no ``[M*k, C]`` tensor exists in HBM.
+is ``mean`` or ``sum``; ragged lists (radius search) run through the same kernels with per-edge query ids.  Forward and
+backward are single HIP kernels; no ``[M*k, C]`` tensor exists in HBM.
 """
 import os
 from typing import Optional
@@ -68,7 +69,7 @@ def _packed_params(mlp: nn.Module, parts) -> Tensor:
 class _FusedEdge(torch.autograd.Function):
     @staticmethod
     def forward(ctx, in_feats, q_feats, w1, b1, g1, be1, w2, b2, g2, be2, ws, bs, packed, in_xyz, q_xyz, nbr, k, eps1, eps2,
-                mean):
+                mean, edge_q=None, q_scale=None):
         L = _lib.lib()
         dev = in_feats.device
         in_feats, q_feats = in_feats.contiguous(), q_feats.contiguous()
@@ -76,12 +77,19 @@ class _FusedEdge(torch.autograd.Function):
         nrel = 0 if in_xyz is None else 3
         hid, co = w1.shape[0], w2.shape[0]
         lin = int(ws is not None)
-        out = torch.empty(M, co, dtype=torch.float32, device=dev)
-        _lib.check(L.wcn_pointconv_edge_forward(
-            _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
-            _lib.ptr(packed), hid, co, eps1, eps2, int(mean), lin, _lib.ptr(out), _lib.stream_handle(dev)),
-            "wcn_pointconv_edge_forward")
-        ctx.save_for_backward(in_feats, q_feats, packed, in_xyz, q_xyz, nbr)
+        if edge_q is None:
+            out = torch.empty(M, co, dtype=torch.float32, device=dev)
+            _lib.check(L.wcn_pointconv_edge_forward(
+                _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
+                _lib.ptr(packed), hid, co, eps1, eps2, int(mean), lin, _lib.ptr(out), _lib.stream_handle(dev)),
+                "wcn_pointconv_edge_forward")
+        else:  # ragged lists: segments are added to zero-filled rows
+            out = torch.zeros(M, co, dtype=torch.float32, device=dev)
+            _lib.check(L.wcn_pointconv_edge_forward_ragged(
+                _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), _lib.ptr(edge_q),
+                _lib.ptr(q_scale), nbr.numel(), M, cin, cq, nrel, _lib.ptr(packed), hid, co, eps1, eps2, lin, _lib.ptr(out),
+                _lib.stream_handle(dev)), "wcn_pointconv_edge_forward_ragged")
+        ctx.save_for_backward(in_feats, q_feats, packed, in_xyz, q_xyz, nbr, edge_q, q_scale)
         ctx.dims = (M, k, cin, cq, nrel, hid, co, eps1, eps2, int(mean), lin)
         ctx.has = (b1 is not None, b2 is not None, bs is not None)
         return out
@@ -89,20 +97,31 @@ class _FusedEdge(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         L = _lib.lib()
-        in_feats, q_feats, packed, in_xyz, q_xyz, nbr = ctx.saved_tensors
+        in_feats, q_feats, packed, in_xyz, q_xyz, nbr, edge_q, q_scale = ctx.saved_tensors
         M, k, cin, cq, nrel, hid, co, eps1, eps2, mean, lin = ctx.dims
         dev = in_feats.device
         ein = cin + cq + nrel
         grad_out = grad_out.contiguous().float()
         d_in = torch.zeros_like(in_feats)
-        d_q = torch.empty_like(q_feats)
         grads = torch.empty(L.wcn_pointconv_grad_floats(ein, hid, co, lin), dtype=torch.float32, device=dev)
-        ws_bytes = L.wcn_pointconv_backward_workspace(M, k, ein, hid, co, lin)
-        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
-        _lib.check(L.wcn_pointconv_edge_backward(
-            _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
-            _lib.ptr(packed), hid, co, eps1, eps2, mean, lin, _lib.ptr(grad_out), _lib.ptr(d_in), _lib.ptr(d_q), _lib.ptr(grads),
-            _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)), "wcn_pointconv_edge_backward")
+        if edge_q is None:
+            d_q = torch.empty_like(q_feats)
+            ws_bytes = L.wcn_pointconv_backward_workspace(M, k, ein, hid, co, lin)
+            ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+            _lib.check(L.wcn_pointconv_edge_backward(
+                _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
+                _lib.ptr(packed), hid, co, eps1, eps2, mean, lin, _lib.ptr(grad_out), _lib.ptr(d_in), _lib.ptr(d_q),
+                _lib.ptr(grads), _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)), "wcn_pointconv_edge_backward")
+        else:
+            d_q = torch.zeros_like(q_feats)
+            E = nbr.numel()
+            ws_bytes = L.wcn_pointconv_backward_workspace(E, 1, ein, hid, co, lin)
+            ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+            _lib.check(L.wcn_pointconv_edge_backward_ragged(
+                _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), _lib.ptr(edge_q),
+                _lib.ptr(q_scale), E, M, cin, cq, nrel, _lib.ptr(packed), hid, co, eps1, eps2, lin, _lib.ptr(grad_out),
+                _lib.ptr(d_in), _lib.ptr(d_q), _lib.ptr(grads), _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)),
+                "wcn_pointconv_edge_backward_ragged")
         o = 0
 
         def take(n, shape):
@@ -118,24 +137,35 @@ class _FusedEdge(torch.autograd.Function):
             dws, dbs = take(co * ein, (co, ein)), take(co, (co,))
         has_b1, has_b2, has_bs = ctx.has
         return (d_in, d_q, dw1, db1 if has_b1 else None, dg1, dbe1, dw2, db2 if has_b2 else None, dg2, dbe2,
-                dws, dbs if has_bs else None, None, None, None, None, None, None, None, None)
+                dws, dbs if has_bs else None, None, None, None, None, None, None, None, None, None, None)
 
 
 def fused_point_conv_edge(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nbr: Tensor, k: int, reduction: str,
-                          in_xyz: Optional[Tensor] = None, q_xyz: Optional[Tensor] = None) -> Tensor:
+                          in_xyz: Optional[Tensor] = None, q_xyz: Optional[Tensor] = None,
+                          row_splits: Optional[Tensor] = None) -> Tensor:
     """``row_reduction(edge_mlp(cat([in_feats[nbr], q_feats.repeat(k), in_xyz[nbr] - q_xyz.repeat(k)])), reduction)``
-    for ``nbr`` [M, k] / [M*k] row indices into ``in_feats``; fp32."""
+    for ``nbr`` [M, k] / [M*k] row indices into ``in_feats`` (uniform lists), or ``nbr`` [E] with ``row_splits`` [M+1]
+    (ragged lists, e.g. radius search); fp32."""
     parts = _mlp_parts(mlp)
     assert parts is not None, "fused_point_conv_edge needs the default MLPBlock (see fused_edge_supported)"
     lin1, ln1, lin2, ln2, sc = parts
     packed = _packed_params(mlp, parts)
     nbr32 = nbr.reshape(-1).to(torch.int32).contiguous()
+    edge_q = q_scale = None
+    if row_splits is not None:
+        counts = (row_splits[1:] - row_splits[:-1]).to(in_feats.device)
+        M = counts.numel()
+        edge_q = torch.repeat_interleave(torch.arange(M, dtype=torch.int32, device=in_feats.device), counts,
+                                         output_size=nbr32.numel())
+        if reduction == "mean":
+            q_scale = 1.0 / counts.clamp(min=1).to(torch.float32)
+        k = 1
     if in_xyz is not None:
         in_xyz, q_xyz = in_xyz.float().contiguous(), q_xyz.float().contiguous()
     return _FusedEdge.apply(in_feats.float(), q_feats.float(), lin1.weight, lin1.bias, ln1.weight, ln1.bias, lin2.weight,
                             lin2.bias, ln2.weight, ln2.bias, sc.weight if sc is not None else None,
                             sc.bias if sc is not None else None, packed, in_xyz, q_xyz, nbr32, int(k), float(ln1.eps),
-                            float(ln2.eps), reduction == "mean")
+                            float(ln2.eps), reduction == "mean", edge_q, q_scale)
 
 
 _ARANGE = {}

@@ -118,21 +118,26 @@ class PointConv(BaseSpatialModule):
 
     def _fused_edge(self, in_pc: Points, query_pc: Points, neighbors):
         """gather -> edge MLP -> reduction as ONE HIP kernel (`nn/functional/point_conv.py`) when the configuration allows it:
-        kNN lists of uniform power-of-two length, default edge MLP (identity or Linear shortcut), one mean / sum reduction, no
-        sinusoidal encoding.  None = take the composed path below (same result, edge tensors in HBM)."""
+        kNN lists (uniform power-of-two length) or ragged lists (radius search, other k) with per-edge query ids, default edge
+        MLP (identity or Linear shortcut), one mean / sum reduction, no sinusoidal encoding.  None = take the composed path below (same result, edge tensors in HBM)."""
         nidx = neighbors.neighbor_indices
-        if nidx.ndim != 2 or len(self.reductions) != 1 or self.use_rel_pos_encode:
+        if len(self.reductions) != 1 or self.use_rel_pos_encode or nidx.numel() == 0:
             return None
-        k = nidx.shape[1]
+        uniform = nidx.ndim == 2
+        k = nidx.shape[1] if uniform else 1
+        if uniform and (k & (k - 1)) != 0:  # kNN with a list length that is not a power of two: the ragged form of the kernel
+            uniform, k = False, 1
         fin, fq = in_pc.feature_tensor, query_pc.feature_tensor.view(-1, query_pc.num_channels)
         nrel = 3 if self.use_rel_pos else 0
         if not fused_edge_supported(self.edge_transform_mlp, fin, fq, nrel, k, self.reductions[0]):
             return None
-        counts = in_pc.offsets[1:] - in_pc.offsets[:-1]
-        if int(counts.min()) < k:  # lists padded with -1 (fewer than k points in a batch element): composed path
-            return None
+        if nidx.ndim == 2:
+            counts = in_pc.offsets[1:] - in_pc.offsets[:-1]
+            if int(counts.min()) < nidx.shape[1]:  # lists padded with -1 (fewer than k points in a batch element): composed path
+                return None
         xyz = (in_pc.coordinate_tensor.view(-1, 3), query_pc.coordinate_tensor.view(-1, 3)) if nrel else (None, None)
-        return fused_point_conv_edge(self.edge_transform_mlp, fin, fq, nidx, k, self.reductions[0], *xyz)
+        splits = None if uniform else neighbors.neighbor_row_splits
+        return fused_point_conv_edge(self.edge_transform_mlp, fin, fq, nidx, k, self.reductions[0], *xyz, row_splits=splits)
 
     def forward(self, in_pc: Points, query_pc: Optional[Points] = None) -> Points:
         if self.out_point_feature_type == "provided":
