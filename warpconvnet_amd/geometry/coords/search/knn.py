@@ -34,8 +34,11 @@ def build_cell_grid(ref32: Tensor, cell_size: float = None, min_cell_size: float
     search needs cell >= radius).  Cells grow until the grid fits ``_MAX_CELLS``.  One host read (the bounding box)."""
     dev = ref32.device
     n = ref32.shape[0]
-    lo_t, hi_t = ref32.min(0).values, ref32.max(0).values
-    lo, hi = lo_t.cpu().tolist(), hi_t.cpu().tolist()
+    # bounding box: reductions along the long axis of a [3, N] copy (a column reduction over [N, 3] runs at a fraction of
+    # the bandwidth: 0.14 + 0.09 ms for 200 k points), both bounds in one host read
+    lo_t, hi_t = torch.aminmax(ref32.t().contiguous(), dim=1)
+    lo_hi = torch.stack([lo_t, hi_t]).cpu().tolist()
+    lo, hi = lo_hi[0], lo_hi[1]
     ext = [max(h - l, 1e-6) for l, h in zip(lo, hi)]
     if cell_size is None:
         # a few points per cell on average: shell 1 (27 cells) then usually holds k <= 32 candidates
