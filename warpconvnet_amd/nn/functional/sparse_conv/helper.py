@@ -230,9 +230,17 @@ def spatially_sparse_conv(
         groups, use_fp16_accum, bias,  # bias: fused epilogue + HIP column-sum gradient (reference: helper.py:339-342)
     )
 
-    out_offsets_cpu = out_offsets.cpu().int() if out_offsets.dtype != torch.int32 or out_offsets.device.type != "cpu" else out_offsets
+    if bcoords_out is input_sparse_tensor.batch_indexed_coordinates:
+        # same output set (stride-1, non-generative layers): keep the coordinate object - no [N, 3] copy, no new batch-index
+        # pass for the next layer, and the next map build recognises "same coordinate tensor" by pointer
+        out_coords = input_sparse_tensor.batched_coordinates
+    else:
+        out_offsets_cpu = out_offsets.cpu().int() if out_offsets.dtype != torch.int32 or out_offsets.device.type != "cpu" else out_offsets
+        out_coords = IntCoords(bcoords_out[:, 1:], offsets=out_offsets_cpu)
+        if bcoords_out.dtype == torch.int32 and bcoords_out.is_contiguous():
+            out_coords.__dict__["_bcoords"] = bcoords_out  # (base/coords.py: the cached batch-indexed form)
     return input_sparse_tensor.replace(
-        batched_coordinates=IntCoords(bcoords_out[:, 1:], offsets=out_offsets_cpu),
+        batched_coordinates=out_coords,
         batched_features=out_feats,
         tensor_stride=out_tensor_stride,
     )
