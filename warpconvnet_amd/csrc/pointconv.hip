@@ -783,6 +783,190 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
   }
 }
 
+// Forward for uniform lists, one 32-edge tile per WAVE: nothing to exchange between the waves of a workgroup (every wave
+// owns all hidden channels of its tile), so there is no barrier in the loop and two waves per SIMD overlap each other's
+// gathers, LayerNorm arithmetic and MFMA chains.  The operand images sit in LDS once per (persistent) workgroup.  The
+// tensor-parallel kernel above stays for the backward (its point is the register-resident weight gradients) and for
+// ragged lists.  EIN = 64: lane half h holds x channels [32h, 32h + 32), so the identity shortcut is one lane swap.
+template <int EIN, int HID, int CO, bool LIN>
+__global__ __launch_bounds__(512, 1) void pointconv_fwd_wave_kernel(const PcArgs a) {
+  typedef PC<EIN, HID, CO> P;
+  constexpr int KS1 = P::KS1, NB1 = P::NB1, NB2 = P::NB2;
+  static_assert(KS1 == 32 && CO <= EIN, "identity shortcut by lane swap");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sP = smem;                          // P1 | P2 (packed image prefix)
+  float* sTab = sP + P::OFF_P2T;             // T1 | T2
+  float* sPS = sTab + (NB1 + NB2) * 96;      // PS (Linear shortcut)
+  float* sTS = sPS + EIN * CO;               // bs
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, e = lane & 31;
+  for (int i = tid; i < P::OFF_P2T / 4; i += 512) reinterpret_cast<f32x4*>(sP)[i] = reinterpret_cast<const f32x4*>(a.packed)[i];
+  for (int i = tid; i < (NB1 + NB2) * 96; i += 512) sTab[i] = a.packed[P::OFF_T1 + i];
+  if (LIN) {
+    for (int i = tid; i < EIN * CO / 4; i += 512)
+      reinterpret_cast<f32x4*>(sPS)[i] = reinterpret_cast<const f32x4*>(a.packed + P::OFF_PS)[i];
+    for (int i = tid; i < NB2 * 32; i += 512) sTS[i] = a.packed[P::OFF_TS + i];
+  }
+  __syncthreads();  // the only barrier: the waves are independent from here on
+
+  const int k = 1 << a.log2k;
+  const int64_t n_edges = a.n_query << a.log2k;
+  const int64_t ntiles = (n_edges + 31) >> 5;
+  const float inv_hid = 1.f / (float)a.hid_t, inv_co = 1.f / (float)a.co_t;
+  const int64_t nwaves = (int64_t)gridDim.x * 8;
+  int64_t tile = (int64_t)blockIdx.x * 8 + (tid >> 6);
+  // neighbour id of the first tile; the next tile's id is requested while the current tile is computed
+  int32_t j_nxt = 0;
+  if (tile < ntiles && tile * 32 + e < n_edges) j_nxt = a.nbr[tile * 32 + e];
+  for (; tile < ntiles; tile += nwaves) {
+    // the operand images never change, so the compiler would hoist all 512 registers' worth of LDS reads out of the tile
+    // loop (and spill them): the LDS offsets are laundered per tile
+    uint32_t o1 = (uint32_t)(P::OFF_P1 * 4 + lane * 16), o2 = (uint32_t)(P::OFF_P2 * 4 + lane * 16), ot = 0u;
+    asm volatile("" : "+v"(o1), "+v"(o2), "+v"(ot));
+    const f32x4* p1 = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sP) + o1);
+    const f32x4* p2 = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sP) + o2);
+    const float* sTabL = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sTab) + ot);
+    const float* sPSL = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sPS) + ot);
+    const float* sTSL = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sTS) + ot);
+    const int64_t E = tile * 32 + e;
+    const bool valid = E < n_edges;
+    const int64_t q = valid ? (E >> a.log2k) : 0;
+    const int32_t j = j_nxt;
+    {
+      const int64_t En = (tile + nwaves) * 32 + e;
+      j_nxt = (tile + nwaves < ntiles && En < n_edges) ? a.nbr[En] : 0;
+    }
+    float x[KS1];
+    {
+      const float* fi = a.in_feats + (int64_t)j * a.cin;
+      const float* fq = a.q_feats + q * a.cq;
+      const bool vec = ((a.cin | a.cq) & 3) == 0;
+#pragma unroll
+      for (int u = 0; u < KS1 / 4; ++u) {
+        const int c4 = h * KS1 + 4 * u;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+          if (vec && c4 + 4 <= a.cin) {
+            v = *reinterpret_cast<const f32x4*>(fi + c4);
+          } else if (vec && c4 >= a.cin && c4 + 4 <= a.cin + a.cq) {
+            v = *reinterpret_cast<const f32x4*>(fq + (c4 - a.cin));
+          } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const int c = c4 + d;
+              float sv = 0.f;
+              if (c < a.cin) sv = fi[c];
+              else if (c < a.cin + a.cq) sv = fq[c - a.cin];
+              else if (c < a.cin + a.cq + a.nrel) sv = a.in_xyz[(int64_t)j * 3 + (c - a.cin - a.cq)] - a.q_xyz[q * 3 + (c - a.cin - a.cq)];
+              v[d] = sv;
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) x[4 * u + d] = v[d];
+      }
+    }
+    // ---- GEMM1 (all hidden blocks) + LayerNorm1 + ReLU ----
+    f32x16 hb[NB1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NB1; ++blk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hb[blk][r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < KS1 / 4; ++s4) {
+        const f32x4 av = p1[(blk * (KS1 / 4) + s4) * 64];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) hb[blk] = mfma(av[d], x[4 * s4 + d], hb[blk]);
+      }
+      const float* t1 = sTabL + blk * 96 + h * 16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        hb[blk][r] += t1[r];
+        s1 += hb[blk][r];
+        s2 += hb[blk][r] * hb[blk][r];
+      }
+    }
+    s1 += half_swap(s1);
+    s2 += half_swap(s2);
+    const float mu1 = s1 * inv_hid, rstd1 = rsqrtf(fmaxf(s2 * inv_hid - mu1 * mu1, 0.f) + a.eps1);
+#pragma unroll
+    for (int blk = 0; blk < NB1; ++blk) {
+      const float* t1 = sTabL + blk * 96 + h * 16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hb[blk][r] = fmaxf((hb[blk][r] - mu1) * rstd1 * t1[32 + r] + t1[64 + r], 0.f);
+    }
+    // ---- GEMM2 + LayerNorm2 + shortcut ----
+    f32x16 o[NB2];
+    float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < NB1; ++blk)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 av = p2[((blk * NB2 + b) * 4 + r4) * 64];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) o[b] = mfma(av[d], hb[blk][4 * r4 + d], o[b]);
+        }
+      const float* t2 = sTabL + (NB1 + b) * 96 + h * 16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[b][r] += t2[r];
+        u1 += o[b][r];
+        u2 += o[b][r] * o[b][r];
+      }
+    }
+    u1 += half_swap(u1);
+    u2 += half_swap(u2);
+    const float mu2 = u1 * inv_co, rstd2 = rsqrtf(fmaxf(u2 * inv_co - mu2 * mu2, 0.f) + a.eps2);
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) {
+      const float* t2 = sTabL + (NB1 + b) * 96 + h * 16;
+      f32x16 sc;
+      if (LIN) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < KS1 / 4; ++s4) {
+          const f32x4 av = reinterpret_cast<const f32x4*>(sPSL)[(b * (KS1 / 4) + s4) * 64 + lane];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) sc = mfma(av[d], x[4 * s4 + d], sc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] += sTSL[b * 32 + h * 16 + r];
+      } else {
+        // identity: output channel 32b + sigma(r, h) is x channel sigma(r, h) of lane half b (own half or the partner's)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float own = x[sigma(r, b)], other = half_swap(x[sigma(r, 1 - b)]);
+          sc[r] = (h == b) ? own : other;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][r] = (o[b][r] - mu2) * rstd2 * t2[32 + r] + t2[64 + r] + sc[r];
+    }
+    // ---- reduction over the k edges of a query (adjacent lanes), one store per query and channel ----
+    for (int m = k >> 1; m >= 1; m >>= 1) {
+#pragma unroll
+      for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] += __shfl_xor(o[b][r], m, 64);
+    }
+    if (valid && (e & (k - 1)) == 0) {
+      float* dst = a.out + q * a.co_t;
+#pragma unroll
+      for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = 32 * b + sigma(r, h);
+          if (ch < a.co_t) dst[ch] = o[b][r] * a.scale;
+        }
+    }
+  }
+}
+
 // packs the torch-layout parameters into the operand images of PC<EIN, HID, CO>
 struct PackArgs {
   const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2;  // w1 [hid][ein], w2 [co][hid]
@@ -890,6 +1074,28 @@ int launch_edge_lin(const PcArgs& a, int grid, hipStream_t s) {
   return launch_status();
 }
 
+template <int EIN, int HID, int CO>
+int launch_fwd_wave(const PcArgs& a, hipStream_t s) {
+  typedef PC<EIN, HID, CO> P;
+  constexpr int kLds = (P::OFF_P2T + (P::NB1 + P::NB2) * 96 + EIN * CO + P::NB2 * 32) * 4;
+  static unsigned long long attr_done = 0ull;
+  const int rc = once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_fwd_wave_kernel<EIN, HID, CO, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_fwd_wave_kernel<EIN, HID, CO, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+  });
+  if (rc != WCN_SUCCESS) return rc;
+  const int64_t tiles = ((a.n_query << a.log2k) + 31) / 32;
+  const int64_t wgs = (tiles + 7) / 8;
+  const int grid = (int)(wgs < 256 ? wgs : 256);  // one persistent 8-wave workgroup per CU
+  if (a.lin_sc)
+    hipLaunchKernelGGL((pointconv_fwd_wave_kernel<EIN, HID, CO, true>), dim3(grid), dim3(512), kLds, s, a);
+  else
+    hipLaunchKernelGGL((pointconv_fwd_wave_kernel<EIN, HID, CO, false>), dim3(grid), dim3(512), kLds, s, a);
+  return launch_status();
+}
+
 template <int EIN, int HID, int CO, bool BWD>
 int launch_edge(const PcArgs& a, int grid, hipStream_t s) {
   if (a.edge_q)
@@ -966,8 +1172,14 @@ static int run_forward(PcArgs& a, float* out, hipStream_t s) {
   a.out = out;
   const int64_t tiles = (edges + 31) / 32;
   const int grid = (int)(tiles < 1024 ? tiles : 1024);
+  static const int wave_fwd = [] {
+    const char* e = getenv("WARPCONVNET_AMD_POINTCONV_WAVE_FWD");  // 0: tensor-parallel forward kernel for uniform lists too
+    return e ? atoi(e) : 1;
+  }();
   switch (pick_shape(a.ein_t, a.hid_t, a.co_t)) {
-    case 0: return launch_edge<64, 128, 64, false>(a, grid, s);
+    case 0:
+      if (!a.edge_q && wave_fwd) return launch_fwd_wave<64, 128, 64>(a, s);
+      return launch_edge<64, 128, 64, false>(a, grid, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
