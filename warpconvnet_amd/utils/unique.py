@@ -37,6 +37,21 @@ def unique_hashmap(bcoords: Tensor, **kwargs) -> Tuple[Tensor, "PackedHashTable"
     return table.unique_index, table
 
 
+_ARANGE = {}
+
+
+def arange_i32(n: int, dev) -> Tensor:
+    """``torch.arange(n, int32)`` on ``dev``, kept per size (read-only by contract): identity pair lists and first-occurrence
+    tests ask for the same few sizes every iteration."""
+    key = (int(n), str(dev))
+    t = _ARANGE.get(key)
+    if t is None:
+        if len(_ARANGE) >= 32:
+            _ARANGE.clear()
+        t = _ARANGE[key] = torch.arange(n, dtype=torch.int32, device=dev)
+    return t
+
+
 @torch.no_grad()
 def unique_first_indices_with_offsets(bcoords: Tensor) -> Tuple[Tensor, Tensor]:
     """GPU: ``(ascending int64 rows of the first occurrence of every distinct [b, x, y, z] row, CPU int32 offsets [B+1] of
@@ -54,7 +69,7 @@ def unique_first_indices_with_offsets(bcoords: Tensor) -> Tuple[Tensor, Tensor]:
     table = PackedHashTable(max(16, 2 * n), device=dev)
     meta = torch.zeros(1 + PackedHashTable.BATCH_MAX + 1, dtype=torch.int32, device=dev)  # [status, counts[512]]
     table._launch_insert(coords, meta[:1])
-    first = table.search(coords) == torch.arange(n, dtype=torch.int32, device=dev)
+    first = table.search(coords) == arange_i32(n, dev)
     b = coords[:, 0].long().clamp_(0, PackedHashTable.BATCH_MAX)  # out-of-range batch ids are reported through the status
     meta[1:].index_add_(0, b, first.to(torch.int32))
     host = meta.cpu()  # the one host read
