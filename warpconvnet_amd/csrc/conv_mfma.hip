@@ -538,6 +538,18 @@ static int launch_gather_gemm(const void* in, const void* wp, void* out, const i
   return launch_status();
 }
 
+// Output widths 96 / 128: 32 rows per wave (128-row tiles, 64 / 48 accumulator registers, three workgroups per CU instead
+// of two).  Round 1 measured this as a wash; with the round-2 index-slab / epilogue code it is 4-6 % faster on both scene
+// types (forward 64->128: 237 vs 253 us in-step on the uniform scene, 293 vs 304 us on the surface scene).  Width 64 keeps
+// 64 rows per wave (already three workgroups per CU; 32 rows: 277 vs 270 us).  WARPCONVNET_AMD_GEMM_ROWS32=0 switches back.
+static bool rows_per_wave_32() {
+  static const bool v = [] {
+    const char* e = getenv("WARPCONVNET_AMD_GEMM_ROWS32");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+
 template <typename T, int CIC>
 static int dispatch_co(int cout, const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                        const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
@@ -545,8 +557,12 @@ static int dispatch_co(int cout, const void* in, const void* wp, void* out, cons
   switch (cout) {
     case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
-    case 96: return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
-    case 128: return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 96:
+      if (rows_per_wave_32()) return launch_gather_gemm<T, CIC, 96, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+      return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 128:
+      if (rows_per_wave_32()) return launch_gather_gemm<T, CIC, 128, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+      return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
