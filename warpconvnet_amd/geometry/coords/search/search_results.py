@@ -71,6 +71,7 @@ class IntSearchResult:
         self._out_maps = out_maps
         self._offsets = offsets_cpu
         self._pending = None
+        self._lazy_pairs = None
         self._num_offsets = len(offsets_cpu) - 1
         self.identity_map_index = identity_map_index
         self._init_tables()
@@ -96,12 +97,36 @@ class IntSearchResult:
         self = object.__new__(cls)
         self._in_maps, self._out_maps, self._offsets = in_full, out_full, None
         self._pending = (meta_host, event, on_flags)
+        self._lazy_pairs = None
         self._num_offsets = num_offsets
         self.identity_map_index = identity_map_index
         self._init_tables()
         return self
 
+    @classmethod
+    def _from_deferred_pairs(cls, scatter, offsets_host: Tensor, device, identity_map_index: Optional[int]) -> "IntSearchResult":
+        """Builder hook: offsets are known, the pair lists are not written yet.  ``scatter()`` allocates and fills
+        ``(in_maps, out_maps)`` on first use - the forward / dgrad kernels read the neighbour table, only the weight gradient
+        (and the container API) needs the lists, so a forward-only pass never pays for them."""
+        self = object.__new__(cls)
+        self._in_maps = self._out_maps = None
+        self._offsets = offsets_host.detach().cpu()
+        self._pending = None
+        self._lazy_pairs = scatter
+        self._device = torch.device(device)
+        self._num_offsets = len(self._offsets) - 1
+        self.identity_map_index = identity_map_index
+        self._init_tables()
+        return self
+
+    def _ensure_pairs(self):
+        fn = getattr(self, "_lazy_pairs", None)
+        if fn is not None:
+            self._lazy_pairs = None
+            self._in_maps, self._out_maps = fn()
+
     def _materialize(self):
+        self._ensure_pairs()
         if self._pending is None:
             return
         meta_host, event, on_flags = self._pending
@@ -137,10 +162,12 @@ class IntSearchResult:
     @property
     def in_maps_device(self) -> Tensor:
         """Pair buffer without forcing the host copy (may be longer than the number of pairs)."""
+        self._ensure_pairs()
         return self._in_maps
 
     @property
     def out_maps_device(self) -> Tensor:
+        self._ensure_pairs()
         return self._out_maps
 
     # ---- reference container API --------------------------------------------------------
@@ -164,6 +191,8 @@ class IntSearchResult:
 
     @property
     def device(self):
+        if self._in_maps is None:
+            return self._device
         return self._in_maps.device
 
     @torch.no_grad()

@@ -129,6 +129,7 @@ def _first_half(full: IntSearchResult) -> IntSearchResult:
     return IntSearchResult(full.in_maps_device[:n].clone(), full.out_maps_device[:n].clone(), offs, identity_map_index=c)
 
 
+_LAZY_PAIRS = os.environ.get("WARPCONVNET_AMD_KMAP_LAZY_PAIRS", "auto")  # pair lists written on first use: auto = under no_grad
 _SPIN_POLLS = int(os.environ.get("WARPCONVNET_AMD_KMAP_SPIN", "4000"))  # ~0.1 us each: up to ~0.4 ms of spinning
 
 
@@ -315,18 +316,29 @@ def generate_kernel_map(
         has_duplicates = bool(flags & _lib.WCN_FLAG_DUPLICATE_COORD)
     if has_duplicates and same_tensor:
         identity = None  # "output row i == input row i at the centre offset" fails for the rows that lost their coordinate
-    in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
-    out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
-    _lib.check(
-        L.wcn_kmap_scatter(_lib.ptr(nbr), _lib.ptr(mask), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
-                           _lib.ptr(out_maps), pair_capacity, _lib.ptr(meta[K + 1 :]), stream),
-        "wcn_kmap_scatter",
-    )
+    def scatter_pairs():
+        in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
+        out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
+        _lib.check(
+            L.wcn_kmap_scatter(_lib.ptr(nbr), _lib.ptr(mask), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
+                               _lib.ptr(out_maps), pair_capacity, _lib.ptr(meta[K + 1 :]), _lib.stream_handle(dev)),
+            "wcn_kmap_scatter",
+        )
+        return in_maps, out_maps
+
     if async_ok:
+        in_maps, out_maps = scatter_pairs()
         result = IntSearchResult._from_pending(
             in_maps, out_maps, meta_host, event, K, identity,
             lambda flags, n=N, c=table_capacity: PackedHashTable.raise_for_flags(flags, n, c))
+    elif _LAZY_PAIRS == "1" or (_LAZY_PAIRS == "auto" and not torch.is_grad_enabled()):
+        # the pair lists (CSR by offset) are written on first use: the forward and dgrad kernels read the neighbour table,
+        # only wgrad and the container API need the lists, so a forward-only pass (inference, no_grad) skips the 49 us
+        # scatter.  Not in training: run later, between dgrad and wgrad, the scatter finds the 128 MB table evicted from
+        # the Infinity Cache and the step is 35-45 us slower (measured 1.079 vs 1.031 ms).
+        result = IntSearchResult._from_deferred_pairs(scatter_pairs, offsets_host, dev, identity)
     else:
+        in_maps, out_maps = scatter_pairs()
         result = IntSearchResult(in_maps, out_maps, offsets_host, identity_map_index=identity)
     result._nbr, result._mask, result._perm = nbr, mask, perm
     result._offsets_dev = meta[: K + 1]
