@@ -397,3 +397,78 @@ def test_pointconv_fused_edge_kernel_ragged_lists_vs_fp64(n, cin, cout, mode, ar
     for (name, p), (_, pr) in zip(conv.named_parameters(), ref.named_parameters()):
         err = float((p.grad.cpu().double() - pr.grad).abs().max()) / (float(pr.grad.abs().max()) + 1e-12)
         assert err < 1e-3, f"{name}: relative max error {err:.2e}"
+
+
+@pytest.mark.parametrize("kind", ["provided", "downsample"])
+def test_pointconv_fused_edge_kernel_other_query_sets(kind):
+    """Query points that are not the input points (`out_point_type` "provided" with its own feature width, "downsample" with
+    pooled queries): the one-pass edge pipeline against the fp64 op-by-op evaluation on the same neighbour lists."""
+    import copy
+
+    from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
+    from warpconvnet_amd.geometry.types.points import Points
+    from warpconvnet_amd.nn.functional import point_conv as fpc
+    from warpconvnet_amd.nn.modules import PointConv
+    from warpconvnet_amd.ops.reductions import row_reduction
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    n, cin, k = 4000, 24, 8
+    coords = torch.rand(n, 3, generator=g) * 3.0
+    feats = torch.randn(n, cin, generator=g)
+    cfg = RealSearchConfig(mode="knn", knn_k=k)
+    torch.manual_seed(3)
+    if kind == "provided":
+        m, cq, cout = 1500, 16, 40
+        conv = PointConv(cin, cout, cfg, out_point_type="provided", provided_in_channels=cq)
+        qcoords = torch.rand(m, 3, generator=g) * 3.0
+        qfeats = torch.randn(m, cq, generator=g)
+    else:
+        cout = 48
+        conv = PointConv(cin, cout, cfg, out_point_type="downsample", pooling_reduction="mean", pooling_voxel_size=0.3)
+    ref = copy.deepcopy(conv).double()
+    conv = conv.to(dev)
+    x = feats.to(dev).requires_grad_(True)
+    pc = Points(coords.to(dev), x, offsets=torch.tensor([0, n]))
+    calls = []
+    orig = fpc._FusedEdge.apply
+    fpc._FusedEdge.apply = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        if kind == "provided":
+            qx = qfeats.to(dev).requires_grad_(True)
+            qpc = Points(qcoords.to(dev), qx, offsets=torch.tensor([0, m]))
+            out_pc = conv(pc, qpc)
+        else:
+            qpc = pc.voxel_downsample(0.3, reduction="mean")
+            out_pc = conv(pc)
+    finally:
+        fpc._FusedEdge.apply = orig
+    assert calls, "the fused edge kernel was not used"
+    out = out_pc.feature_tensor
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy.to(dev))
+
+    nb = pc.neighbors(query_coords=qpc.batched_coordinates, search_args=cfg)
+    idx = nb.neighbor_indices.cpu().view(-1)
+    mq = qpc.coordinate_tensor.shape[0]
+    assert out.shape[0] == mq
+    xr = feats.double().requires_grad_(True)
+    if kind == "provided":
+        qr = qfeats.double().requires_grad_(True)
+        qf = qr
+    else:  # pooled query features are a function of the inputs: the same pooling on the CPU in fp64, rows matched by position
+        cpu_q = Points(coords.double(), xr, offsets=torch.tensor([0, n])).voxel_downsample(0.3, reduction="mean")
+        got_xyz = qpc.coordinate_tensor.detach().cpu().double()
+        order = torch.cdist(got_xyz, cpu_q.coordinate_tensor.double()).argmin(1)
+        assert torch.allclose(cpu_q.coordinate_tensor.double()[order], got_xyz, atol=1e-4)
+        qf = cpu_q.feature_tensor[order]
+    e = ref.edge_transform_mlp(torch.cat([xr[idx], qf.repeat_interleave(k, dim=0)], 1))
+    want = ref.out_transform_mlp(row_reduction(e, torch.arange(0, mq * k + 1, k), reduction="mean"))
+    want.backward(dy.double())
+    torch.testing.assert_close(out.detach().cpu().double(), want.detach(), rtol=1e-4, atol=1e-4)
+    assert float((x.grad.cpu().double() - xr.grad).norm() / xr.grad.norm()) < 1e-3
+    if kind == "provided":
+        assert float((qx.grad.cpu().double() - qr.grad).norm() / qr.grad.norm()) < 1e-3
+    for (name, p), (_, pr) in zip(conv.named_parameters(), ref.named_parameters()):
+        err = float((p.grad.cpu().double() - pr.grad).abs().max()) / (float(pr.grad.abs().max()) + 1e-12)
+        assert err < 1e-3, f"{name}: relative max error {err:.2e}"
