@@ -25,8 +25,19 @@ def hip_batch_norm_supported(x: Tensor) -> bool:
             and os.environ.get("WARPCONVNET_AMD_HIP_BATCHNORM", "1") not in ("0", "false"))
 
 
+_WS = {}
+
+
 def _workspace(c: int, dev) -> Tensor:
-    return torch.empty(_lib.lib().wcn_bn_workspace(c), dtype=torch.uint8, device=dev)
+    """Partial-sum workspace of the two reduction passes: kept per (device, stream, width) - the passes of one stream are
+    ordered, so they can share it - instead of a fresh allocation per call."""
+    key = (str(dev), _lib.stream_handle(dev), int(c))
+    ws = _WS.get(key)
+    if ws is None:
+        if len(_WS) >= 64:
+            _WS.clear()
+        ws = _WS[key] = torch.empty(_lib.lib().wcn_bn_workspace(c), dtype=torch.uint8, device=dev)
+    return ws
 
 
 def _apply(x: Tensor, scale: Tensor, shift: Tensor, relu: bool) -> Tensor:
@@ -51,12 +62,10 @@ class _HipBatchNorm(Function):
             return None if t is None else (t.detach() if t.dtype == torch.float32 and t.is_contiguous() else t.detach().float().contiguous())
 
         gamma, beta = f32(weight), f32(bias)
-        mean = torch.empty(c, dtype=torch.float32, device=dev)
-        rstd = torch.empty(c, dtype=torch.float32, device=dev)
-        scale = torch.empty(c, dtype=torch.float32, device=dev)
-        shift = torch.empty(c, dtype=torch.float32, device=dev)
+        stats = torch.empty((5, c), dtype=torch.float32, device=dev)  # one allocation for the five per-channel vectors
+        mean, rstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
         if training:
-            var = torch.empty(c, dtype=torch.float32, device=dev)
+            var = stats[4]
             ws = _workspace(c, dev)
             # running statistics are updated inside the kernel when they are fp32 (the usual case), else below
             fused_running = (running_mean is not None and running_mean.dtype == torch.float32
@@ -95,8 +104,8 @@ class _HipBatchNorm(Function):
         dy = grad_out.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        sum_dy = torch.empty(c, dtype=torch.float32, device=dev)
-        sum_dy_xhat = torch.empty(c, dtype=torch.float32, device=dev)
+        sums = torch.empty((2, c), dtype=torch.float32, device=dev)
+        sum_dy, sum_dy_xhat = sums[0], sums[1]
         ws = _workspace(c, dev)
         _lib.check(
             L.wcn_bn_backward_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), n, c, _lib.dtype_code(x.dtype), _lib.ptr(mean),
