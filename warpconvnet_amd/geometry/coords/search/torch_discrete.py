@@ -134,7 +134,7 @@ _SPIN_POLLS = int(os.environ.get("WARPCONVNET_AMD_KMAP_SPIN", "4000"))  # ~0.1 u
 
 
 # binned builder: does this process see scenes with >= 4 voxels per occupied 8^3 block?  (size of the first-try block table)
-_BINNED_HINT = {"dense": True}
+_BINNED_HINT = {"div": int(os.environ.get("WARPCONVNET_AMD_KMAP_BLOCK_DIV", "4"))}  # block-table bound = N / div, grown to N / 4 and N on TABLE_FULL (16: quarter the workspace, same speed)
 
 
 @torch.compiler.disable
@@ -230,9 +230,10 @@ def generate_kernel_map(
         raise RuntimeError("WARPCONVNET_AMD_KMAP_METHOD=binned needs a submanifold map (same coordinate tensor, stride 1, "
                            "halo <= 8, K % 32 != 0)")
     table_capacity = _next_power_of_2(max(16, 2 * N))
-    # binned path: capacity of the block table.  Most scenes have >= 4 voxels per occupied 8^3 block; sparser ones raise
-    # TABLE_FULL on the device and are rebuilt with one block per voxel (always enough).  `strict`: see wcn.h.
-    max_blocks = max(1024, N // 4) if _BINNED_HINT["dense"] else max(N, 1)
+    # binned path: capacity of the block table.  Most scenes have >= 4 voxels per occupied 8^3 block (uniform 12 % occupancy:
+    # 28, surfaces: ~64); sparser ones raise TABLE_FULL on the device and are rebuilt with one block per voxel (always
+    # enough).  `strict`: see wcn.h.
+    max_blocks = max(1024, N // _BINNED_HINT["div"]) if _BINNED_HINT["div"] > 1 else max(N, 1)
     strict = 0
     # WARPCONVNET_AMD_ASYNC_KMAP=1 (opt-in): never wait - pairs go to worst-case sized buffers and offsets / flags are
     # validated lazily (IntSearchResult.poll / first host access); the binned builder then runs in its no-retry
@@ -295,8 +296,10 @@ def generate_kernel_map(
             event.synchronize()
         flags = int(meta_host[K + 1])
         if use_binned and (flags & _lib.WCN_FLAG_TABLE_FULL) and max_blocks < N:
-            _BINNED_HINT["dense"] = False  # this process sees sparse scenes: start with the large table from now on
-            max_blocks = N
+            # this process sees sparser scenes than the bound assumed (>= 16, then >= 4 voxels per occupied 8^3 block): start
+            # with the next larger table from now on
+            _BINNED_HINT["div"] = 4 if _BINNED_HINT["div"] > 4 else 1
+            max_blocks = max(1024, N // 4) if _BINNED_HINT["div"] == 4 and max_blocks < max(1024, N // 4) else N
             continue
         if use_binned and (flags & _lib.WCN_FLAG_NEED_STRICT) and not strict:
             strict = 1
