@@ -148,6 +148,7 @@ def generate_kernel_map(
     kernel_center_offset: Optional[Tuple[int, ...]] = None,
     method: Literal["offset", "size"] = "size",
     skip_symmetric_kernel_map: bool = False,
+    need_pairs: bool = True,
     **kwargs,
 ) -> IntSearchResult:
     """Kernel map between integer coordinate sets: ``in = out * stride + offset[k]``.
@@ -334,11 +335,12 @@ def generate_kernel_map(
         result = IntSearchResult._from_pending(
             in_maps, out_maps, meta_host, event, K, identity,
             lambda flags, n=N, c=table_capacity: PackedHashTable.raise_for_flags(flags, n, c))
-    elif _LAZY_PAIRS == "1" or (_LAZY_PAIRS == "auto" and not torch.is_grad_enabled()):
+    elif _LAZY_PAIRS == "1" or (_LAZY_PAIRS == "auto" and not need_pairs):
         # the pair lists (CSR by offset) are written on first use: the forward and dgrad kernels read the neighbour table,
-        # only wgrad and the container API need the lists, so a forward-only pass (inference, no_grad) skips the 49 us
-        # scatter.  Not in training: run later, between dgrad and wgrad, the scatter finds the 128 MB table evicted from
-        # the Infinity Cache and the step is 35-45 us slower (measured 1.079 vs 1.031 ms).
+        # only wgrad and the container API need the lists, so a caller that will not run a weight gradient (need_pairs =
+        # False: the convolution under no_grad) skips the 49 us scatter.  Not in training: run later, between dgrad and
+        # wgrad, the scatter finds the 128 MB table evicted from the Infinity Cache and the step is 35-45 us slower
+        # (measured 1.079 vs 1.031 ms).
         result = IntSearchResult._from_deferred_pairs(scatter_pairs, offsets_host, dev, identity)
     else:
         in_maps, out_maps = scatter_pairs()

@@ -61,8 +61,10 @@ def generate_output_coords_and_kernel_map(
     order=None,
     kernel_search_batch_size: Optional[int] = None,
     out_code_backend: Optional[str] = None,
+    need_pairs: bool = True,
 ) -> Tuple[Tensor, Tensor, IntSearchResult]:
-    """Returns ``(batch_indexed_out_coords [M, D+1], out_offsets (CPU), kernel_map)``."""
+    """Returns ``(batch_indexed_out_coords [M, D+1], out_offsets (CPU), kernel_map)``.  ``need_pairs``: the caller will
+    run a weight gradient on the map (pair lists written with the build); False defers them to their first use."""
     bcoords_in = input_sparse_tensor.batch_indexed_coordinates
     if bcoords_in.dtype != torch.int32:
         bcoords_in = bcoords_in.to(torch.int32)
@@ -120,9 +122,10 @@ def generate_output_coords_and_kernel_map(
                 fwd = source.cache.get(fwd_key)
                 if fwd is not None:
                     return bcoords_out, out_offsets, _swap(fwd)
-        kernel_map = _swap(generate_kernel_map(bcoords_out, bcoords_in, map_stride, kernel_size, kernel_dilation))
+        kernel_map = _swap(generate_kernel_map(bcoords_out, bcoords_in, map_stride, kernel_size, kernel_dilation,
+                                               need_pairs=need_pairs))
     else:
-        kernel_map = generate_kernel_map(bcoords_in, bcoords_out, map_stride, kernel_size, kernel_dilation)
+        kernel_map = generate_kernel_map(bcoords_in, bcoords_out, map_stride, kernel_size, kernel_dilation, need_pairs=need_pairs)
 
     if input_sparse_tensor.cache is None:
         input_sparse_tensor._extra_attributes["_cache"] = IntSearchCache()
@@ -212,6 +215,7 @@ def spatially_sparse_conv(
     bcoords_out, out_offsets, kernel_map = generate_output_coords_and_kernel_map(
         input_sparse_tensor, _kernel_size, _dilation, _stride, generative=generative, transposed=transposed,
         output_spatially_sparse_tensor=output_spatially_sparse_tensor, stride_mode=stride_mode, order=order,
+        need_pairs=torch.is_grad_enabled(),  # (the map builders run under no_grad: the caller's mode is read here)
     )
     num_out = bcoords_out.shape[0]
     if torch.is_grad_enabled() and hasattr(kernel_map, "_ensure_pairs"):
