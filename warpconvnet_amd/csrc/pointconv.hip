@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
 // gathers, LayerNorm arithmetic and MFMA chains.  The operand images sit in LDS once per (persistent) workgroup.  The
 // tensor-parallel kernel above stays for the backward (its point is the register-resident weight gradients) and for
 // ragged lists.  EIN = 64: lane half h holds x channels [32h, 32h + 32), so the identity shortcut is one lane swap.
-template <int EIN, int HID, int CO, bool LIN>
+template <int EIN, int HID, int CO, bool LIN, bool RAG>
 __global__ __launch_bounds__(512, 1) void pointconv_fwd_wave_kernel(const PcArgs a) {
   typedef PC<EIN, HID, CO> P;
   constexpr int KS1 = P::KS1, NB1 = P::NB1, NB2 = P::NB2;
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(512, 1) void pointconv_fwd_wave_kernel(const PcArgs
   __syncthreads();  // the only barrier: the waves are independent from here on
 
   const int k = 1 << a.log2k;
-  const int64_t n_edges = a.n_query << a.log2k;
+  const int64_t n_edges = RAG ? a.n_edges : (a.n_query << a.log2k);
   const int64_t ntiles = (n_edges + 31) >> 5;
   const float inv_hid = 1.f / (float)a.hid_t, inv_co = 1.f / (float)a.co_t;
   const int64_t nwaves = (int64_t)gridDim.x * 8;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void pointconv_fwd_wave_kernel(const PcArgs
     const float* sTSL = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sTS) + ot);
     const int64_t E = tile * 32 + e;
     const bool valid = E < n_edges;
-    const int64_t q = valid ? (E >> a.log2k) : 0;
+    const int64_t q = valid ? (RAG ? (int64_t)a.edge_q[E] : (E >> a.log2k)) : -1;
     const int32_t j = j_nxt;
     {
       const int64_t En = (tile + nwaves) * 32 + e;
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(512, 1) void pointconv_fwd_wave_kernel(const PcArgs
     float x[KS1];
     {
       const float* fi = a.in_feats + (int64_t)j * a.cin;
-      const float* fq = a.q_feats + q * a.cq;
+      const float* fq = a.q_feats + (q < 0 ? 0 : q) * a.cq;
       const bool vec = ((a.cin | a.cq) & 3) == 0;
 #pragma unroll
       for (int u = 0; u < KS1 / 4; ++u) {
@@ -947,22 +947,52 @@ __global__ __launch_bounds__(512, 1) void pointconv_fwd_wave_kernel(const PcArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[b][r] = (o[b][r] - mu2) * rstd2 * t2[32 + r] + t2[64 + r] + sc[r];
     }
-    // ---- reduction over the k edges of a query (adjacent lanes), one store per query and channel ----
-    for (int m = k >> 1; m >= 1; m >>= 1) {
+    if (RAG) {
+      // ragged lists: segmented inclusive scan over the lanes of the tile (equal query ids are adjacent); the last lane
+      // of every segment ADDS its total to the (zero-filled) output row - a list may continue in the next tile
+      const int qi = (int)q;
 #pragma unroll
-      for (int b = 0; b < NB2; ++b)
+      for (int off = 1; off < 32; off <<= 1) {
+        const int qo = __shfl_up(qi, off, 32);
+        const bool take = e >= off && qo == qi && qi >= 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[b][r] += __shfl_xor(o[b][r], m, 64);
-    }
-    if (valid && (e & (k - 1)) == 0) {
-      float* dst = a.out + q * a.co_t;
+        for (int b = 0; b < NB2; ++b)
 #pragma unroll
-      for (int b = 0; b < NB2; ++b)
+          for (int r = 0; r < 16; ++r) {
+            const float v = __shfl_up(o[b][r], off, 32);
+            if (take) o[b][r] += v;
+          }
+      }
+      const int qn = __shfl_down(qi, 1, 32);
+      if (valid && (e == 31 || qn != qi)) {
+        const float sc = a.q_scale ? a.q_scale[q] : a.scale;
+        float* dst = a.out + q * a.co_t;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ch = 32 * b + sigma(r, h);
-          if (ch < a.co_t) dst[ch] = o[b][r] * a.scale;
-        }
+        for (int b = 0; b < NB2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ch = 32 * b + sigma(r, h);
+            if (ch < a.co_t) unsafeAtomicAdd(dst + ch, o[b][r] * sc);
+          }
+      }
+    } else {
+      // ---- reduction over the k edges of a query (adjacent lanes), one store per query and channel ----
+      for (int m = k >> 1; m >= 1; m >>= 1) {
+#pragma unroll
+        for (int b = 0; b < NB2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[b][r] += __shfl_xor(o[b][r], m, 64);
+      }
+      if (valid && (e & (k - 1)) == 0) {
+        float* dst = a.out + q * a.co_t;
+#pragma unroll
+        for (int b = 0; b < NB2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ch = 32 * b + sigma(r, h);
+            if (ch < a.co_t) dst[ch] = o[b][r] * a.scale;
+          }
+      }
     }
   }
 }
@@ -1080,19 +1110,23 @@ int launch_fwd_wave(const PcArgs& a, hipStream_t s) {
   constexpr int kLds = (P::OFF_P2T + (P::NB1 + P::NB2) * 96 + EIN * CO + P::NB2 * 32) * 4;
   static unsigned long long attr_done = 0ull;
   const int rc = once_per_device(attr_done, [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_fwd_wave_kernel<EIN, HID, CO, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(pointconv_fwd_wave_kernel<EIN, HID, CO, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+    bool ok = true;
+    for (const void* f : {reinterpret_cast<const void*>(pointconv_fwd_wave_kernel<EIN, HID, CO, false, false>),
+                          reinterpret_cast<const void*>(pointconv_fwd_wave_kernel<EIN, HID, CO, true, false>),
+                          reinterpret_cast<const void*>(pointconv_fwd_wave_kernel<EIN, HID, CO, false, true>),
+                          reinterpret_cast<const void*>(pointconv_fwd_wave_kernel<EIN, HID, CO, true, true>)})
+      ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+    return ok;
   });
   if (rc != WCN_SUCCESS) return rc;
-  const int64_t tiles = ((a.n_query << a.log2k) + 31) / 32;
+  const int64_t edges = a.edge_q ? a.n_edges : (a.n_query << a.log2k);
+  const int64_t tiles = (edges + 31) / 32;
   const int64_t wgs = (tiles + 7) / 8;
   const int grid = (int)(wgs < 256 ? wgs : 256);  // one persistent 8-wave workgroup per CU
-  if (a.lin_sc)
-    hipLaunchKernelGGL((pointconv_fwd_wave_kernel<EIN, HID, CO, true>), dim3(grid), dim3(512), kLds, s, a);
-  else
-    hipLaunchKernelGGL((pointconv_fwd_wave_kernel<EIN, HID, CO, false>), dim3(grid), dim3(512), kLds, s, a);
+#define WCN_PCW(L, R) hipLaunchKernelGGL((pointconv_fwd_wave_kernel<EIN, HID, CO, L, R>), dim3(grid), dim3(512), kLds, s, a)
+  if (a.edge_q) { if (a.lin_sc) WCN_PCW(true, true); else WCN_PCW(false, true); }
+  else { if (a.lin_sc) WCN_PCW(true, false); else WCN_PCW(false, false); }
+#undef WCN_PCW
   return launch_status();
 }
 
@@ -1178,7 +1212,7 @@ static int run_forward(PcArgs& a, float* out, hipStream_t s) {
   }();
   switch (pick_shape(a.ein_t, a.hid_t, a.co_t)) {
     case 0:
-      if (!a.edge_q && wave_fwd) return launch_fwd_wave<64, 128, 64>(a, s);
+      if (wave_fwd) return launch_fwd_wave<64, 128, 64>(a, s);
       return launch_edge<64, 128, 64, false>(a, grid, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
