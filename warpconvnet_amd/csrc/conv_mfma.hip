@@ -575,6 +575,14 @@ int conv_gather_gemm_lds(const void* in, const void* wp, void* out, const int32_
                          const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
                          float* out32, hipStream_t s);
 
+// conv_mfma_cs.hip: channel-split family, gathered rows staged through LDS (round 3)
+bool gather_gemm_cs_supported(int cin, int cout, int K, int dtype);
+int conv_gather_gemm_cs(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                        const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
+                        float* out32, hipStream_t s);
+int pack_weight_cs(const void* w, int w_is_f32, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
+                   hipStream_t s);
+
 // conv_mfma16.hip
 bool mfma16_supported(int cin, int cout, int K, int dtype);
 int conv_gather_gemm16(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
@@ -648,6 +656,8 @@ int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32
                           const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
                           float* out32, hipStream_t s) {
   if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (gather_gemm_cs_supported(cin, cout, K, dtype))  // channel-split family (conv_mfma_cs.hip)
+    return conv_gather_gemm_cs(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, dtype, out32, s);
   if (gather_gemm_lds_supported(cin, cout, K, dtype))  // rows staged through LDS (conv_mfma_lds.hip, opt-in)
     return conv_gather_gemm_lds(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, dtype, out32, s);
   if (mfma16_supported(cin, cout, K, dtype))  // 16x16x32 shape: row-shaped gathers (conv_mfma16.hip)
@@ -659,6 +669,7 @@ int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32
 int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                          hipStream_t s) {
   // the layout of the packed image follows the kernel that will consume it (a pure function of the shape)
+  if (gather_gemm_cs_supported(cin, cout, K, dtype)) return pack_weight_cs(w, 1, K, cin, cout, dtype, transpose, flip, packed, s);
   if (!gather_gemm_lds_supported(cin, cout, K, dtype) && mfma16_supported(cin, cout, K, dtype))
     return pack_weight16(w, 1, K, cin, cout, dtype, transpose, flip, packed, s);
   const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin, cout, K);
@@ -675,6 +686,7 @@ int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, in
 
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s) {
+  if (gather_gemm_cs_supported(cin, cout, K, dtype)) return pack_weight_cs(w, 0, K, cin, cout, dtype, transpose, flip, packed, s);
   if (!gather_gemm_lds_supported(cin, cout, K, dtype) && mfma16_supported(cin, cout, K, dtype))
     return pack_weight16(w, 0, K, cin, cout, dtype, transpose, flip, packed, s);
   const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin, cout, K);

@@ -1,0 +1,437 @@
+// conv_mfma_cs.hip - fused gather -> LDS -> MFMA -> store kernel for the AB (forward) and ABt (dgrad) sparse-conv GEMMs,
+// "channel-split" family (round 3): the gathered feature rows are STAGED THROUGH LDS with row-shaped requests and SHARED
+// by the waves of a workgroup, every wave owns a 32-channel slice of the output and keeps ITS weight fragments in registers.
+//
+// Why (measured in rounds 1-2): the register-gather kernel (conv_mfma.hip) is bound by the texture
+// addresser, not by HBM - a lane pulling 16-B fragments of its own row makes every wave instruction touch 32 different
+// 128-B lines (each line is visited by four instructions), and every 128-row workgroup re-fetches the whole 16 KB weight
+// slab of a step through LDS-DMA.  Here, per step (kernel offset k, 64 input channels) of a 128-row mask-sorted tile:
+//   * rows: 16 LDS-DMA wave instructions per WORKGROUP, 8 adjacent lanes per 128-B row piece (exec-masked for absent
+//     neighbours: no request), landing row-major in a ring stage; the 16-B pieces are XOR-swizzled on the source side
+//     (the DMA destination is lane-linear) so that the B-fragment ds_read_b128 (row pitch 128 B) are bank-conflict free;
+//   * weights: wave `cs` loads only W[k][64 ci][32 co of its slice] = 4 KB straight HBM/L2 -> VGPR (4 coalesced
+//     dwordx4 loads, packed lane-linear by wcn_pack_weight), double buffered in registers - no LDS hop for weights;
+//   * MFMA (v_mfma_f32_32x32x16, transposed: A = weight fragment, B = 32 rows): every wave multiplies its slice with
+//     ALL row blocks of its row group that have the offset, so the four waves of a workgroup do equal work per step
+//     (the register-gather kernel gives a wave the rows and lets it idle at the barrier when its rows lack the offset);
+//   * rows that lack the offset read a 128-B zero row in LDS instead of their stage slot (one address select per
+//     32-row block and step; no zero fills, no per-fragment selects).
+// Workgroup = 4 waves = WR row groups x WC channel slices, WC = CO / 32, tile = 128 rows for every width:
+//   CO = 128: 1 x 4, a wave holds 4 row blocks x 32 channels;  CO = 64: 2 x 2, 2 row blocks;  CO = 32: 4 x 1, 1 row block.
+//
+// Math and epilogue exactly as conv_mfma.hip (same C-ABI entry points pick the kernel by shape):
+//   out[r] = act((sum_k in[nbr[r][k]] . W[k] + bias) * scale + shift + residual).
+// Reference semantics: warpconvnet/nn/functional/sparse_conv/detail/explicit.py:22-57, 60-92; role of
+// _C.mask_gemm.fwd/.dgrad (warpconvnet/csrc/bindings/mask_gemm_bindings.cu:2074-2101); index prefetch idea
+// MaskGemm_forward_64x64x32_1s_flat.h:287-296.
+#include <cstdlib>
+
+#include "wcn_common.h"
+
+namespace wcn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 c_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 c_f16x8;
+typedef __attribute__((ext_vector_type(16))) float c_f32x16;
+
+template <typename T> struct CFrag;
+template <> struct CFrag<__bf16> {
+  typedef c_bf16x8 type;
+  static __device__ __forceinline__ c_f32x16 mfma(c_bf16x8 a, c_bf16x8 b, c_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct CFrag<_Float16> {
+  typedef c_f16x8 type;
+  static __device__ __forceinline__ c_f32x16 mfma(c_f16x8 a, c_f16x8 b, c_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int kCsWaves = 4;
+constexpr int kCsTile = 128;       // output rows per workgroup
+constexpr int kCsSlabPitch = 28;   // staged table columns (ints): kernel volumes up to 28 (3^3 = 27)
+constexpr int kCsMaxK = 28;
+constexpr int kCsCIC = 64;         // input channels per step (one 128-B row piece)
+constexpr int kCsStageBytes = kCsTile * kCsCIC * 2;  // 16 KB
+
+template <int CO, int D>
+struct CsCfg {
+  static constexpr int WC = CO / 32;            // channel slices (waves across the output width)
+  static constexpr int WR = kCsWaves / WC;      // row groups
+  static constexpr int RBW = kCsTile / 32 / WR; // 32-row blocks per wave
+  static_assert(CO == 32 || CO == 64 || CO == 128, "channel-split kernel: CO in {32, 64, 128}");
+  static constexpr size_t OFF_NBR = (size_t)D * kCsStageBytes;
+  static constexpr size_t OFF_ROWS = OFF_NBR + (size_t)kCsTile * kCsSlabPitch * 4;
+  static constexpr size_t OFF_MASK = OFF_ROWS + (size_t)kCsTile * 4;
+  static constexpr size_t OFF_WMASK = OFF_MASK + (size_t)kCsTile * 4;
+  static constexpr size_t OFF_ZERO = OFF_WMASK + 16;
+  static constexpr size_t LDS_BYTES = OFF_ZERO + 128;
+  static constexpr int OUT_PITCH = CO * 2 + 16;  // epilogue stage: +16 B keeps the b128 stage writes conflict-free
+  static_assert((size_t)kCsTile * OUT_PITCH <= OFF_ROWS, "the epilogue stage reuses the ring and the index slab");
+};
+
+// ---- weight packing: [k][chunk][cs][s][lane][j], lane = (h << 5) | m ------------------------------------------------
+//   ci = chunk*64 + 16*s + 8*h + j                      (the K index of the MFMA: natural channel order)
+//   co = cs*32 + 16*((m >> 2) & 1) + 4*(m >> 3) + (m & 3)
+// so that the C fragment of lane (h', n) holds output channels cs*32 + 16*h' + reg, reg = 0..15, of row n.
+template <typename TS, typename TD>
+__global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__ packed, int K, int cin, int cout,
+                                      int transpose, int flip) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * cin * cout;
+  if (e >= total) return;
+  const int WC = cout / 32, nchunk = cin / kCsCIC;
+  int64_t t = e;
+  const int j = (int)(t % 8); t /= 8;
+  const int lane = (int)(t % 64); t /= 64;
+  const int s = (int)(t % 4); t /= 4;
+  const int cs = (int)(t % WC); t /= WC;
+  const int chunk = (int)(t % nchunk); t /= nchunk;
+  const int k = (int)t;
+  const int h = lane >> 5, m = lane & 31;
+  const int ci = chunk * kCsCIC + 16 * s + 8 * h + j;
+  const int co = cs * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+  const int kw = flip ? (K - 1 - k) : k;
+  // not transposed: w[kw][ci][co] ([K, cin, cout]); transposed: w is the forward weight [K, cout, cin]
+  const int64_t src = transpose ? (((int64_t)kw * cout + co) * cin + ci) : (((int64_t)kw * cin + ci) * cout + co);
+  packed[e] = (TD)w[src];
+}
+
+// ---- main kernel --------------------------------------------------------------------------------------------------------
+template <typename T, int CO, int D>
+__global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restrict__ in, const T* __restrict__ wp,
+                                                                T* __restrict__ out, const int32_t* __restrict__ nbr,
+                                                                const uint32_t* __restrict__ mask,
+                                                                const int32_t* __restrict__ perm, const ConvEpilogue epi,
+                                                                int64_t n_out, int cin, int K, int kp,
+                                                                float* __restrict__ out32) {
+  typedef CsCfg<CO, D> G;
+  typedef typename CFrag<T>::type frag_t;
+  constexpr int WC = G::WC, RBW = G::RBW, SP = kCsSlabPitch, TILE = kCsTile;
+  static_assert(D == 2, "ring depth 2 (deeper rings need counted waits)");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_ring = smem;                                                     // [D][128 rows][128 B]
+  int32_t* s_nbr = reinterpret_cast<int32_t*>(smem + G::OFF_NBR);         // [TILE][SP]
+  int32_t* s_rows = reinterpret_cast<int32_t*>(smem + G::OFF_ROWS);       // [TILE]
+  uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem + G::OFF_MASK);     // [TILE]
+  uint32_t* s_wmask = reinterpret_cast<uint32_t*>(smem + G::OFF_WMASK);   // [4]: OR of the row masks per 32-row block
+  char* s_zero = smem + G::OFF_ZERO;                                       // 128 B of zeros
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, n = lane & 31;
+  const int cs = wave % WC, rg = wave / WC;  // channel slice, row group
+  const int nchunk = cin / kCsCIC;
+  const int64_t row0 = (int64_t)blockIdx.x * TILE;
+
+  // ---- output row ids (through the mask-sorted permutation), masks, index slab ----
+  if (tid < TILE) {
+    const int64_t pr = row0 + tid;
+    int32_t r = -1;
+    if (pr < n_out) r = perm ? perm[pr] : (int32_t)pr;
+    s_rows[tid] = r;
+  }
+  if (tid < 8) reinterpret_cast<int4*>(s_zero)[tid] = make_int4(0, 0, 0, 0);
+  if (tid < 4) s_wmask[tid] = 0;
+  __syncthreads();
+  {
+    uint32_t my_mask = 0;
+    if (tid < TILE) {
+      const int32_t r = s_rows[tid];
+      if (r >= 0) my_mask = mask[r];
+      s_mask[tid] = my_mask;
+      if (my_mask) atomicOr(&s_wmask[tid >> 5], my_mask);
+    }
+    // all row ids first, then all table loads, then all LDS writes (one global round trip)
+    constexpr int kVec = SP / 4;  // 16-B pieces per slab row
+    constexpr int kIter = (TILE * kVec + 255) / 256;
+    int32_t rr[kIter];
+    int4 vv[kIter];
+#pragma unroll
+    for (int t = 0; t < kIter; ++t) {
+      const int e = tid + t * 256;
+      rr[t] = (e < TILE * kVec) ? s_rows[e / kVec] : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < kIter; ++t) {
+      const int e = tid + t * 256;
+      const int c = e % kVec;
+      vv[t] = make_int4(-1, -1, -1, -1);
+      if (rr[t] >= 0 && c * 4 < kp) {  // read once: non-temporal
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * kp) + c);
+        vv[t] = make_int4(q.x, q.y, q.z, q.w);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kIter; ++t) {
+      const int e = tid + t * 256;
+      if (e < TILE * kVec) reinterpret_cast<int4*>(s_nbr + (e / kVec) * SP)[e % kVec] = vv[t];
+    }
+  }
+  __syncthreads();
+  uint32_t rb_mask[RBW];
+  uint32_t block_mask = 0u;
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb) rb_mask[rb] = __builtin_amdgcn_readfirstlane(s_wmask[rg * RBW + rb]);  // SGPR
+#pragma unroll
+  for (int q = 0; q < 4; ++q) block_mask |= s_wmask[q];
+  block_mask = __builtin_amdgcn_readfirstlane(block_mask);
+  // the DMA instructions of this wave cover tile rows [32*wave, 32*wave + 32): OR of their masks (skip empty instructions)
+  const uint32_t dma_mask = __builtin_amdgcn_readfirstlane(s_wmask[wave]);
+  // mask of the row this lane holds in the B fragment of row block rb
+  uint32_t mrow[RBW];
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb) mrow[rb] = s_mask[(rg * RBW + rb) * 32 + n];
+
+  c_f32x16 acc[RBW];
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
+
+  if (block_mask != 0u) {
+    // per-lane constants (LDS addresses as plain 32-bit integers: no generic-pointer null checks in the loop)
+    typedef const __attribute__((address_space(3))) frag_t* lds_frag_p;
+    typedef const __attribute__((address_space(3))) int32_t* lds_i32_p;
+    const uint32_t lds0 = lds_addr_of(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // wave-uniform copy (SGPR)
+    const int sw = (n >> 1) & 7;                      // swizzle of the row this lane reads
+    uint32_t boff[4];                                 // byte offset of k-slice s inside a staged row
+#pragma unroll
+    for (int s = 0; s < 4; ++s) boff[s] = (uint32_t)(((2 * s + h) ^ sw) << 4);
+    const uint32_t zaddr = lds0 + (uint32_t)G::OFF_ZERO;
+    const uint32_t rowaddr = lds0 + (uint32_t)(rg * RBW * 32 + n) * 128u;  // + stage, + rb * 4096
+    const char* wbase = reinterpret_cast<const char*>(wp) + (size_t)cs * 4096 + lane * 16;
+    const size_t wstep = (size_t)WC * 4096;           // bytes of one (k, chunk) weight slab
+    const uint32_t rowbytes = (uint32_t)cin * 2u;
+    // DMA: lane covers row (lane >> 3) of an 8-row instruction, 16-B position (lane & 7); source piece = position ^ swizzle
+    const uint32_t idxaddr = lds0 + (uint32_t)G::OFF_NBR + (uint32_t)((wave * 32 + (lane >> 3)) * SP) * 4u;
+    const char* gsrc_e = reinterpret_cast<const char*>(in) + (((lane & 7) ^ (lane >> 4)) << 4);        // even instructions
+    const char* gsrc_o = reinterpret_cast<const char*>(in) + (((lane & 7) ^ (4 + (lane >> 4))) << 4);  // odd instructions
+
+    auto issue_rows = [&](int buf, int k, int chunk) {
+      if (!((dma_mask >> k) & 1u)) return;  // wave-uniform: none of this wave's 32 DMA rows has the offset
+      const uint32_t dst = lds0 + (uint32_t)buf * kCsStageBytes + (uint32_t)wave_u * 4096u;
+      int32_t idx[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) idx[it] = *(lds_i32_p)(uintptr_t)(idxaddr + (uint32_t)(k * 4 + it * 8 * SP * 4));
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        if (idx[it] >= 0) {
+          const char* src = ((it & 1) ? gsrc_o : gsrc_e) + (uint64_t)(uint32_t)idx[it] * rowbytes + (uint32_t)(chunk * 128);
+          glds16(src, dst + it * 1024);
+        }
+      }
+    };
+    auto load_w = [&](frag_t (&w)[4], int k, int chunk) {
+      const char* p = wbase + (size_t)(k * nchunk + chunk) * wstep;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) w[s] = *reinterpret_cast<const frag_t*>(p + s * 1024);
+    };
+    // B fragments of row block rb (rows that lack the offset read the zero row); the fragments of the next active block
+    // are requested before the MFMAs of the current one
+    auto load_b = [&](frag_t (&b)[4], uint32_t sbase, int rb, int k) {
+      const uint32_t rbase = ((mrow[rb] >> k) & 1u) ? (sbase + (uint32_t)rb * 4096u) : zaddr;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[s] = *(lds_frag_p)(uintptr_t)(rbase + boff[s]);
+    };
+    auto compute = [&](const frag_t (&w)[4], int buf, int k) {
+      const uint32_t sbase = rowaddr + (uint32_t)buf * kCsStageBytes;
+      frag_t b[2][4];
+      if ((rb_mask[0] >> k) & 1u) load_b(b[0], sbase, 0, k);
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb) {
+        if (rb + 1 < RBW && ((rb_mask[rb + 1 < RBW ? rb + 1 : rb] >> k) & 1u)) load_b(b[(rb + 1) & 1], sbase, rb + 1, k);
+        if ((rb_mask[rb] >> k) & 1u) {  // wave-uniform: some row of this block has the offset
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[rb] = CFrag<T>::mfma(w[s], b[rb & 1][s], acc[rb]);
+        }
+      }
+    };
+    // step iterator over (set bits of block_mask ascending) x (channel chunks)
+    uint32_t rem = block_mask;
+    auto next_step = [&](int& k, int& chunk) -> bool {
+      if (k >= 0 && chunk + 1 < nchunk) { ++chunk; return true; }
+      if (rem == 0u) return false;
+      k = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      chunk = 0;
+      return true;
+    };
+    auto sync_step = [&]() {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), gfx9 encoding; also resets hipcc's own load scoreboard
+      __syncthreads();
+    };
+
+    frag_t Wa[4], Wb[4];
+    int k0 = -1, c0 = 0, k1 = -1, c1 = 0;
+    next_step(k0, c0);
+    issue_rows(0, k0, c0);
+    load_w(Wa, k0, c0);
+    for (;;) {
+      k1 = k0; c1 = c0;
+      const bool has1 = next_step(k1, c1);
+      sync_step();  // stage 0 has landed for every wave; every wave is done reading stage 1
+      if (has1) { issue_rows(1, k1, c1); load_w(Wb, k1, c1); }
+      compute(Wa, 0, k0);
+      if (!has1) break;
+      k0 = k1; c0 = c1;
+      const bool has0 = next_step(k0, c0);
+      sync_step();
+      if (has0) { issue_rows(0, k0, c0); load_w(Wa, k0, c0); }
+      compute(Wb, 1, k1);
+      if (!has0) break;
+    }
+  }
+
+  // ---- epilogue: lane (h, n) of wave (rg, cs) holds channels cs*32 + 16*h + q, q = 0..15, of row (rg, rb, n) ----
+  if (out32) {
+    // fp32 output (the fp32-feature path: fp16 operands, fp32 accumulate, unrounded result)
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+      const int32_t r = s_rows[(rg * RBW + rb) * 32 + n];
+      if (r < 0) continue;
+      float* dst = out32 + (int64_t)r * CO + cs * 32 + 16 * h;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float4 o = make_float4(acc[rb][4 * v + 0], acc[rb][4 * v + 1], acc[rb][4 * v + 2], acc[rb][4 * v + 3]);
+        if (epi.bias) {
+          const float4 bv = reinterpret_cast<const float4*>(epi.bias + cs * 32 + 16 * h)[v];
+          o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+        }
+        reinterpret_cast<float4*>(dst)[v] = o;
+      }
+    }
+    return;
+  }
+  __syncthreads();  // ring and index slab are dead: reuse them as the [TILE][OUT_PITCH] output stage
+  {
+    float bs[16], sc[16], sh[16];
+    const int cbase = cs * 32 + 16 * h;
+    if (epi.bias) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) bs[q] = epi.bias[cbase + q];
+    }
+    if (epi.scale) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { sc[q] = epi.scale[cbase + q]; sh[q] = epi.shift[cbase + q]; }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+      frag_t lo, hi;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float f = acc[rb][q];
+        if (epi.bias) f += bs[q];
+        if (epi.scale) f = f * sc[q] + sh[q];
+        if (epi.relu && !epi.residual) f = fmaxf(f, 0.f);  // (with a residual the activation follows the add below)
+        if (q < 8) lo[q] = (T)f; else hi[q - 8] = (T)f;
+      }
+      frag_t* sp = reinterpret_cast<frag_t*>(smem + (size_t)((rg * RBW + rb) * 32 + n) * G::OUT_PITCH + cbase * 2);
+      sp[0] = lo;
+      sp[1] = hi;
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int kLanesPerRow = CO / 8;  // 16-B pieces per output row
+    constexpr int kRowsPerInstr = 64 / kLanesPerRow;
+    const int piece = lane % kLanesPerRow, rsub = lane / kLanesPerRow;
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += kRowsPerInstr) {
+      const int row = wave * 32 + r0 + rsub;
+      const int32_t rr = s_rows[row];
+      if (rr >= 0) {
+        frag_t o = *reinterpret_cast<const frag_t*>(smem + (size_t)row * G::OUT_PITCH + piece * 16);
+        if (epi.residual) {  // residual rows are read the way the output is written: whole rows, adjacent lanes
+          const frag_t rv = __builtin_nontemporal_load(
+              reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(epi.residual) + (int64_t)rr * CO + piece * 8));
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float f = (float)o[q] + (float)rv[q];
+            if (epi.relu) f = fmaxf(f, 0.f);
+            o[q] = (T)f;
+          }
+        }
+        // streamed once: non-temporal, so the output does not push the gathered input out of the caches
+        __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)rr * CO + piece * 8));
+      }
+    }
+  }
+}
+
+template <typename T, int CO, int D>
+static int launch_cs(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                     const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
+                     hipStream_t s) {
+  typedef CsCfg<CO, D> G;
+  static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
+  const int rc = once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_cs_kernel<T, CO, D>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
+  });
+  if (rc != WCN_SUCCESS) return rc;
+  const int kp = wcn_kmap_row_pitch(K);
+  hipLaunchKernelGGL((gather_gemm_cs_kernel<T, CO, D>), dim3((unsigned)ceil_div(n_out, kCsTile)), dim3(256), G::LDS_BYTES, s,
+                     (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, out32);
+  return launch_status();
+}
+
+// WARPCONVNET_AMD_GEMM_CS: 1 (default) = shapes below take this family, 0 = the register-gather kernels (conv_mfma.hip)
+static int cs_mode() {
+  static const int v = [] {
+    const char* e = getenv("WARPCONVNET_AMD_GEMM_CS");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
+bool gather_gemm_cs_supported(int cin, int cout, int K, int dtype) {
+  if (cs_mode() == 0) return false;
+  if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
+  if (K < 1 || K > kCsMaxK) return false;
+  if (cin < kCsCIC || cin % kCsCIC != 0) return false;
+  return cout == 64 || cout == 128;
+}
+
+template <typename T>
+static int dispatch_cs(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                       const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, float* out32,
+                       hipStream_t s) {
+  switch (cout) {
+    case 64: return launch_cs<T, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 128: return launch_cs<T, 128, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    default: return WCN_ERROR_UNSUPPORTED_CONFIG;
+  }
+}
+
+int conv_gather_gemm_cs(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
+                        const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
+                        float* out32, hipStream_t s) {
+  if (!gather_gemm_cs_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (dtype == WCN_BF16) return dispatch_cs<__bf16>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+  return dispatch_cs<_Float16>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+}
+
+int pack_weight_cs(const void* w, int w_is_f32, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
+                   hipStream_t s) {
+  if (!gather_gemm_cs_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  const int64_t total = (int64_t)K * cin * cout;
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (w_is_f32) {
+    if (dtype == WCN_BF16)
+      hipLaunchKernelGGL((pack_weight_cs_kernel<float, __bf16>), grid, block, 0, s, (const float*)w, (__bf16*)packed, K, cin,
+                         cout, transpose, flip);
+    else
+      hipLaunchKernelGGL((pack_weight_cs_kernel<float, _Float16>), grid, block, 0, s, (const float*)w, (_Float16*)packed, K,
+                         cin, cout, transpose, flip);
+  } else {
+    hipLaunchKernelGGL((pack_weight_cs_kernel<uint16_t, uint16_t>), grid, block, 0, s, (const uint16_t*)w, (uint16_t*)packed,
+                       K, cin, cout, transpose, flip);
+  }
+  return launch_status();
+}
+
+}  // namespace wcn
