@@ -14,7 +14,8 @@ from typing import Optional
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libwcn_hip.so")
+# WARPCONVNET_AMD_LIB: alternative build of the same library (e.g. the phase-stamp build `make prof`)
+LIB_PATH = os.environ.get("WARPCONVNET_AMD_LIB") or os.path.join(_CSRC, "libwcn_hip.so")
 
 WCN_F32, WCN_F16, WCN_BF16 = 0, 1, 2
 WCN_ALGO_AUTO, WCN_ALGO_REF, WCN_ALGO_MFMA = 0, 1, 2

@@ -48,27 +48,37 @@ template <> struct CFrag<_Float16> {
   }
 };
 
-constexpr int kCsWaves = 4;
-constexpr int kCsTile = 128;       // output rows per workgroup
 constexpr int kCsSlabPitch = 28;   // staged table columns (ints): kernel volumes up to 28 (3^3 = 27)
 constexpr int kCsMaxK = 28;
 constexpr int kCsCIC = 64;         // input channels per step (one 128-B row piece)
-constexpr int kCsStageBytes = kCsTile * kCsCIC * 2;  // 16 KB
 
-template <int CO, int D>
+// Workgroup shape: WC = CO / 32 channel slices x WR row groups waves; a wave holds RBW 32-row blocks of its 32 channels.
+//   CO = 128: RBW 4, WR 1 -> 4 waves, 128-row tile (RBW 2: 64-row tile, half the LDS, twice the weight traffic per row)
+//   CO =  64: RBW 2, WR 2 -> 4 waves, 128-row tile;  RBW 2, WR 1 -> 2 waves, 64-row tile (same weight traffic per row)
+template <int CO, int RBW_, int WR_>
 struct CsCfg {
-  static constexpr int WC = CO / 32;            // channel slices (waves across the output width)
-  static constexpr int WR = kCsWaves / WC;      // row groups
-  static constexpr int RBW = kCsTile / 32 / WR; // 32-row blocks per wave
+  static constexpr int D = 2;                    // ring depth (deeper rings need counted waits)
+  static constexpr int WC = CO / 32;             // channel slices (waves across the output width)
+  static constexpr int WR = WR_;                 // row groups
+  static constexpr int RBW = RBW_;               // 32-row blocks per wave
+  static constexpr int WAVES = WC * WR;
+  static constexpr int NT = 64 * WAVES;          // threads
+  static constexpr int TILE = 32 * RBW * WR;     // output rows per workgroup
+  static constexpr int NBLK = TILE / 32;
+  static constexpr int DMA_ROWS = TILE / WAVES;  // rows each wave requests per step
+  static constexpr int DMA_INSTR = DMA_ROWS / 8;
+  static constexpr int STAGE_BYTES = TILE * kCsCIC * 2;
   static_assert(CO == 32 || CO == 64 || CO == 128, "channel-split kernel: CO in {32, 64, 128}");
-  static constexpr size_t OFF_NBR = (size_t)D * kCsStageBytes;
-  static constexpr size_t OFF_ROWS = OFF_NBR + (size_t)kCsTile * kCsSlabPitch * 4;
-  static constexpr size_t OFF_MASK = OFF_ROWS + (size_t)kCsTile * 4;
-  static constexpr size_t OFF_WMASK = OFF_MASK + (size_t)kCsTile * 4;
+  static_assert(DMA_ROWS % 8 == 0 && TILE % 32 == 0 && NT >= TILE, "tile shape");
+  static constexpr size_t OFF_NBR = (size_t)D * STAGE_BYTES;
+  static constexpr size_t OFF_ROWS = OFF_NBR + (size_t)TILE * kCsSlabPitch * 4;
+  static constexpr size_t OFF_MASK = OFF_ROWS + (size_t)TILE * 4;
+  static constexpr size_t OFF_WMASK = OFF_MASK + (size_t)TILE * 4;
   static constexpr size_t OFF_ZERO = OFF_WMASK + 16;
-  static constexpr size_t LDS_BYTES = OFF_ZERO + 128;
+  static constexpr size_t OFF_EPI = OFF_ZERO + 128;                     // bias / scale / shift, CO floats each
+  static constexpr size_t LDS_BYTES = OFF_EPI + 3 * (size_t)CO * 4;
   static constexpr int OUT_PITCH = CO * 2 + 16;  // epilogue stage: +16 B keeps the b128 stage writes conflict-free
-  static_assert((size_t)kCsTile * OUT_PITCH <= OFF_ROWS, "the epilogue stage reuses the ring and the index slab");
+  static_assert((size_t)TILE * OUT_PITCH <= OFF_ROWS, "the epilogue stage reuses the ring and the index slab");
 };
 
 // ---- weight packing: [k][chunk][cs][s][lane][j], lane = (h << 5) | m ------------------------------------------------
@@ -99,17 +109,17 @@ __global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__
 }
 
 // ---- main kernel --------------------------------------------------------------------------------------------------------
-template <typename T, int CO, int D>
-__global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restrict__ in, const T* __restrict__ wp,
+template <typename T, int CO, int RBW_, int WR_, int MINW>
+__global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_kernel(const T* __restrict__ in, const T* __restrict__ wp,
                                                                 T* __restrict__ out, const int32_t* __restrict__ nbr,
                                                                 const uint32_t* __restrict__ mask,
                                                                 const int32_t* __restrict__ perm, const ConvEpilogue epi,
                                                                 int64_t n_out, int cin, int K, int kp,
                                                                 float* __restrict__ out32) {
-  typedef CsCfg<CO, D> G;
+  typedef CsCfg<CO, RBW_, WR_> G;
   typedef typename CFrag<T>::type frag_t;
-  constexpr int WC = G::WC, RBW = G::RBW, SP = kCsSlabPitch, TILE = kCsTile;
-  static_assert(D == 2, "ring depth 2 (deeper rings need counted waits)");
+  constexpr int WC = G::WC, RBW = G::RBW, SP = kCsSlabPitch, TILE = G::TILE, NT = G::NT;
+  constexpr int kCsStageBytes = G::STAGE_BYTES;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_ring = smem;                                                     // [D][128 rows][128 B]
@@ -118,6 +128,7 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restr
   uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem + G::OFF_MASK);     // [TILE]
   uint32_t* s_wmask = reinterpret_cast<uint32_t*>(smem + G::OFF_WMASK);   // [4]: OR of the row masks per 32-row block
   char* s_zero = smem + G::OFF_ZERO;                                       // 128 B of zeros
+  float* s_epi = reinterpret_cast<float*>(smem + G::OFF_EPI);             // [3][CO]: bias, scale, shift
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, n = lane & 31;
@@ -134,6 +145,12 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restr
   }
   if (tid < 8) reinterpret_cast<int4*>(s_zero)[tid] = make_int4(0, 0, 0, 0);
   if (tid < 4) s_wmask[tid] = 0;
+  // per-channel epilogue terms: requested first, used last (their latency is off the critical path)
+  for (int c = tid; c < CO; c += NT) {
+    s_epi[c] = epi.bias ? epi.bias[c] : 0.f;
+    s_epi[CO + c] = epi.scale ? epi.scale[c] : 1.f;
+    s_epi[2 * CO + c] = epi.scale ? epi.shift[c] : 0.f;
+  }
   __syncthreads();
   {
     uint32_t my_mask = 0;
@@ -145,17 +162,17 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restr
     }
     // all row ids first, then all table loads, then all LDS writes (one global round trip)
     constexpr int kVec = SP / 4;  // 16-B pieces per slab row
-    constexpr int kIter = (TILE * kVec + 255) / 256;
+    constexpr int kIter = (TILE * kVec + NT - 1) / NT;
     int32_t rr[kIter];
     int4 vv[kIter];
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
-      const int e = tid + t * 256;
+      const int e = tid + t * NT;
       rr[t] = (e < TILE * kVec) ? s_rows[e / kVec] : -1;
     }
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
-      const int e = tid + t * 256;
+      const int e = tid + t * NT;
       const int c = e % kVec;
       vv[t] = make_int4(-1, -1, -1, -1);
       if (rr[t] >= 0 && c * 4 < kp) {  // read once: non-temporal
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restr
     }
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
-      const int e = tid + t * 256;
+      const int e = tid + t * NT;
       if (e < TILE * kVec) reinterpret_cast<int4*>(s_nbr + (e / kVec) * SP)[e % kVec] = vv[t];
     }
   }
@@ -176,10 +193,13 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restr
 #pragma unroll
   for (int rb = 0; rb < RBW; ++rb) rb_mask[rb] = __builtin_amdgcn_readfirstlane(s_wmask[rg * RBW + rb]);  // SGPR
 #pragma unroll
-  for (int q = 0; q < 4; ++q) block_mask |= s_wmask[q];
+  for (int q = 0; q < G::NBLK; ++q) block_mask |= s_wmask[q];
   block_mask = __builtin_amdgcn_readfirstlane(block_mask);
   // the DMA instructions of this wave cover tile rows [32*wave, 32*wave + 32): OR of their masks (skip empty instructions)
-  const uint32_t dma_mask = __builtin_amdgcn_readfirstlane(s_wmask[wave]);
+  uint32_t dma_mask = 0u;
+#pragma unroll
+  for (int q = 0; q < (G::DMA_ROWS + 31) / 32; ++q) dma_mask |= s_wmask[(wave * G::DMA_ROWS) / 32 + q];
+  dma_mask = __builtin_amdgcn_readfirstlane(dma_mask);
   // mask of the row this lane holds in the B fragment of row block rb
   uint32_t mrow[RBW];
 #pragma unroll
@@ -207,18 +227,20 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restr
     const size_t wstep = (size_t)WC * 4096;           // bytes of one (k, chunk) weight slab
     const uint32_t rowbytes = (uint32_t)cin * 2u;
     // DMA: lane covers row (lane >> 3) of an 8-row instruction, 16-B position (lane & 7); source piece = position ^ swizzle
-    const uint32_t idxaddr = lds0 + (uint32_t)G::OFF_NBR + (uint32_t)((wave * 32 + (lane >> 3)) * SP) * 4u;
-    const char* gsrc_e = reinterpret_cast<const char*>(in) + (((lane & 7) ^ (lane >> 4)) << 4);        // even instructions
-    const char* gsrc_o = reinterpret_cast<const char*>(in) + (((lane & 7) ^ (4 + (lane >> 4))) << 4);  // odd instructions
+    const uint32_t idxaddr = lds0 + (uint32_t)G::OFF_NBR + (uint32_t)((wave * G::DMA_ROWS + (lane >> 3)) * SP) * 4u;
+    // (tile row >> 1) & 7 of the row a lane requests: (lane >> 4) + 4 * (instruction index + first instruction of the wave)
+    const int first_odd = ((wave * G::DMA_ROWS) >> 3) & 1;
+    const char* gsrc_e = reinterpret_cast<const char*>(in) + (((lane & 7) ^ ((lane >> 4) + 4 * first_odd)) << 4);
+    const char* gsrc_o = reinterpret_cast<const char*>(in) + (((lane & 7) ^ ((lane >> 4) + 4 * (1 - first_odd))) << 4);
 
     auto issue_rows = [&](int buf, int k, int chunk) {
       if (!((dma_mask >> k) & 1u)) return;  // wave-uniform: none of this wave's 32 DMA rows has the offset
-      const uint32_t dst = lds0 + (uint32_t)buf * kCsStageBytes + (uint32_t)wave_u * 4096u;
-      int32_t idx[4];
+      const uint32_t dst = lds0 + (uint32_t)buf * kCsStageBytes + (uint32_t)wave_u * (G::DMA_ROWS * 128u);
+      int32_t idx[G::DMA_INSTR];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) idx[it] = *(lds_i32_p)(uintptr_t)(idxaddr + (uint32_t)(k * 4 + it * 8 * SP * 4));
+      for (int it = 0; it < G::DMA_INSTR; ++it) idx[it] = *(lds_i32_p)(uintptr_t)(idxaddr + (uint32_t)(k * 4 + it * 8 * SP * 4));
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < G::DMA_INSTR; ++it) {
         if (idx[it] >= 0) {
           const char* src = ((it & 1) ? gsrc_o : gsrc_e) + (uint64_t)(uint32_t)idx[it] * rowbytes + (uint32_t)(chunk * 128);
           glds16(src, dst + it * 1024);
@@ -287,95 +309,102 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_cs_kernel(const T* __restr
   }
 
   // ---- epilogue: lane (h, n) of wave (rg, cs) holds channels cs*32 + 16*h + q, q = 0..15, of row (rg, rb, n) ----
+  const int cbase = cs * 32 + 16 * h;
   if (out32) {
     // fp32 output (the fp32-feature path: fp16 operands, fp32 accumulate, unrounded result)
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb) {
       const int32_t r = s_rows[(rg * RBW + rb) * 32 + n];
       if (r < 0) continue;
-      float* dst = out32 + (int64_t)r * CO + cs * 32 + 16 * h;
+      float* dst = out32 + (int64_t)r * CO + cbase;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        float4 o = make_float4(acc[rb][4 * v + 0], acc[rb][4 * v + 1], acc[rb][4 * v + 2], acc[rb][4 * v + 3]);
-        if (epi.bias) {
-          const float4 bv = reinterpret_cast<const float4*>(epi.bias + cs * 32 + 16 * h)[v];
-          o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
-        }
-        reinterpret_cast<float4*>(dst)[v] = o;
+        const float4 bv = reinterpret_cast<const float4*>(s_epi + cbase)[v];
+        reinterpret_cast<float4*>(dst)[v] = make_float4(acc[rb][4 * v + 0] + bv.x, acc[rb][4 * v + 1] + bv.y,
+                                                        acc[rb][4 * v + 2] + bv.z, acc[rb][4 * v + 3] + bv.w);
       }
     }
     return;
   }
   __syncthreads();  // ring and index slab are dead: reuse them as the [TILE][OUT_PITCH] output stage
-  {
-    float bs[16], sc[16], sh[16];
-    const int cbase = cs * 32 + 16 * h;
-    if (epi.bias) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) bs[q] = epi.bias[cbase + q];
-    }
-    if (epi.scale) {
+  for (int rb = 0; rb < RBW; ++rb) {
+    frag_t lo, hi;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) { sc[q] = epi.scale[cbase + q]; sh[q] = epi.shift[cbase + q]; }
-    }
+    for (int v = 0; v < 4; ++v) {
+      const float4 bv = reinterpret_cast<const float4*>(s_epi + cbase)[v];
+      const float4 sv = reinterpret_cast<const float4*>(s_epi + CO + cbase)[v];
+      const float4 tv = reinterpret_cast<const float4*>(s_epi + 2 * CO + cbase)[v];
+      float f[4] = {(acc[rb][4 * v + 0] + bv.x) * sv.x + tv.x, (acc[rb][4 * v + 1] + bv.y) * sv.y + tv.y,
+                    (acc[rb][4 * v + 2] + bv.z) * sv.z + tv.z, (acc[rb][4 * v + 3] + bv.w) * sv.w + tv.w};
 #pragma unroll
-    for (int rb = 0; rb < RBW; ++rb) {
-      frag_t lo, hi;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float f = acc[rb][q];
-        if (epi.bias) f += bs[q];
-        if (epi.scale) f = f * sc[q] + sh[q];
-        if (epi.relu && !epi.residual) f = fmaxf(f, 0.f);  // (with a residual the activation follows the add below)
-        if (q < 8) lo[q] = (T)f; else hi[q - 8] = (T)f;
+      for (int j = 0; j < 4; ++j) {
+        if (epi.relu && !epi.residual) f[j] = fmaxf(f[j], 0.f);  // (with a residual the activation follows the add below)
+        const int q = 4 * v + j;
+        if (q < 8) lo[q] = (T)f[j]; else hi[q - 8] = (T)f[j];
       }
-      frag_t* sp = reinterpret_cast<frag_t*>(smem + (size_t)((rg * RBW + rb) * 32 + n) * G::OUT_PITCH + cbase * 2);
-      sp[0] = lo;
-      sp[1] = hi;
     }
+    frag_t* sp = reinterpret_cast<frag_t*>(smem + (size_t)((rg * RBW + rb) * 32 + n) * G::OUT_PITCH + cbase * 2);
+    sp[0] = lo;
+    sp[1] = hi;
   }
   __syncthreads();
   {
     constexpr int kLanesPerRow = CO / 8;  // 16-B pieces per output row
     constexpr int kRowsPerInstr = 64 / kLanesPerRow;
+    constexpr int kStores = G::DMA_ROWS / kRowsPerInstr;  // every wave stores TILE / WAVES rows
+    constexpr int kBatch = kStores < 4 ? kStores : 4;     // rows in flight per lane (residual loads)
     const int piece = lane % kLanesPerRow, rsub = lane / kLanesPerRow;
 #pragma unroll
-    for (int r0 = 0; r0 < 32; r0 += kRowsPerInstr) {
-      const int row = wave * 32 + r0 + rsub;
-      const int32_t rr = s_rows[row];
-      if (rr >= 0) {
-        frag_t o = *reinterpret_cast<const frag_t*>(smem + (size_t)row * G::OUT_PITCH + piece * 16);
-        if (epi.residual) {  // residual rows are read the way the output is written: whole rows, adjacent lanes
-          const frag_t rv = __builtin_nontemporal_load(
-              reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(epi.residual) + (int64_t)rr * CO + piece * 8));
+    for (int j0 = 0; j0 < kStores; j0 += kBatch) {
+      int32_t orow[kBatch];
+      frag_t ov[kBatch], rv[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) orow[j] = s_rows[wave * G::DMA_ROWS + (j0 + j) * kRowsPerInstr + rsub];
+      if (epi.residual) {  // residual rows are read the way the output is written: whole rows, adjacent lanes, all in flight
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j)
+          if (orow[j] >= 0)
+            rv[j] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(
+                reinterpret_cast<const T*>(epi.residual) + (int64_t)orow[j] * CO + piece * 8));
+      }
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j)
+        ov[j] = *reinterpret_cast<const frag_t*>(
+            smem + (size_t)(wave * G::DMA_ROWS + (j0 + j) * kRowsPerInstr + rsub) * G::OUT_PITCH + piece * 16);
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        if (orow[j] < 0) continue;
+        frag_t o = ov[j];
+        if (epi.residual) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            float f = (float)o[q] + (float)rv[q];
+            float f = (float)o[q] + (float)rv[j][q];
             if (epi.relu) f = fmaxf(f, 0.f);
             o[q] = (T)f;
           }
         }
         // streamed once: non-temporal, so the output does not push the gathered input out of the caches
-        __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)rr * CO + piece * 8));
+        __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * CO + piece * 8));
       }
     }
   }
 }
 
-template <typename T, int CO, int D>
+template <typename T, int CO, int RBW, int WR, int MINW>
 static int launch_cs(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                      const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
                      hipStream_t s) {
-  typedef CsCfg<CO, D> G;
+  typedef CsCfg<CO, RBW, WR> G;
   static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
   const int rc = once_per_device(attr_done, [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_cs_kernel<T, CO, D>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_cs_kernel<T, CO, RBW, WR, MINW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
   });
   if (rc != WCN_SUCCESS) return rc;
   const int kp = wcn_kmap_row_pitch(K);
-  hipLaunchKernelGGL((gather_gemm_cs_kernel<T, CO, D>), dim3((unsigned)ceil_div(n_out, kCsTile)), dim3(256), G::LDS_BYTES, s,
-                     (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, out32);
+  hipLaunchKernelGGL((gather_gemm_cs_kernel<T, CO, RBW, WR, MINW>), dim3((unsigned)ceil_div(n_out, G::TILE)), dim3(G::NT),
+                     G::LDS_BYTES, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, out32);
   return launch_status();
 }
 
@@ -400,9 +429,12 @@ template <typename T>
 static int dispatch_cs(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                        const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, float* out32,
                        hipStream_t s) {
+  // Measured on the 1 M-voxel scenes (uniform / surface, in-step us): CO = 128 with 128-row tiles 208 / 251 vs 64-row tiles
+  // 238 / 272 (twice the weight traffic per row); CO = 64 with 2 waves x 64 rows 256 / 374 vs 4 waves x 128 rows 264 / 378
+  // vs 2 waves x 128 rows 275 / 392.
   switch (cout) {
-    case 64: return launch_cs<T, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 128: return launch_cs<T, 128, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 64: return launch_cs<T, 64, 2, 1, 4>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 128: return launch_cs<T, 128, 4, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
