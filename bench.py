@@ -106,18 +106,58 @@ def cpu_baseline(n_sample, seed):
                        f"+ fwd+bwd {t3 - t2:.2f}s (torch CPU, {torch.get_num_threads()} threads)")
 
 
-def secondary_configs(dev):
-    """BASELINE configs 3 and 5 as secondary figures of the same run (never the headline): MinkUNet-14 forward + backward
-    on surface scenes of 200 k and 1 M voxels, and PointConv(32->64, kNN 16) on 200 k points followed by voxelisation and
-    a depthwise k=3 convolution, forward + backward (with the one-kernel edge pipeline, and composed from separate kernels).
-    Milliseconds per iteration (HIP events, 3 warm-up + 5 timed)."""
-    from tests.minkunet14 import MinkUNet14
+def conv_bytes(rec, e=2):
+    """SURVEY.md §8(d) byte model of one convolution layer, forward + dgrad + wgrad (16-bit features, fp32 weight gradient)."""
+    cin, cout, K, n_in, n_out, L = rec["cin"], rec["cout"], rec["K"], rec["n_in"], rec["n_out"], rec["pairs"]
+    w = K * cin * cout
+    fwd = L * cin * e + w * e + n_out * cout * e + (4 * K * n_out if K > 1 else 0)
+    dgrad = L * cout * e + w * e + n_in * cin * e + (4 * K * n_in if K > 1 else 0)
+    wgrad = L * (cin + cout) * e + 4 * w + (8 * L if K > 1 else 0)
+    return fwd + dgrad + wgrad
+
+
+def secondary_configs(dev, args):
+    """BASELINE configs 3 and 5 and the S scene of config 2 as secondary figures of the same run (never the headline):
+    the headline step on a surface-like 1 M-voxel scene; MinkUNet-14 forward + backward on surface scenes of 200 k and 1 M
+    voxels; PointConv(32->64, kNN 16) on 200 k points followed by voxelisation and a depthwise k=3 convolution, forward +
+    backward (with the one-kernel edge pipeline, and composed from separate kernels).  HIP events, warm-up + timed."""
+    from bench_models import ConvLayerRecorder, MinkUNet14
     from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
     from warpconvnet_amd.geometry.types.points import Points
     from warpconvnet_amd.geometry.types.voxels import Voxels
     from warpconvnet_amd.nn.modules import PointConv, SparseDepthwiseConv3d
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
 
     out = {}
+    # ---- config 2 on generator S (ScanNet-like sheets, ~9 pairs per voxel): the headline step, module API, fresh map per step
+    cs = torch.from_numpy(scene_surface(args.voxels, seed=1000)).to(dev)
+    ns = cs.shape[0]
+    g = torch.Generator().manual_seed(7)
+    fs = torch.randn(ns, CIN, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    gs = torch.randn(ns, COUT, generator=g).to(dev, torch.bfloat16)
+    offs = torch.tensor([0, ns], dtype=torch.int32)
+    torch.manual_seed(0)
+    conv_s = SparseConv3d(CIN, COUT, 3, bias=True).to(dev)
+    pairs = [0]
+
+    def surface_step():
+        for p in conv_s.parameters():
+            p.grad = None
+        fs.grad = None
+        x = Voxels(cs, fs, offsets=offs)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv_s(x)
+        y.batched_features.batched_tensor.backward(gs)
+        if not pairs[0]:
+            pairs[0] = int(next(iter(x.cache.values())).offsets[-1])
+
+    ms = time_events(surface_step, 50, warmup=10)
+    ab = algorithmic_bytes(ns, pairs[0])
+    out["surface_1M"] = {"value": round(ns / (ms * 1e-3) / 1e6, 3), "unit": "M voxels/s", "ms_per_step": round(ms, 4),
+                         "voxels": ns, "pairs_per_voxel": round(pairs[0] / ns, 2),
+                         "whole_step_hbm_frac": round(sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- config 3: MinkUNet-14 ----
     torch.manual_seed(0)
     net = MinkUNet14(3, 20).to(dev)
     for label, n_vox in (("200k", 200_000), ("1M", 1_000_000)):
@@ -132,14 +172,32 @@ def secondary_configs(dev):
                 y = net(Voxels(c, f, offsets=off))
             y.feature_tensor.float().square().mean().backward()
 
-        out[f"minkunet14_{label}_ms"] = round(time_events(unet_step, 5, warmup=3), 3)
+        rec = ConvLayerRecorder(net)
+        unet_step()
+        rec.close()
+        ms = time_events(unet_step, 5, warmup=3)
+        out[f"minkunet14_{label}_ms"] = round(ms, 3)
         out[f"minkunet14_{label}_voxels"] = n
+        layer_bytes = [conv_bytes(r) for r in rec.records]
+        top = max(range(len(layer_bytes)), key=lambda i: layer_bytes[i])
+        tr = rec.records[top]
+        out[f"minkunet14_{label}_roofline"] = {
+            "bound": "hbm", "scope": "all convolution layers, forward + dgrad + wgrad (SURVEY 8d byte model per layer; BatchNorm / ReLU "
+                                     "passes and map builds not counted), over the whole iteration's time",
+            "algorithmic_bytes": int(sum(layer_bytes)), "achieved": round(sum(layer_bytes) / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(sum(layer_bytes) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "conv_layers": len(layer_bytes),
+            "dominant_layer": f"{tr['cin']}->{tr['cout']} K={tr['K']} N_out={tr['n_out']} pairs={tr['pairs']}",
+            "dominant_layer_bytes": int(layer_bytes[top]),
+        }
+
+    # ---- config 5: PointConv + depthwise ----
     g = torch.Generator().manual_seed(5)
     n = 200_000
     pts = (torch.rand(n, 3, generator=g) * torch.tensor([50.0, 50.0, 4.0])).to(dev)
     pf = torch.randn(n, 32, generator=g).to(dev)
     torch.manual_seed(0)
-    pconv = PointConv(32, 64, RealSearchConfig(mode="knn", knn_k=16)).to(dev)
+    knn_k = 16
+    pconv = PointConv(32, 64, RealSearchConfig(mode="knn", knn_k=knn_k)).to(dev)
     dw = SparseDepthwiseConv3d(64, 3).to(dev)
 
     def point_step():
@@ -149,8 +207,19 @@ def secondary_configs(dev):
         y = dw(o.to_voxels(0.25))
         y.feature_tensor.sum().backward()
 
-    out["pointconv_dw_ms"] = round(time_events(point_step, 5, warmup=3), 3)
+    ms = time_events(point_step, 5, warmup=3)
+    out["pointconv_dw_ms"] = round(ms, 3)
     out["pointconv_dw_points"] = n
+    # edge MLP on the fp32 matrix cores: Linear(e_in -> hidden) + Linear(hidden -> out) per edge; the backward recomputes the
+    # forward and adds the data-gradient and weight-gradient products (3x the forward's multiply-adds)
+    lin = [m for m in pconv.edge_transform_mlp.modules() if isinstance(m, torch.nn.Linear)] if hasattr(pconv, "edge_transform_mlp") else []
+    macs = sum(m.in_features * m.out_features for m in lin)
+    flops = 2.0 * n * knn_k * macs * 4 if macs else None
+    if flops:
+        out["pointconv_dw_roofline"] = {"bound": "mfma", "kernel": "pointconv edge kernels (forward + backward), fp32 v_mfma_f32_32x32x2_f32",
+                                        "flops": flops, "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                        "frac": round(flops / (ms * 1e-3) / 1e12 / 157.3, 4),
+                                        "note": "edge-MLP products only, over the whole step's time (kNN, voxelisation, depthwise conv included in the time)"}
     # the same step with the edge pipeline composed from separate kernels (what the reference's op sequence costs here)
     from warpconvnet_amd.nn.functional import point_conv as fpc
     fpc._ENABLED = False
@@ -161,7 +230,7 @@ def secondary_configs(dev):
     return out
 
 
-def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, value, ms_per_step):
+def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, value, ms_per_step, second_half):
     """Rank 0: per-kernel timing IN THE STEP (HIP events on the launch stream between the four phases of an unrolled step,
     so every kernel meets the cache state it meets in the module step), roofline figures, secondary configs, CPU baseline."""
     from warpconvnet_amd import _lib
@@ -174,7 +243,7 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
     L = int(km.offsets[-1])
     X = feats.detach()
     W = conv.weight.detach().to(torch.bfloat16)
-    it = max(5, args.steps)
+    it = max(5, min(args.steps, 40))
     Lc = _lib.lib()
     stream = _lib.stream_handle(dev)
     wp_f = hip_gemm.pack_weight(W, False, False)
@@ -234,8 +303,8 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
         "wgrad": N * (CIN + COUT) * e + 4 * KVOL * CIN * COUT + 4 * KVOL * N,
     }
     names = {
-        "fwd": "gather_gemm_mfma_kernel<bf16,64,128> (fwd)",
-        "dgrad": "gather_gemm_mfma_kernel<bf16,64,64> (dgrad)",
+        "fwd": "gather_gemm_cs_kernel<bf16,CO=128> (fwd)",
+        "dgrad": "gather_gemm_cs_kernel<bf16,CO=64> (dgrad)",
         "wgrad": "wgrad_mfma_kernel<bf16,64,128> (+ wgrad_reduce)",
         "kmap": "kernel map build (all launches)",
     }
@@ -251,13 +320,13 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
     dom_key = max(("fwd", "dgrad", "wgrad"), key=lambda k: times[k])
     dom = entry(dom_key)
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
     if N == 1_000_000 and args.scene == "uniform" and os.path.exists(pmc_file):
         with open(pmc_file) as f:
             pmc = json.load(f)
         if dom_key in pmc:
             traffic = pmc[dom_key]["hbm_bytes"]
-            traffic_src = "profiles/r02_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+            traffic_src = "profiles/r03_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)"
 
     # map-cached variant (networks amortise the map over the layers of a resolution level)
     x_cached = Voxels(coords, feats, offsets=offsets)
@@ -281,7 +350,9 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "settle_steps": args.settle,
         "ms_per_step": round(ms_per_step, 4),
+        "second_half": second_half,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -290,14 +361,14 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
         "config": {
             "workload": f"configs[1]: one {N}-voxel {'uniform (U)' if args.scene == 'uniform' else 'surface-like (S, secondary)'} scene per GPU, SparseConv3d 64->128 k=3, bf16 autocast, "
                         "kernel-map build + AB fwd + ABt dgrad + AtB wgrad per step",
-            "voxels_per_gpu": N, "pairs_per_scene": L, "coord_order": args.coord_order, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)",
+            "voxels_per_gpu": N, "pairs_per_scene": L, "coord_order": args.coord_order, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)" + ("" if world == 1 else "; N > 1 has run under gloo on CPU only before this launch (no earlier RCCL measurement exists)"),
         },
         "roofline": {
             "bound": "hbm", "kernel": names[dom_key], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac"], "compulsory_frac": dom["compulsory_frac"], "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
             "timing": "HIP events on the launch stream between the phases of an unrolled step (map build -> fwd -> dgrad -> wgrad), "
-                      "i.e. in-step; profiles/r02_kernel_trace_stats.md is the rocprofv3 trace of this command",
+                      "i.e. in-step; profiles/r03_kernel_trace_stats.md is the rocprofv3 trace of this command",
         },
         "roofline_all": {names[k]: entry(k) for k in ("fwd", "dgrad", "wgrad", "kmap")},
         "phases_ms": {"kmap": round(t_kmap, 4), "fwd_kernel": round(tk_fwd, 4), "dgrad_kernel": round(tk_dgrad, 4),
@@ -309,7 +380,7 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
     }
     if world == 1 and not args.no_secondary:
         try:
-            result["secondary"] = secondary_configs(dev)
+            result["secondary"] = secondary_configs(dev, args)
         except Exception as exc:  # the headline line must come out even if a secondary workload fails
             result["secondary"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and not args.no_cpu_baseline:
@@ -317,15 +388,113 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
     return result
 
 
-def main():
+def build_workload(args, dev, rank, conv_kwargs=None):
+    """Resident inputs: one scene per rank (weak scaling), identical weights on every rank."""
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    c_np = (scene_u if args.scene == "uniform" else scene_surface)(args.voxels, seed=1000 + rank)
+    if args.coord_order == "block":
+        key = (((c_np[:, 0] >> 4) * 4096 + (c_np[:, 1] >> 4)) * 4096 + (c_np[:, 2] >> 4)).astype(np.int64)
+        c_np = c_np[np.lexsort((c_np[:, 2], c_np[:, 1], c_np[:, 0], key))]
+    coords = torch.from_numpy(np.ascontiguousarray(c_np)).to(dev)
+    N = coords.shape[0]
+    g = torch.Generator().manual_seed(rank)
+    fdtype = torch.bfloat16 if dev.type == "cuda" else torch.float32
+    # features resident in device memory; a leaf that requires grad, so the backward pass runs ABt (dgrad) as well as AtB
+    feats = torch.randn(N, CIN, generator=g).to(dev, fdtype).requires_grad_(True)
+    grad_out = torch.randn(N, COUT, generator=g).to(dev, fdtype)
+    offsets = torch.tensor([0, N], dtype=torch.int32)
+    torch.manual_seed(0)
+    conv = SparseConv3d(CIN, COUT, 3, bias=True, **(conv_kwargs or {})).to(dev)
+    return coords, feats, grad_out, offsets, conv, [p for p in conv.parameters()]
+
+
+def make_step(dev, world, coords, feats, grad_out, offsets, conv, params, attach=None):
+    """The timed step, exactly as `main` runs it: fresh geometry -> kernel map rebuilt -> forward -> backward (dgrad + wgrad) ->
+    (N > 1) the flat-bucket gradient all-reduce launched from the autograd hook of the last gradient.  `attach(voxels)` lets
+    the CPU test (tests/test_dist_gloo.py: gloo, explicit backend) supply an oracle-built kernel map; None on the GPU."""
+    from warpconvnet_amd.dist import GradientBuckets
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+
+    buckets = GradientBuckets(params) if world > 1 else None
+
+    def step():
+        if buckets is not None:
+            buckets.zero_grad()
+        else:
+            for p in params:
+                p.grad = None
+        feats.grad = None
+        x = Voxels(coords, feats, offsets=offsets)  # fresh geometry -> kernel map rebuilt every step
+        if attach is not None:
+            attach(x)
+        if dev.type == "cuda":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = conv(x)
+        else:
+            y = conv(x)
+        y.batched_features.batched_tensor.backward(grad_out)
+        if buckets is not None:
+            buckets.finish()
+
+    return step, buckets
+
+
+def timed_loop(step, args, dev, world):
+    """W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides; the maximum over ranks.
+    A fresh process (and a fresh box) runs its first ~60 steps at cold clocks with first-use allocator / pinned-memory /
+    kernel-module costs (830-860 instead of 960-1 020 M voxels/s over a 20-step window).  Nothing hidden: `--settle` (default
+    0, printed as settle_steps) adds untimed steps, the default K = 200 timed steps carry the cold start inside the timed
+    region, and `second_half` reports the rate of the last K/2 steps (HIP events, no extra synchronisation)."""
+    cuda = dev.type == "cuda"
+    sync = torch.cuda.synchronize if cuda else (lambda: None)
+    for _ in range(args.settle):
+        step()
+    sync()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    ev_mid = torch.cuda.Event(enable_timing=True) if cuda else None
+    ev_end = torch.cuda.Event(enable_timing=True) if cuda else None
+    half = args.steps // 2
+    t0 = time.perf_counter()
+    t_mid = t0
+    for i in range(args.steps):
+        if i == half:
+            if cuda:
+                ev_mid.record()
+            t_mid = time.perf_counter()
+        step()
+    if cuda:
+        ev_end.record()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    ms_half = (ev_mid.elapsed_time(ev_end) if cuda else (time.perf_counter() - t_mid) * 1e3) / max(1, args.steps - half)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, ms_half
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle", type=int, default=0,
+                    help="extra untimed steps in front of the warm-up (reported as settle_steps): a fresh process on a fresh box "
+                         "runs its first ~60 steps at cold clocks / first-use allocator cost")
     ap.add_argument("--voxels", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)  # the whole configs[1] scene: ~10-15 s of CPU work
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the MinkUNet-14 / PointConv secondary timings")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the surface-scene / MinkUNet-14 / PointConv secondary timings")
     ap.add_argument("--coord-order", choices=["generator", "block"], default="generator",
                     help="generator: rows in the order the reference's generator emits them (the headline workload); "
                          "block: the same scene with rows sorted by 16^3 block then x,y,z (what a voxelised scan looks like) - "
@@ -333,8 +502,11 @@ def main():
     ap.add_argument("--scene", choices=["uniform", "surface"], default="uniform",
                     help="uniform: the reference-style generator U the metric is quoted on; surface: generator S of "
                          "SURVEY.md §8d (ScanNet-like sheets, ~2x the pairs per voxel) - a secondary workload")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -346,76 +518,23 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from warpconvnet_amd import _lib
-    from warpconvnet_amd.dist import GradientBuckets
-    from warpconvnet_amd.geometry.types.voxels import Voxels
-    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
-    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
 
     _lib.lib()  # fail loudly if the HIP extension is missing
 
-    # ---- resident inputs: one scene per GPU (weak scaling), identical weights on every rank ----
-    c_np = (scene_u if args.scene == "uniform" else scene_surface)(args.voxels, seed=1000 + rank)
-    if args.coord_order == "block":
-        key = (((c_np[:, 0] >> 4) * 4096 + (c_np[:, 1] >> 4)) * 4096 + (c_np[:, 2] >> 4)).astype(np.int64)
-        c_np = c_np[np.lexsort((c_np[:, 2], c_np[:, 1], c_np[:, 0], key))]
-    coords = torch.from_numpy(np.ascontiguousarray(c_np)).to(dev)
+    coords, feats, grad_out, offsets, conv, params = build_workload(args, dev, rank)
     N = coords.shape[0]
-    g = torch.Generator().manual_seed(rank)
-    # bf16 features resident in HBM; a leaf that requires grad, so the backward pass runs ABt (dgrad) as well as AtB
-    feats = torch.randn(N, CIN, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
-    grad_out = torch.randn(N, COUT, generator=g).to(dev, torch.bfloat16)
-    offsets = torch.tensor([0, N], dtype=torch.int32)
-    torch.manual_seed(0)
-    conv = SparseConv3d(CIN, COUT, 3, bias=True).to(dev)
-    params = [p for p in conv.parameters()]
     # N > 1: persistent flat gradient bucket, the all-reduce is launched from the autograd hook of the last gradient
-    buckets = GradientBuckets(params) if world > 1 else None
-
-    def step():
-        if buckets is not None:
-            buckets.zero_grad()
-        else:
-            for p in params:
-                p.grad = None
-        feats.grad = None
-        x = Voxels(coords, feats, offsets=offsets)  # fresh geometry -> kernel map rebuilt every step
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            y = conv(x)
-        y.batched_features.batched_tensor.backward(grad_out)
-        if buckets is not None:
-            buckets.finish()
-
-    # steady state: a fresh process (and a fresh box) starts with cold clocks, an empty caching allocator and first-use
-    # pinned-memory / kernel-module costs; 5 warm-up steps are 5 ms of GPU time, not enough to get past them (first run on
-    # a new box measured 830-860 instead of 960-980 M voxels/s).  A fixed, untimed settle phase runs before the W warm-up
-    # steps the contract asks for.
-    for _ in range(60):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    step, _ = make_step(dev, world, coords, feats, grad_out, offsets, conv, params)
+    elapsed, ms_half = timed_loop(step, args, dev, world)
+    second_half = {"value": round(N * world / (ms_half * 1e-3) / 1e6, 3), "ms_per_step": round(ms_half, 4),
+                   "steps": args.steps - args.steps // 2,
+                   "note": "rank 0's last K/2 timed steps between two HIP events (steady state; the headline value covers all K)"}
     ms_per_step = elapsed / args.steps * 1e3
     value = N * world * args.steps / elapsed / 1e6
 
     result = None
     if rank == 0:
-        result = report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, value, ms_per_step)
+        result = report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, value, ms_per_step, second_half)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,6 +9,7 @@ import os
 import tempfile
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -149,3 +150,81 @@ def test_allreduce_is_noop_without_process_group():
     p = torch.nn.Parameter(torch.ones(3))
     p.grad = torch.ones(3)
     assert allreduce_gradients([p]) == 0 and p.grad.tolist() == [1.0, 1.0, 1.0]
+
+
+def _bench_worker(rank, world, init_file, out_dir):
+    """bench.py's own N > 1 code path (`build_workload` -> `make_step` -> `timed_loop`), with the process group on gloo, the
+    tensors on the CPU and the convolution on the explicit backend with an oracle-built map: the functions the driver's
+    `torch.distributed.run ... bench.py --gpus N` executes, minus the device."""
+    import bench
+    from tests.test_host_api import _attach_oracle_map
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--voxels", "600"])
+    dev = torch.device("cpu")
+    kw = dict(fwd_algo="explicit_gemm", dgrad_algo="explicit_gemm", wgrad_algo="explicit_gemm")
+    coords, feats, grad_out, offsets, conv, params = bench.build_workload(args, dev, rank, conv_kwargs=kw)
+    step, buckets = bench.make_step(dev, world, coords, feats, grad_out, offsets, conv, params, attach=_attach_oracle_map)
+    assert buckets is not None and buckets.world == world
+    elapsed, ms_half = bench.timed_loop(step, args, dev, world)
+    torch.save({"w": conv.weight.grad.clone(), "b": conv.bias.grad.clone(), "elapsed": elapsed, "ms_half": ms_half,
+                "n": coords.shape[0], "coords": coords.clone()}, os.path.join(out_dir, f"bench{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_wiring_under_gloo():
+    """`bench.py --gpus 2` end to end on CPU: different scenes per rank (weak scaling), the step's gradient buckets reduce to
+    the same averaged gradient on both ranks = the mean of the two single-process gradients, the timed loop returns the
+    maximum over ranks."""
+    import bench
+    from tests.test_host_api import _attach_oracle_map
+
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_bench_worker, args=(2, init_file, tmp), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(tmp, "bench0.pt")), torch.load(os.path.join(tmp, "bench1.pt"))
+    assert not torch.equal(r0["coords"], r1["coords"])  # one scene per rank
+    assert r0["elapsed"] == r1["elapsed"] > 0 and r0["ms_half"] > 0  # max over ranks, agreed
+    torch.testing.assert_close(r0["w"], r1["w"], rtol=0, atol=0)
+    torch.testing.assert_close(r0["b"], r1["b"], rtol=0, atol=0)
+    # single process: the same two workloads, gradients averaged by hand
+    kw = dict(fwd_algo="explicit_gemm", dgrad_algo="explicit_gemm", wgrad_algo="explicit_gemm")
+    args = bench.parse_args(["--gpus", "1", "--steps", "1", "--warmup", "0", "--voxels", "600"])
+    gw, gb = [], []
+    for rank in range(2):
+        coords, feats, grad_out, offsets, conv, params = bench.build_workload(args, torch.device("cpu"), rank, conv_kwargs=kw)
+        step, buckets = bench.make_step(torch.device("cpu"), 1, coords, feats, grad_out, offsets, conv, params, attach=_attach_oracle_map)
+        assert buckets is None
+        step()
+        gw.append(conv.weight.grad.clone())
+        gb.append(conv.bias.grad.clone())
+    torch.testing.assert_close(r0["w"], (gw[0] + gw[1]) / 2, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(r0["b"], (gb[0] + gb[1]) / 2, rtol=1e-4, atol=1e-3)
+
+
+def test_gradient_buckets_refuse_unsynchronised_accumulation():
+    """Two backward() passes before finish() used to leave the second pass's gradients out of the (already launched)
+    all-reduce silently; now the second pass raises, and `no_sync()` is the way to accumulate."""
+    from warpconvnet_amd.dist import GradientBuckets
+
+    lin = torch.nn.Linear(4, 3)
+    buckets = GradientBuckets(lin.parameters(), average=False)
+    x = torch.randn(5, 4)
+    lin(x).sum().backward()
+    with pytest.raises(RuntimeError, match="second gradient before finish"):
+        lin(x).sum().backward()
+    buckets.finish()
+    buckets.zero_grad()
+    with buckets.no_sync():
+        lin(x).sum().backward()
+    lin(x).sum().backward()
+    buckets.finish()
+    ref = torch.nn.Linear(4, 3)
+    ref.load_state_dict(lin.state_dict())
+    (ref(x).sum() * 2).backward()
+    torch.testing.assert_close(lin.weight.grad, ref.weight.grad)
+    buckets.remove()
+    assert buckets._handles == []

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.minkunet14 import MinkUNet14
+from bench_models import MinkUNet14
 from tests.util import rel_max_err, scene_surface
 
 pytestmark = pytest.mark.gpu

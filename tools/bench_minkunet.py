@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from bench import scene_surface
-from tests.minkunet14 import MinkUNet14
+from bench_models import MinkUNet14
 from warpconvnet_amd.geometry.types.voxels import Voxels
 
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs ON the GPU box (through gpurun): rocprofv3 kernel trace + separate PMC passes of the default bench command
 # (counters in their own runs, never combined with runtime / marker traces), summaries into gpurun_out/prof/ as text.
-# Usage: bash tools/collect_profiles.sh [round-tag, default r02]
-R=${1:-r02}
+# Usage: bash tools/collect_profiles.sh [round-tag, default r03]
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof
 CMD="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
@@ -21,7 +21,11 @@ python tools/rocpd_stats.py gpurun_out/prof/${R}_write_results.db pmc > gpurun_o
 python tools/rocpd_stats.py gpurun_out/prof/${R}_mfma_results.db mfma > gpurun_out/prof/${R}_pmc_mfma_busy.md
 python tools/rocpd_stats.py gpurun_out/prof/${R}_sq_results.db sq > gpurun_out/prof/${R}_pmc_wave_cycles.md
 python tools/rocpd_stats.py traffic gpurun_out/prof/${R}_fetch_results.db gpurun_out/prof/${R}_write_results.db > gpurun_out/prof/${R}_pmc_traffic.json
-rm -f gpurun_out/prof/*_results.db   # the summaries travel back, the databases do not fit the 64 MiB return budget
+# the summaries travel back; of the databases only the kernel trace of the headline command does (the others do not fit the
+# 64 MiB return budget)
+mv gpurun_out/prof/${R}_trace_results.db gpurun_out/prof/${R}_trace_results.keep
+rm -f gpurun_out/prof/*_results.db
+mv gpurun_out/prof/${R}_trace_results.keep gpurun_out/prof/${R}_trace_results.db
 head -30 gpurun_out/prof/${R}_kernel_trace_stats.md
 cat gpurun_out/prof/${R}_bench_line.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['phases_ms'], d['roofline'])"
 grep -h "\"metric\"" gpurun_out/prof/${R}_secondary.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('secondary'))"

@@ -8,6 +8,7 @@ absent, ``lib()`` raises.  Tensors cross the boundary as raw device pointers + s
 import ctypes
 import os
 import subprocess
+import threading
 from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p
 from typing import Optional
 
@@ -213,7 +214,7 @@ class _GuardedLib:
             return fn
 
         def guarded(*args, _fn=fn):
-            dev = _CALL_DEVICE[0]
+            dev = getattr(_CALL_DEVICE, "dev", None)
             if dev is None or dev == torch.cuda.current_device():
                 return _fn(*args)
             with torch.cuda.device(dev):
@@ -225,7 +226,7 @@ class _GuardedLib:
 
 
 _HOST_ONLY = {"wcn_status_string"}
-_CALL_DEVICE = [None]  # device index of the stream handed out last (single-threaded dispatch: evaluated per call)
+_CALL_DEVICE = threading.local()  # .dev = device index of the stream this THREAD asked for last (evaluated per call)
 
 
 def build(verbose: bool = False) -> str:
@@ -283,7 +284,7 @@ def stream_handle(device: torch.device) -> int:
     idx = device.index
     if idx is None:
         idx = torch.cuda.current_device()
-    _CALL_DEVICE[0] = idx
+    _CALL_DEVICE.dev = idx
     if _RAW_STREAM is not None:
         return _RAW_STREAM(idx)
     return torch.cuda.current_stream(device).cuda_stream

@@ -538,18 +538,8 @@ static int launch_gather_gemm(const void* in, const void* wp, void* out, const i
   return launch_status();
 }
 
-// Output widths 96 / 128: 32 rows per wave (128-row tiles, 64 / 48 accumulator registers, three workgroups per CU instead
-// of two).  Round 1 measured this as a wash; with the round-2 index-slab / epilogue code it is 4-6 % faster on both scene
-// types (forward 64->128: 237 vs 253 us in-step on the uniform scene, 293 vs 304 us on the surface scene).  Width 64 keeps
-// 64 rows per wave (already three workgroups per CU; 32 rows: 277 vs 270 us).  WARPCONVNET_AMD_GEMM_ROWS32=0 switches back.
-static bool rows_per_wave_32() {
-  static const bool v = [] {
-    const char* e = getenv("WARPCONVNET_AMD_GEMM_ROWS32");
-    return e ? atoi(e) != 0 : true;
-  }();
-  return v;
-}
-
+// Output widths 96 / 128 run 32 rows per wave (128-row tiles, 64 / 48 accumulator registers, three workgroups per CU
+// instead of two): 4-6 % faster than 64 rows per wave on both scene types (round 2).  Width 64 keeps 64 rows per wave.
 template <typename T, int CIC>
 static int dispatch_co(int cout, const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                        const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
@@ -557,23 +547,13 @@ static int dispatch_co(int cout, const void* in, const void* wp, void* out, cons
   switch (cout) {
     case 32: return launch_gather_gemm<T, CIC, 32, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 64: return launch_gather_gemm<T, CIC, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
-    case 96:
-      if (rows_per_wave_32()) return launch_gather_gemm<T, CIC, 96, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
-      return launch_gather_gemm<T, CIC, 96, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
-    case 128:
-      if (rows_per_wave_32()) return launch_gather_gemm<T, CIC, 128, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
-      return launch_gather_gemm<T, CIC, 128, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 96: return launch_gather_gemm<T, CIC, 96, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
+    case 128: return launch_gather_gemm<T, CIC, 128, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 192: return launch_gather_gemm<T, CIC, 192, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 256: return launch_gather_gemm<T, CIC, 256, 1>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
-
-// conv_mfma_lds.hip
-bool gather_gemm_lds_supported(int cin, int cout, int K, int dtype);
-int conv_gather_gemm_lds(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                         const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
-                         float* out32, hipStream_t s);
 
 // conv_mfma_cs.hip: channel-split family, gathered rows staged through LDS (round 3)
 bool gather_gemm_cs_supported(int cin, int cout, int K, int dtype);
@@ -591,18 +571,11 @@ int conv_gather_gemm16(const void* in, const void* wp, void* out, const int32_t*
 int pack_weight16(const void* w, int w_is_f32, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                   hipStream_t s);
 
-// reduction chunk per step.  128 when the output is narrow (accumulators <= 64 registers leave room for two 64-register
-// row buffers): a 128 -> 64 dgrad then runs one step per offset instead of two - half the drains and barriers.
-static int chunk128_mode() {
-  static const int v = [] {
-    const char* e = getenv("WARPCONVNET_AMD_GEMM_CIC128");
-    return e ? atoi(e) : 0;  // measured: 128 -> 64 dgrad 317 vs 265 us in-step - more loads in flight per step stall the issue
-  }();
-  return v;
-}
+// reduction chunk per step: 64 channels when they divide cin (measured optimum between loads in flight per wave and steps
+// per tile: a 128 -> 64 dgrad with one 128-channel step per offset 317 us, with 32-channel steps 314 us, vs 265 us)
 int mfma_chunk_for(int cin, int cout, int K) {
-  if (cin % 128 == 0 && cout <= 64 && K <= 32 && chunk128_mode() > 0) return 128;  // (the multi-word-mask instance spills)
-  if (cin % 64 == 0 && chunk128_mode() >= 0) return 64;  // (-1: dev switch, 32-channel steps)
+  (void)cout; (void)K;
+  if (cin % 64 == 0) return 64;
   if (cin % 32 == 0) return 32;
   if (cin % 16 == 0) return 16;
   return 0;
@@ -626,9 +599,6 @@ static int dispatch_cic(int cin, int cout, const void* in, const void* wp, void*
                         const uint32_t* mask, const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int K, float* out32,
                         hipStream_t s, int groups = 1) {
   switch (mfma_chunk_for(cin, cout, K)) {
-    case 128:
-      if (cout == 32) return launch_gather_gemm<T, 128, 32, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
-      return launch_gather_gemm<T, 128, 64, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 64: return dispatch_co<T, 64>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 32: return dispatch_co<T, 32>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
     case 16: return dispatch_co<T, 16>(cout, in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s, groups);
@@ -658,8 +628,6 @@ int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32
   if (!mfma_gather_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   if (gather_gemm_cs_supported(cin, cout, K, dtype))  // channel-split family (conv_mfma_cs.hip)
     return conv_gather_gemm_cs(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, dtype, out32, s);
-  if (gather_gemm_lds_supported(cin, cout, K, dtype))  // rows staged through LDS (conv_mfma_lds.hip, opt-in)
-    return conv_gather_gemm_lds(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, dtype, out32, s);
   if (mfma16_supported(cin, cout, K, dtype))  // 16x16x32 shape: row-shaped gathers (conv_mfma16.hip)
     return conv_gather_gemm16(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, dtype, out32, s);
   if (dtype == WCN_BF16) return dispatch_cic<__bf16>(cin, cout, in, wp, out, nbr, mask, perm, epi, n_out, K, out32, s);
@@ -670,9 +638,8 @@ int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, in
                          hipStream_t s) {
   // the layout of the packed image follows the kernel that will consume it (a pure function of the shape)
   if (gather_gemm_cs_supported(cin, cout, K, dtype)) return pack_weight_cs(w, 1, K, cin, cout, dtype, transpose, flip, packed, s);
-  if (!gather_gemm_lds_supported(cin, cout, K, dtype) && mfma16_supported(cin, cout, K, dtype))
-    return pack_weight16(w, 1, K, cin, cout, dtype, transpose, flip, packed, s);
-  const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin, cout, K);
+  if (mfma16_supported(cin, cout, K, dtype)) return pack_weight16(w, 1, K, cin, cout, dtype, transpose, flip, packed, s);
+  const int cic = mfma_chunk_for(cin, cout, K);
   if (cic == 0 || cout % 32 != 0 || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   const int64_t total = (int64_t)K * cin * cout;
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
@@ -687,9 +654,8 @@ int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, in
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s) {
   if (gather_gemm_cs_supported(cin, cout, K, dtype)) return pack_weight_cs(w, 0, K, cin, cout, dtype, transpose, flip, packed, s);
-  if (!gather_gemm_lds_supported(cin, cout, K, dtype) && mfma16_supported(cin, cout, K, dtype))
-    return pack_weight16(w, 0, K, cin, cout, dtype, transpose, flip, packed, s);
-  const int cic = gather_gemm_lds_supported(cin, cout, K, dtype) ? 32 : mfma_chunk_for(cin, cout, K);
+  if (mfma16_supported(cin, cout, K, dtype)) return pack_weight16(w, 0, K, cin, cout, dtype, transpose, flip, packed, s);
+  const int cic = mfma_chunk_for(cin, cout, K);
   if (cic == 0 || cout % 32 != 0 || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   const int64_t total = (int64_t)K * cin * cout;
   // bf16 and f16 are both 2-byte moves

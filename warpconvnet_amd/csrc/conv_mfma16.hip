@@ -92,18 +92,11 @@ struct GG16 {
   static constexpr size_t STAGE_BYTES = (size_t)kMWaves * 16 * PITCH;
   static constexpr size_t OFF_NBR = 2 * (size_t)SLAB_BYTES > STAGE_BYTES ? 2 * (size_t)SLAB_BYTES : STAGE_BYTES;
   static constexpr size_t OFF_ROWS = OFF_NBR + (size_t)TILE * kMMaxKp * 4;
-  static constexpr size_t OFF_TSTAGE = OFF_ROWS + (size_t)TILE * 4 + 128;    // [kMWaves][2][1 KiB] operand transposes (ROWS)
-  static constexpr size_t LDS_BYTES = OFF_TSTAGE + (size_t)kMWaves * 2048;
+  static constexpr size_t LDS_BYTES = OFF_ROWS + (size_t)TILE * 4 + 128;
   typedef typename MFrag<T>::type frag_t;
 };
 
-// ROWS: gathers are ROW-SHAPED - lane l takes the 16-B piece (l & 3) of row (l >> 2) of the 16-row group, four ADJACENT
-// lanes per 64 contiguous bytes, which the address pipeline merges (tools/gather_probe.hip, data resident in cache:
-// 25 TB/s chip-wide against 8 TB/s for operand-shaped loads, i.e. ~25 instead of ~77 clk per instruction, and the
-// 32x32x16 kernels spend all their time there) - and each fragment is moved into MFMA operand order right before its
-// MFMAs by one ds_write_b128 + one ds_read_b128 through a 1-KiB wave-private LDS stage (XOR-swizzled, conflict free,
-// 16 LDS clocks; the ds_bpermute version of the same transpose was 4 crossbar instructions per fragment and lost).
-template <typename T, int CIC, int CO, int RG, bool MULTI, bool ROWS>
+template <typename T, int CIC, int CO, int RG, bool MULTI>
 __global__ __launch_bounds__(256, 2) void gather_gemm16_kernel(const T* __restrict__ in, const T* __restrict__ wp,
                                                                T* __restrict__ out, const int32_t* __restrict__ nbr,
                                                                const uint32_t* __restrict__ mask,
@@ -119,7 +112,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm16_kernel(const T* __restri
   int32_t* s_nbr = reinterpret_cast<int32_t*>(smem + G::OFF_NBR);    // [TILE][kpw]
   int32_t* s_rows = reinterpret_cast<int32_t*>(smem + G::OFF_ROWS);  // [TILE]
   uint32_t* s_gmask = reinterpret_cast<uint32_t*>(s_rows + TILE);    // [kMWaves * RG] OR of the row masks per 16-row group
-  char* s_tst = smem + G::OFF_TSTAGE + (threadIdx.x >> 6) * 2048;     // this wave's two transpose stages
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
@@ -224,11 +216,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm16_kernel(const T* __restri
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) {
           if (RG > 1 && !((rg_mask[rg] >> k) & 1u)) continue;  // wave-uniform: no row of this group has offset k
-          const int32_t idx = s_nbr[(grp(rg) * 16 + (ROWS ? (lane >> 2) : n)) * kpw + k];
+          const int32_t idx = s_nbr[(grp(rg) * 16 + n) * kpw + k];
 #ifdef WCN_ABL_LOCAL
-          const T* p = in + (int64_t)(idx & 8191) * cin + chunk * CIC + 8 * (ROWS ? (lane & 3) : g);
+          const T* p = in + (int64_t)(idx & 8191) * cin + chunk * CIC + 8 * g;
 #else
-          const T* p = in + (int64_t)idx * cin + chunk * CIC + 8 * (ROWS ? (lane & 3) : g);
+          const T* p = in + (int64_t)idx * cin + chunk * CIC + 8 * g;
 #endif
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
@@ -244,21 +236,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm16_kernel(const T* __restri
         if (!((wave_mask >> k) & 1u)) return;
         const frag_t* wl = reinterpret_cast<const frag_t*>(s_w + (size_t)buf * G::SLAB_BYTES) + lane;
         // weight fragments of output block cb+1 are read from LDS while the MFMAs of block cb run
-        // (ROWS) loaded as (row l >> 2, piece l & 3), wanted as (row n, piece g): stage slot = piece ^ ((row >> 1) & 3)
-        const int wr_off = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) << 4);
-        const int rd_off = n * 64 + ((g ^ ((n >> 1) & 3)) << 4);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           frag_t bt[RG];
 #pragma unroll
-          for (int rg = 0; rg < RG; ++rg) {
-            bt[rg] = bf[rg][c];
-            if (ROWS && (RG == 1 || ((rg_mask[rg] >> k) & 1u))) {
-              char* st = s_tst + (rg & 1) * 1024;  // LDS operations of one wave execute in order: no wait between the two
-              *reinterpret_cast<frag_t*>(st + wr_off) = bf[rg][c];
-              bt[rg] = *reinterpret_cast<const frag_t*>(st + rd_off);
-            }
-          }
+          for (int rg = 0; rg < RG; ++rg) bt[rg] = bf[rg][c];
           frag_t a_cur = wl[(c * NCB) * 64], a_nxt = a_cur;
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) {
@@ -397,33 +379,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm16_kernel(const T* __restri
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-// WARPCONVNET_AMD_GEMM_16 = 0: never; 1 (default): for the channel shapes the 32x32x16 kernels do not cover; 2: for every
-// shape this family takes.  Measured on MI355X (1 M voxels, bf16, round 2): 64->128 forward 212 vs 200 us, 128->64 dgrad
-// 228 vs 231 us - the halved line visits do not show, both families sit at ~5 TB/s of real gather / table / store traffic,
-// so the older kernels keep the shapes they have and this family widens the coverage (cout 16, 48, 160, 384, 512).
-static int mfma16_mode() {
-  static const int v = [] {
-    const char* e = getenv("WARPCONVNET_AMD_GEMM_16");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-static int ilv16() {
-  static const int v = [] {
-    const char* e = getenv("WARPCONVNET_AMD_GEMM_16_ILV");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-// Row-shaped gathers + LDS operand transpose (template parameter ROWS): a measured alternative kept behind a compile
-// flag.  MI355X, 1 M voxels, bf16, isolated: 64->128 forward 248 vs 238 us, 128->64 dgrad 282 vs 269 us - and still
-// 239 / 277 us with every gather redirected into a 1 MiB window (tools/gather_probe.hip: 23 TB/s there), so the
-// gather path is not what bounds this kernel.
-#ifdef WCN_GEMM16_ROWS
-static constexpr bool kRows16 = true;
-#else
-static constexpr bool kRows16 = false;
-#endif
+// This family takes the channel shapes the other two gather-GEMM families do not cover (cout 16, 48, 160, 384, 512, ...).
+// Measured on MI355X (1 M voxels, bf16, round 2) where both apply: 64->128 forward 212 vs 200 us, 128->64 dgrad 228 vs
+// 231 us - a wash, so the older kernels keep their shapes.  (Row-shaped gathers with an LDS or ds_bpermute operand
+// transpose in front of the MFMAs were measured too: 248 / 282 and 227 / 284 us - dropped.)
 bool mfma32_shape(int cin, int cout);  // conv_mfma.hip
 
 // reduction chunk per step: 64 channels when they divide cin and the two weight slabs stay within 64 KB, else 32
@@ -431,8 +390,7 @@ static int chunk16(int cin, int cout) { return (cin % 64 == 0 && 2 * 64 * cout *
 
 // Shapes this kernel family takes.  ONE pure function of the shape for the weight packer and the launcher.
 bool mfma16_supported(int cin, int cout, int K, int dtype) {
-  const int mode = mfma16_mode();
-  if (mode == 0 || (mode == 1 && mfma32_shape(cin, cout))) return false;
+  if (mfma32_shape(cin, cout)) return false;
   if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
   if (K < 1 || K > kMMaxK) return false;
   if (cin < 32 || cin % 32 != 0) return false;
@@ -451,19 +409,19 @@ static int launch16(const void* in, const void* wp, void* out, const int32_t* nb
   static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
   const int rc = once_per_device(attr_done, [] {
     bool ok = true;
-    for (const void* f : {reinterpret_cast<const void*>(gather_gemm16_kernel<T, CIC, CO, RG, false, kRows16>),
-                          reinterpret_cast<const void*>(gather_gemm16_kernel<T, CIC, CO, RG, true, kRows16>)})
+    for (const void* f : {reinterpret_cast<const void*>(gather_gemm16_kernel<T, CIC, CO, RG, false>),
+                          reinterpret_cast<const void*>(gather_gemm16_kernel<T, CIC, CO, RG, true>)})
       ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
     return ok;
   });
   if (rc != WCN_SUCCESS) return rc;
   const unsigned grid = (unsigned)ceil_div(n_out, G::TILE);
   if (mw == 1)
-    hipLaunchKernelGGL((gather_gemm16_kernel<T, CIC, CO, RG, false, kRows16>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32, ilv16());
+    hipLaunchKernelGGL((gather_gemm16_kernel<T, CIC, CO, RG, false>), dim3(grid), dim3(256), G::LDS_BYTES, s,
+                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32, 1);
   else
-    hipLaunchKernelGGL((gather_gemm16_kernel<T, CIC, CO, RG, true, kRows16>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32, ilv16());
+    hipLaunchKernelGGL((gather_gemm16_kernel<T, CIC, CO, RG, true>), dim3(grid), dim3(256), G::LDS_BYTES, s,
+                       (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, mw, out32, 1);
   return launch_status();
 }
 

@@ -451,9 +451,8 @@ static int dispatch_wgrad(const void* x, const void* dy, float* dw, const int32_
   // 128 input channels: two 64-wide tiles instead of one 128-wide.  dY is then streamed twice (+43 % algorithmic traffic at
   // 128 -> 96), but the 128 x 96 / 128 x 128 tiles spill (22 / 24 VGPRs at the 256-register limit) and run at 0.49 of the
   // roofline against 0.87 for 64 x 128: measured on MinkUNet-14 at 1 M voxels, 128 -> 96: 320 -> 272 us per call,
-  // 128 -> 128: 50 -> 31 us.  WARPCONVNET_AMD_WGRAD_CIT128=1 switches back.
-  static const bool wide = [] { const char* e = getenv("WARPCONVNET_AMD_WGRAD_CIT128"); return e && atoi(e) != 0; }();
-  if (cit == 128 && !wide) cit = 64;
+  // 128 -> 128: 50 -> 31 us.
+  if (cit == 128) cit = 64;
   switch (cit) {
     case 32: return dispatch_wgrad_co<T, 32>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
     case 64: return dispatch_wgrad_co<T, 64>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);

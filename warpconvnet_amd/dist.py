@@ -116,9 +116,8 @@ class GradientBuckets:
                 size += nbytes
             if cur:
                 self._make_bucket(cur, dtype, device)
-        self._handles = []
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._hook)
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        self._accumulate = False
         self._reset()
 
     def _make_bucket(self, plist, dtype, device):
@@ -162,10 +161,39 @@ class GradientBuckets:
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)  # the gradient arrived as a fresh tensor: move it into the bucket
             p.grad = v
-        if id(p) not in b["seen"]:
-            b["seen"].add(id(p))
-            b["ready"] += 1
-            self._launch_ready()
+        if self._accumulate:
+            return  # no_sync(): gradients pile up in the buckets, nothing is launched until the next synchronised backward
+        if b["launched"] or id(p) in b["seen"]:
+            # a second backward() before finish(): its gradients were added into a buffer whose all-reduce is already in
+            # flight (or done) and would never be reduced - refuse instead of training on silently wrong gradients
+            raise RuntimeError(
+                "GradientBuckets: a parameter received a second gradient before finish() - call finish() after every "
+                "synchronised backward(), and wrap the accumulation micro-steps in `with buckets.no_sync():`")
+        b["seen"].add(id(p))
+        b["ready"] += 1
+        self._launch_ready()
+
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it only accumulate into the buckets (no
+        collective is launched); the first backward outside it - followed by ``finish()`` - reduces the sum."""
+        outer = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                self_inner.prev = outer._accumulate
+                outer._accumulate = True
+
+            def __exit__(self_inner, *exc):
+                outer._accumulate = self_inner.prev
+                return False
+
+        return _NoSync()
+
+    def remove(self):
+        """Detach the autograd hooks (the gradients stay views of the buckets until they are reassigned)."""
+        for h in self._handles:
+            h.remove()
+        self._handles = []
 
     @torch.no_grad()
     def finish(self) -> int:

@@ -133,7 +133,12 @@ class IntSearchResult:
         event.synchronize()
         self._pending = None
         K = self._num_offsets
-        on_flags(int(meta_host[K + 1]))
+        flags = int(meta_host[K + 1])
+        on_flags(flags)
+        refresh = getattr(self, "_refresh_flags", None)
+        if refresh is not None:  # what the builder had to assume while the flags were in flight (duplicate coordinates)
+            refresh(flags)
+            self._refresh_flags = None
         self._offsets = meta_host[: K + 1].clone()
         n = int(self._offsets[-1])
         self._in_maps = self._in_maps[:n]

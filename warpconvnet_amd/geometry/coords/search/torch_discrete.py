@@ -129,12 +129,11 @@ def _first_half(full: IntSearchResult) -> IntSearchResult:
     return IntSearchResult(full.in_maps_device[:n].clone(), full.out_maps_device[:n].clone(), offs, identity_map_index=c)
 
 
-_LAZY_PAIRS = os.environ.get("WARPCONVNET_AMD_KMAP_LAZY_PAIRS", "auto")  # pair lists written on first use: auto = under no_grad
-_SPIN_POLLS = int(os.environ.get("WARPCONVNET_AMD_KMAP_SPIN", "4000"))  # ~0.1 us each: up to ~0.4 ms of spinning
+_SPIN_POLLS = 4000  # polls of the pinned READY word, ~0.1 us each: up to ~0.4 ms of spinning before the ordinary event wait
 
 
 # binned builder: does this process see scenes with >= 4 voxels per occupied 8^3 block?  (size of the first-try block table)
-_BINNED_HINT = {"div": int(os.environ.get("WARPCONVNET_AMD_KMAP_BLOCK_DIV", "4"))}  # block-table bound = N / div, grown to N / 4 and N on TABLE_FULL (16: quarter the workspace, same speed)
+_BINNED_HINT = {"div": 16}  # block-table bound = N / div (0.15 GB of workspace per million voxels), grown to N / 4 and N on TABLE_FULL
 
 
 @torch.compiler.disable
@@ -335,7 +334,7 @@ def generate_kernel_map(
         result = IntSearchResult._from_pending(
             in_maps, out_maps, meta_host, event, K, identity,
             lambda flags, n=N, c=table_capacity: PackedHashTable.raise_for_flags(flags, n, c))
-    elif _LAZY_PAIRS == "1" or (_LAZY_PAIRS == "auto" and not need_pairs):
+    elif not need_pairs:
         # the pair lists (CSR by offset) are written on first use: the forward and dgrad kernels read the neighbour table,
         # only wgrad and the container API need the lists, so a caller that will not run a weight gradient (need_pairs =
         # False: the convolution under no_grad) skips the 49 us scatter.  Not in training: run later, between dgrad and
@@ -355,6 +354,16 @@ def generate_kernel_map(
     # duplicate OUTPUT rows (a submanifold map over repeated coordinates) share their input rows per offset: the
     # [N_in, K] reverse table has one slot per (input row, offset), so dgrad then goes through the pair lists
     result._has_duplicates = bool(same_tensor and has_duplicates)
+    if async_ok:
+        # the flags are still in flight: duplicates were assumed above; once the mirror arrives (poll / first host access)
+        # the map gets its real properties back, so dgrad returns to the k-flipped table instead of the pair-list path
+        def _refresh(flags, r=result, ident=(K // 2 if (odd and unit_stride and N == M) else None)):
+            dup = bool(flags & _lib.WCN_FLAG_DUPLICATE_COORD)
+            r._symmetric = r._self_exact = bool(same_tensor and odd and unit_stride and not dup)
+            r._has_duplicates = bool(same_tensor and dup)
+            if not dup:
+                r.identity_map_index = ident
+        result._refresh_flags = _refresh
     result._num_in, result._num_out = N, M
     result._hashtable = table
     result._kernel_size = ksize

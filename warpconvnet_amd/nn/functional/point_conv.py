@@ -36,6 +36,8 @@ def _mlp_parts(mlp: nn.Module):
 def fused_edge_supported(mlp: nn.Module, in_feats: Tensor, q_feats: Tensor, nrel: int, k: int, reduction: str) -> bool:
     if not _ENABLED or not in_feats.is_cuda or reduction not in ("mean", "sum"):
         return False
+    if in_feats.shape[0] == 0 or q_feats.shape[0] == 0:  # empty inputs: the composed path returns the empty result
+        return False
     parts = _mlp_parts(mlp)
     if parts is None:
         return False
@@ -51,7 +53,8 @@ def _packed_params(mlp: nn.Module, parts) -> Tensor:
     lin1, ln1, lin2, ln2, sc = parts
     ps = (lin1.weight, lin1.bias, ln1.weight, ln1.bias, lin2.weight, lin2.bias, ln2.weight, ln2.bias,
           sc.weight if sc is not None else None, sc.bias if sc is not None else None)
-    key = tuple((p.data_ptr(), p._version) if p is not None else None for p in ps)
+    # (in-place writes through p.data leave this key unchanged: hip_gemm.invalidate_packed(module) after such updates)
+    key = tuple((p.data_ptr(), p._version, p.device) if p is not None else None for p in ps)
     hit = getattr(mlp, "_wcn_pc_packed", None)
     if hit is not None and hit[0] == key:
         return hit[1]

@@ -102,16 +102,21 @@ def pack_weight(weight: Tensor, transpose: bool, flip: bool, dtype: Optional[tor
 
     The image of a PARAMETER (a leaf that requires grad) is kept on the tensor object itself and reused while its version
     counter stands - inference, gradient accumulation, several micro-batches per optimizer step, a layer applied more than
-    once; any in-place update bumps ``_version`` and the next use repacks.  Temporaries (autocast copies, computed
-    weights) are never remembered: the cache lives and dies with the parameter object, there is no global table."""
+    once; any in-place update bumps ``_version`` and the next use repacks.  The key also carries the storage address and
+    the device, so ``module.to(device)`` / ``.double()`` / ``p.data = ...`` (which keep the Parameter object and its
+    version) repack.  NOT seen: in-place writes through ``p.data`` (``p.data.copy_``, an EMA swap, an optimizer that
+    updates ``p.data``) - they leave version, address and device unchanged; call ``invalidate_packed(module_or_params)``
+    after such an update.  Temporaries (autocast copies, computed weights) are never remembered: the cache lives and
+    dies with the parameter object, there is no global table."""
     K, c_in, c_out = weight.shape
     kin, kout = (c_out, c_in) if transpose else (c_in, c_out)  # kernel-side channel roles
     dtype = dtype or weight.dtype
     key = (dtype, bool(transpose), bool(flip))
+    stamp = (weight._version, weight.data_ptr(), weight.device)
     cache = getattr(weight, "_wcn_packed", None)
     if cache is not None:
         hit = cache.get(key)
-        if hit is not None and hit[0] == weight._version:
+        if hit is not None and hit[0] == stamp:
             return hit[1]
     packed = _pack_weight_uncached(weight, K, kin, kout, transpose, flip, dtype)
     if weight.requires_grad and weight.is_leaf:
@@ -121,8 +126,21 @@ def pack_weight(weight: Tensor, transpose: bool, flip: bool, dtype: Optional[tor
                 weight._wcn_packed = cache
             except AttributeError:
                 return packed
-        cache[key] = (weight._version, packed)
+        cache[key] = (stamp, packed)
     return packed
+
+
+def invalidate_packed(obj) -> None:
+    """Drop the cached packed weight images of a module's parameters (or of an iterable of tensors): needed after in-place
+    updates through ``p.data`` (EMA swaps, ``p.data.copy_``), which no version counter records."""
+    params = obj.parameters() if hasattr(obj, "parameters") else obj
+    for p in params:
+        for attr in ("_wcn_packed", "_wcn_packed_grouped", "_wcn_pc_packed"):
+            if hasattr(p, attr):
+                try:
+                    delattr(p, attr)
+                except AttributeError:
+                    pass
 
 
 def _pack_weight_uncached(weight: Tensor, K: int, kin: int, kout: int, transpose: bool, flip: bool,
@@ -385,10 +403,11 @@ def _pack_grouped(weight: Tensor, transpose: bool, flip: bool, dtype: torch.dtyp
     K, G, cg_in, cg_out = weight.shape
     kin, kout = (cg_out, cg_in) if transpose else (cg_in, cg_out)
     key = ("grouped", dtype, bool(transpose), bool(flip))
+    stamp = (weight._version, weight.data_ptr(), weight.device)
     cache = getattr(weight, "_wcn_packed", None)
     if cache is not None:
         hit = cache.get(key)
-        if hit is not None and hit[0] == weight._version:
+        if hit is not None and hit[0] == stamp:
             return hit[1]
     w = weight.contiguous()
     if w.dtype not in (torch.float32, dtype):
@@ -406,7 +425,7 @@ def _pack_grouped(weight: Tensor, transpose: bool, flip: bool, dtype: torch.dtyp
                 weight._wcn_packed = cache
             except AttributeError:
                 return packed
-        cache[key] = (weight._version, packed)
+        cache[key] = (stamp, packed)
     return packed
 
 

@@ -129,6 +129,10 @@ class PointConv(BaseSpatialModule):
             uniform, k = False, 1
         fin, fq = in_pc.feature_tensor, query_pc.feature_tensor.view(-1, query_pc.num_channels)
         nrel = 3 if self.use_rel_pos else 0
+        if torch.is_autocast_enabled():  # the one-kernel path computes in fp32: under autocast the composed path sets the dtypes
+            return None
+        if nrel and (in_pc.coordinate_tensor.requires_grad or query_pc.coordinate_tensor.requires_grad):
+            return None  # the kernel has no coordinate gradient: the composed path differentiates the relative positions
         if not fused_edge_supported(self.edge_transform_mlp, fin, fq, nrel, k, self.reductions[0]):
             return None
         if nidx.ndim == 2:
