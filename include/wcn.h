@@ -214,7 +214,9 @@ int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype);
 
 /* Packed weight image consumed by the MFMA kernels (fragment order, zero padding).  `transpose`=1
  * packs w[k]^T (dgrad); `flip`=1 additionally reverses k (dgrad of a submanifold map reuses the
- * forward table: rnbr[n][k] == nbr[n][K-1-k]).  Returns bytes needed / fills `packed`. */
+ * forward table: rnbr[n][k] == nbr[n][K-1-k]).  Returns bytes needed / fills `packed`.  `cin` / `cout` are the kernel-side
+ * roles (reduce over cin, produce cout); the image holds num_offsets * round_up(cin, 64) * cout elements (the channel-split
+ * kernels reduce in 64-channel chunks and zero-pad a trailing 32-channel chunk) - size `packed` with wcn_packed_weight_bytes. */
 size_t wcn_packed_weight_bytes(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose);
 int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype,
                     int32_t transpose, int32_t flip, void* packed, wcn_stream_t stream);

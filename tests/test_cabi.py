@@ -51,6 +51,7 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_pointconv_supported(24, 24, 0, 128, 64, 16, 1) == 1 and L.wcn_pointconv_supported(32, 32, 0, 128, 64, 12, 0) == 0
     assert L.wcn_pointconv_grad_floats(64, 128, 64, 1) - L.wcn_pointconv_grad_floats(64, 128, 64, 0) == 64 * 64 + 64
     assert L.wcn_packed_weight_bytes(27, 64, 128, _lib.WCN_BF16, 0) == 27 * 64 * 128 * 2
+    assert L.wcn_packed_weight_bytes(27, 96, 96, _lib.WCN_BF16, 0) == 27 * 128 * 96 * 2  # trailing 32-channel chunk zero-padded
     assert L.wcn_conv_wgrad_workspace(27, 64, 128, _lib.WCN_ALGO_MFMA) > 27 * 64 * 128 * 4
     assert L.wcn_mask_argsort_workspace(1000) > 3 * 4000 and L.wcn_kmap_binned_workspace(1000, 250) > 250 * 2048
     assert L.wcn_kmap_binned_supported(_lib.i3((4, 4, 2)), _lib.i3((1, 1, 1))) == 0  # K % 32 == 0: hash path

@@ -1,0 +1,84 @@
+"""Dev tool: where the HOST time of a MinkUNet-14 iteration goes (the network is host-bound below ~1 M voxels).
+Prints forward / backward host-enqueue time and a cProfile table of the forward (main thread) and of the backward
+(autograd worker thread, profiled through threading.setprofile).  GPU box only.
+
+    python tools/host_profile.py [voxels]
+"""
+import cProfile
+import os
+import pstats
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from bench import scene_surface
+from bench_models import MinkUNet14
+from warpconvnet_amd.geometry.types.voxels import Voxels
+
+dev = torch.device("cuda:0")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+c = torch.from_numpy(scene_surface(N, seed=3)).to(dev)
+n = c.shape[0]
+feats = torch.randn(n, 3, device=dev)
+torch.manual_seed(0)
+net = MinkUNet14(3, 20).to(dev)
+off = torch.tensor([0, n], dtype=torch.int32)
+
+
+def fwd():
+    net.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = net(Voxels(c, feats, offsets=off))
+    return y.feature_tensor.float().square().mean()
+
+
+for _ in range(3):
+    fwd().backward()
+torch.cuda.synchronize()
+tf = tb = 0.0
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = fwd()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    loss.backward()
+    t3 = time.perf_counter()
+    tf += t1 - t0
+    tb += t3 - t2
+print(f"{n} voxels: host enqueue forward {tf * 100:.2f} ms, backward {tb * 100:.2f} ms per iteration")
+
+pr = cProfile.Profile()
+pr.enable()
+losses = [fwd() for _ in range(5)]
+pr.disable()
+print("---- forward (5 iterations), by tottime")
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+
+profs = {}
+
+
+def hook(frame, event, arg):  # per-thread profiler for the autograd worker
+    tid = threading.get_ident()
+    if tid not in profs:
+        profs[tid] = cProfile.Profile()
+        profs[tid].enable()
+    return None
+
+
+threading.setprofile(hook)
+for l in losses:
+    l.backward()
+threading.setprofile(None)
+torch.cuda.synchronize()
+for tid, p in profs.items():
+    p.disable()
+    print(f"---- backward thread {tid} (5 iterations), by tottime")
+    try:
+        pstats.Stats(p).sort_stats("tottime").print_stats(25)
+    except Exception as e:
+        print("no data", e)

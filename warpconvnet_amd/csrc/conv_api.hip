@@ -64,9 +64,10 @@ int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype) {
 }
 
 size_t wcn_packed_weight_bytes(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose) {
-  (void)transpose;
+  (void)transpose;  // cin / cout are the kernel-side roles already (reduce over cin, produce cout)
   if (num_offsets < 1 || cin < 1 || cout < 1 || !dtype_ok(dtype)) return 0;
-  return (size_t)num_offsets * cin * cout * dtype_size(dtype);
+  // the channel-split kernels reduce in 64-channel chunks: a trailing 32-channel chunk is zero-padded in the image
+  return (size_t)num_offsets * ((cin + 63) / 64 * 64) * cout * dtype_size(dtype);
 }
 
 int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose,

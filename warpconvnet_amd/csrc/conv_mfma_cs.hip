@@ -68,7 +68,7 @@ struct CsCfg {
   static constexpr int DMA_ROWS = TILE / WAVES;  // rows each wave requests per step
   static constexpr int DMA_INSTR = DMA_ROWS / 8;
   static constexpr int STAGE_BYTES = TILE * kCsCIC * 2;
-  static_assert(CO == 32 || CO == 64 || CO == 128, "channel-split kernel: CO in {32, 64, 128}");
+  static_assert(CO == 32 || CO == 64 || CO == 96 || CO == 128, "channel-split kernel: CO in {32, 64, 96, 128}");
   static_assert(DMA_ROWS % 8 == 0 && TILE % 32 == 0 && NT >= TILE, "tile shape");
   static constexpr size_t OFF_NBR = (size_t)D * STAGE_BYTES;
   static constexpr size_t OFF_ROWS = OFF_NBR + (size_t)TILE * kCsSlabPitch * 4;
@@ -89,9 +89,9 @@ template <typename TS, typename TD>
 __global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__ packed, int K, int cin, int cout,
                                       int transpose, int flip) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)K * cin * cout;
+  const int WC = cout / 32, nchunk = (cin + kCsCIC - 1) / kCsCIC;  // a last chunk of 32 channels is zero-padded to 64
+  const int64_t total = (int64_t)K * nchunk * kCsCIC * cout;
   if (e >= total) return;
-  const int WC = cout / 32, nchunk = cin / kCsCIC;
   int64_t t = e;
   const int j = (int)(t % 8); t /= 8;
   const int lane = (int)(t % 64); t /= 64;
@@ -105,7 +105,7 @@ __global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__
   const int kw = flip ? (K - 1 - k) : k;
   // not transposed: w[kw][ci][co] ([K, cin, cout]); transposed: w is the forward weight [K, cout, cin]
   const int64_t src = transpose ? (((int64_t)kw * cout + co) * cin + ci) : (((int64_t)kw * cin + ci) * cout + co);
-  packed[e] = (TD)w[src];
+  packed[e] = ci < cin ? (TD)w[src] : (TD)0;
 }
 
 // ---- main kernel --------------------------------------------------------------------------------------------------------
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, n = lane & 31;
   const int cs = wave % WC, rg = wave / WC;  // channel slice, row group
-  const int nchunk = cin / kCsCIC;
+  const int nchunk = (cin + kCsCIC - 1) / kCsCIC;
+  const int last_pieces = (cin - (nchunk - 1) * kCsCIC) / 8;  // 16-B pieces of the last chunk that exist (8, or 4 when cin % 64 == 32)
   const int64_t row0 = (int64_t)blockIdx.x * TILE;
 
   // ---- output row ids (through the mask-sorted permutation), masks, index slab ----
@@ -145,6 +146,11 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   }
   if (tid < 8) reinterpret_cast<int4*>(s_zero)[tid] = make_int4(0, 0, 0, 0);
   if (tid < 4) s_wmask[tid] = 0;
+  if (last_pieces < 8) {
+    // cin % 64 == 32: the upper half of the last chunk is never requested; it meets zero weights in the packed image, so it
+    // only has to be FINITE - clear the ring once (uninitialised LDS may hold NaN patterns)
+    for (int e = tid; e < (int)(G::OFF_NBR / 16); e += NT) reinterpret_cast<int4*>(smem)[e] = make_int4(0, 0, 0, 0);
+  }
   // per-channel epilogue terms: requested first, used last (their latency is off the critical path)
   for (int c = tid; c < CO; c += NT) {
     s_epi[c] = epi.bias ? epi.bias[c] : 0.f;
@@ -230,8 +236,9 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     const uint32_t idxaddr = lds0 + (uint32_t)G::OFF_NBR + (uint32_t)((wave * G::DMA_ROWS + (lane >> 3)) * SP) * 4u;
     // (tile row >> 1) & 7 of the row a lane requests: (lane >> 4) + 4 * (instruction index + first instruction of the wave)
     const int first_odd = ((wave * G::DMA_ROWS) >> 3) & 1;
-    const char* gsrc_e = reinterpret_cast<const char*>(in) + (((lane & 7) ^ ((lane >> 4) + 4 * first_odd)) << 4);
-    const char* gsrc_o = reinterpret_cast<const char*>(in) + (((lane & 7) ^ ((lane >> 4) + 4 * (1 - first_odd))) << 4);
+    const int piece_e = (lane & 7) ^ ((lane >> 4) + 4 * first_odd), piece_o = (lane & 7) ^ ((lane >> 4) + 4 * (1 - first_odd));
+    const char* gsrc_e = reinterpret_cast<const char*>(in) + (piece_e << 4);
+    const char* gsrc_o = reinterpret_cast<const char*>(in) + (piece_o << 4);
 
     auto issue_rows = [&](int buf, int k, int chunk) {
       if (!((dma_mask >> k) & 1u)) return;  // wave-uniform: none of this wave's 32 DMA rows has the offset
@@ -239,9 +246,10 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       int32_t idx[G::DMA_INSTR];
 #pragma unroll
       for (int it = 0; it < G::DMA_INSTR; ++it) idx[it] = *(lds_i32_p)(uintptr_t)(idxaddr + (uint32_t)(k * 4 + it * 8 * SP * 4));
+      const int npieces = chunk + 1 < nchunk ? 8 : last_pieces;  // pieces of this chunk that exist in the row
 #pragma unroll
       for (int it = 0; it < G::DMA_INSTR; ++it) {
-        if (idx[it] >= 0) {
+        if (idx[it] >= 0 && ((it & 1) ? piece_o : piece_e) < npieces) {
           const char* src = ((it & 1) ? gsrc_o : gsrc_e) + (uint64_t)(uint32_t)idx[it] * rowbytes + (uint32_t)(chunk * 128);
           glds16(src, dst + it * 1024);
         }
@@ -350,7 +358,8 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   }
   __syncthreads();
   {
-    constexpr int kLanesPerRow = CO / 8;  // 16-B pieces per output row
+    constexpr int kPieces = CO / 8;  // 16-B pieces per output row
+    constexpr int kLanesPerRow = kPieces <= 4 ? 4 : (kPieces <= 8 ? 8 : 16);  // lanes set aside per row (CO = 96: 12 of 16 work)
     constexpr int kRowsPerInstr = 64 / kLanesPerRow;
     constexpr int kStores = G::DMA_ROWS / kRowsPerInstr;  // every wave stores TILE / WAVES rows
     constexpr int kBatch = kStores < 4 ? kStores : 4;     // rows in flight per lane (residual loads)
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
             smem + (size_t)(wave * G::DMA_ROWS + (j0 + j) * kRowsPerInstr + rsub) * G::OUT_PITCH + piece * 16);
 #pragma unroll
       for (int j = 0; j < kBatch; ++j) {
-        if (orow[j] < 0) continue;
+        if (orow[j] < 0 || piece >= kPieces) continue;
         frag_t o = ov[j];
         if (epi.residual) {
 #pragma unroll
@@ -421,8 +430,8 @@ bool gather_gemm_cs_supported(int cin, int cout, int K, int dtype) {
   if (cs_mode() == 0) return false;
   if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
   if (K < 1 || K > kCsMaxK) return false;
-  if (cin < kCsCIC || cin % kCsCIC != 0) return false;
-  return cout == 64 || cout == 128;
+  if (cin < kCsCIC || cin % 32 != 0) return false;  // (a last chunk of 32 channels runs zero-padded)
+  return cout == 64 || cout == 96 || cout == 128;
 }
 
 template <typename T>
@@ -434,6 +443,7 @@ static int dispatch_cs(const void* in, const void* wp, void* out, const int32_t*
   // vs 2 waves x 128 rows 275 / 392.
   switch (cout) {
     case 64: return launch_cs<T, 64, 2, 1, 4>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+    case 96: return launch_cs<T, 96, 3, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);  // 3 waves x 96 rows
     case 128: return launch_cs<T, 128, 4, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
@@ -450,7 +460,7 @@ int conv_gather_gemm_cs(const void* in, const void* wp, void* out, const int32_t
 int pack_weight_cs(const void* w, int w_is_f32, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                    hipStream_t s) {
   if (!gather_gemm_cs_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
-  const int64_t total = (int64_t)K * cin * cout;
+  const int64_t total = (int64_t)K * ((cin + kCsCIC - 1) / kCsCIC) * kCsCIC * cout;  // = wcn_packed_weight_elements
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
   if (w_is_f32) {
     if (dtype == WCN_BF16)

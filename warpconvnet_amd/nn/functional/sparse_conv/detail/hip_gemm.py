@@ -145,7 +145,9 @@ def invalidate_packed(obj) -> None:
 
 def _pack_weight_uncached(weight: Tensor, K: int, kin: int, kout: int, transpose: bool, flip: bool,
                           dtype: torch.dtype) -> Tensor:
-    packed = torch.empty(weight.numel(), dtype=dtype, device=weight.device)
+    nbytes = _lib.lib().wcn_packed_weight_bytes(K, kin, kout, _lib.dtype_code(dtype), int(transpose))
+    packed = torch.empty(max(weight.numel(), nbytes // max(1, torch.empty((), dtype=dtype).element_size())), dtype=dtype,
+                         device=weight.device)
     if weight.dtype == torch.float32 and dtype != torch.float32:
         _lib.check(
             _lib.lib().wcn_pack_weight_f32(_lib.ptr(weight), K, kin, kout, _lib.dtype_code(dtype), int(transpose), int(flip),
