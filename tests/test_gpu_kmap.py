@@ -107,7 +107,7 @@ def test_binned_edge_cases(kmap_method):
     assert r["found"][22, i_hi] == i_lo  # k = 22 is offset (+1, 0, 0)
     bad = s.copy(); bad[3, 2] = 131072
     with pytest.raises(ValueError):
-        _gen(bad, bad, (3, 3, 3), same=True).offsets  # (.offsets: also covers the lazy WARPCONVNET_AMD_ASYNC_KMAP=1 mode)
+        _gen(bad, bad, (3, 3, 3), same=True).offsets
 
 
 def test_dilation_and_2d(kmap_method):
@@ -320,3 +320,33 @@ def test_large_halo_maps_bit_exact(n, ksize, dil):
         finally:
             os.environ.pop("WARPCONVNET_AMD_KMAP_METHOD", None)
     assert _lib.lib().wcn_kmap_binned_supported(arr(3, 3, 3), arr(9, 1, 1)) == 0  # halo 9: hash path
+
+
+def test_optimistic_build_validates_and_rebuilds(kmap_method):
+    """`generate_kernel_map(..., optimistic=True)` (what the convolution uses): the device tables exist before the status
+    word is read; `validate()` finishes the build - offsets, pair lists, identities - reports False for an ordinary scene,
+    rebuilds for duplicate coordinates (strict insert) and raises the build-time errors."""
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+    dev = _dev()
+    s = scene_u(6000, 21)
+    a = torch.from_numpy(s).to(dev)
+    km = generate_kernel_map(a, a, (1, 1, 1), (3, 3, 3), optimistic=True)
+    assert km._nbr is not None and km._mask is not None and km._perm is not None and km._validate_fn is not None
+    assert km.validate() is False and km.validate() is False  # idempotent
+    _check_against_oracle(km, s, s, (3, 3, 3))
+    assert km.identity_map_index == 13 and km._symmetric
+    # duplicate coordinates, the LATER copy first in memory order of the cell stores: the plain-store build may keep the
+    # wrong row and must be redone with the strict insert - either way the validated map is the oracle's
+    d = np.concatenate([s[:300][::-1], s], 0).astype(np.int32)
+    b = torch.from_numpy(d).to(dev)
+    km2 = generate_kernel_map(b, b, (1, 1, 1), (3, 3, 3), optimistic=True)
+    rebuilt = km2.validate()
+    assert isinstance(rebuilt, bool)
+    _check_against_oracle(km2, d, d, (3, 3, 3))
+    assert km2.identity_map_index is None and km2._has_duplicates and not km2._symmetric
+    bad = s.copy(); bad[3, 2] = 131072
+    c = torch.from_numpy(bad).to(dev)
+    km3 = generate_kernel_map(c, c, (1, 1, 1), (3, 3, 3), optimistic=True)
+    with pytest.raises(ValueError):
+        km3.validate()

@@ -19,7 +19,6 @@ def _unflatten(children, ctx) -> IntSearchResult:
     # no constructor call: its offsets[-1] check would read a tensor value under tracing
     self = object.__new__(IntSearchResult)
     self._in_maps, self._out_maps, self._offsets = children
-    self._pending = None
     self._lazy_pairs = None
     self._num_offsets = len(children[2]) - 1
     self.identity_map_index = ctx["identity_map_index"]

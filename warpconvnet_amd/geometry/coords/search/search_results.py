@@ -70,7 +70,6 @@ class IntSearchResult:
         self._in_maps = in_maps
         self._out_maps = out_maps
         self._offsets = offsets_cpu
-        self._pending = None
         self._lazy_pairs = None
         self._num_offsets = len(offsets_cpu) - 1
         self.identity_map_index = identity_map_index
@@ -89,17 +88,19 @@ class IntSearchResult:
         self._num_in: Optional[int] = None
         self._num_out: Optional[int] = None
         self._pair_table_cache: Optional[Tensor] = None
+        self._validate_fn = None  # optimistic builds: reads the status word, finishes / repeats the build (see validate)
 
     @classmethod
-    def _from_pending(cls, in_full: Tensor, out_full: Tensor, meta_host: Tensor, event, num_offsets: int,
-                      identity_map_index: Optional[int], on_flags) -> "IntSearchResult":
-        """Builder hook: buffers of worst-case length + pinned ``meta_host`` = offsets[K+1] ++ [flags], ready at ``event``."""
+    def _blank(cls, num_offsets: int, device) -> "IntSearchResult":
+        """Builder hook: an empty container the kernel-map builder fills (tables at once, offsets / pair lists / identities
+        when the build's status word has been read - `validate`)."""
         self = object.__new__(cls)
-        self._in_maps, self._out_maps, self._offsets = in_full, out_full, None
-        self._pending = (meta_host, event, on_flags)
+        self._in_maps = self._out_maps = None
+        self._offsets = None
         self._lazy_pairs = None
+        self._device = torch.device(device)
         self._num_offsets = num_offsets
-        self.identity_map_index = identity_map_index
+        self.identity_map_index = None
         self._init_tables()
         return self
 
@@ -108,18 +109,25 @@ class IntSearchResult:
         """Builder hook: offsets are known, the pair lists are not written yet.  ``scatter()`` allocates and fills
         ``(in_maps, out_maps)`` on first use - the forward / dgrad kernels read the neighbour table, only the weight gradient
         (and the container API) needs the lists, so a forward-only pass never pays for them."""
-        self = object.__new__(cls)
-        self._in_maps = self._out_maps = None
+        self = cls._blank(len(offsets_host) - 1, device)
         self._offsets = offsets_host.detach().cpu()
-        self._pending = None
         self._lazy_pairs = scatter
-        self._device = torch.device(device)
-        self._num_offsets = len(self._offsets) - 1
         self.identity_map_index = identity_map_index
-        self._init_tables()
         return self
 
+    def validate(self) -> bool:
+        """Read the status word of an OPTIMISTIC build (`generate_kernel_map(..., optimistic=True)`): raises the build-time
+        errors (coordinate range, table capacity), fills offsets / identities / pair lists, and rebuilds the tables if the
+        device rejected the first attempt.  Returns True when the device tables were REPLACED - launches made on the old
+        ones must be repeated.  Idempotent and free once done; a no-op for every other map."""
+        fn = getattr(self, "_validate_fn", None)
+        if fn is None:
+            return False
+        self._validate_fn = None
+        return bool(fn(self))
+
     def _ensure_pairs(self):
+        self.validate()
         fn = getattr(self, "_lazy_pairs", None)
         if fn is not None:
             self._lazy_pairs = None
@@ -127,27 +135,9 @@ class IntSearchResult:
 
     def _materialize(self):
         self._ensure_pairs()
-        if self._pending is None:
-            return
-        meta_host, event, on_flags = self._pending
-        event.synchronize()
-        self._pending = None
-        K = self._num_offsets
-        flags = int(meta_host[K + 1])
-        on_flags(flags)
-        refresh = getattr(self, "_refresh_flags", None)
-        if refresh is not None:  # what the builder had to assume while the flags were in flight (duplicate coordinates)
-            refresh(flags)
-            self._refresh_flags = None
-        self._offsets = meta_host[: K + 1].clone()
-        n = int(self._offsets[-1])
-        self._in_maps = self._in_maps[:n]
-        self._out_maps = self._out_maps[:n]
 
     def poll(self):
-        """Non-blocking: if the pending host copy has arrived, validate its status flags (raises on error)."""
-        if self._pending is not None and self._pending[1].query():
-            self._materialize()
+        """Non-blocking hook kept for callers of earlier builds: nothing to do (see `validate`)."""
 
     @property
     def in_maps(self) -> Tensor:

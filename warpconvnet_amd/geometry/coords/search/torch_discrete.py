@@ -148,11 +148,15 @@ def generate_kernel_map(
     method: Literal["offset", "size"] = "size",
     skip_symmetric_kernel_map: bool = False,
     need_pairs: bool = True,
+    optimistic: bool = False,
     **kwargs,
 ) -> IntSearchResult:
     """Kernel map between integer coordinate sets: ``in = out * stride + offset[k]``.
 
-    Returns an ``IntSearchResult`` whose buckets are ordered by output row (deterministic).
+    Returns an ``IntSearchResult`` whose buckets are ordered by output row (deterministic).  ``optimistic``: return as
+    soon as the build is queued - the device tables (``_nbr / _mask / _perm``) may be used for launches right away, the
+    status word (range / capacity errors, pair count, duplicate flags) is read by ``result.validate()``, which every
+    host-side accessor calls first and which returns True if it had to rebuild the tables (see the builder's tail).
     """
     dev = batch_indexed_in_coords.device
     assert dev == batch_indexed_out_coords.device
@@ -233,22 +237,19 @@ def generate_kernel_map(
     # binned path: capacity of the block table.  Most scenes have >= 4 voxels per occupied 8^3 block (uniform 12 % occupancy:
     # 28, surfaces: ~64); sparser ones raise TABLE_FULL on the device and are rebuilt with one block per voxel (always
     # enough).  `strict`: see wcn.h.
-    max_blocks = max(1024, N // _BINNED_HINT["div"]) if _BINNED_HINT["div"] > 1 else max(N, 1)
-    strict = 0
-    # WARPCONVNET_AMD_ASYNC_KMAP=1 (opt-in): never wait - pairs go to worst-case sized buffers and offsets / flags are
-    # validated lazily (IntSearchResult.poll / first host access); the binned builder then runs in its no-retry
-    # configuration.  Default: wait for the mirror, raise range / capacity errors at build time like the reference,
-    # allocate exact-size pair buffers.
-    async_ok = os.environ.get("WARPCONVNET_AMD_ASYNC_KMAP", "0") in ("1", "true") and K * M * 8 <= (1 << 29)
-    if async_ok and use_binned:
-        max_blocks, strict = max(N, 1), 1
-    while True:
+    state = {"max_blocks": max(1024, N // _BINNED_HINT["div"]) if _BINNED_HINT["div"] > 1 else max(N, 1), "strict": 0}
+    odd = all(k % 2 == 1 for k in ksize)
+
+    def launch():
+        """Queue one build (tables + tally + scans + mask sort) on the current stream; nothing waits."""
+        max_blocks, strict = state["max_blocks"], state["strict"]
         nbr = torch.empty((M, kp), dtype=torch.int32, device=dev)
         mask = torch.empty((M, mw), dtype=torch.int32, device=dev)
         block_counts = torch.empty(L.wcn_kmap_counts_bytes(M, K) // 4, dtype=torch.int32, device=dev)
         perm = torch.empty(M, dtype=torch.int32, device=dev)
         meta = (torch.empty if use_binned else torch.zeros)(K + 2, dtype=torch.int32, device=dev)
         table, bin_ws = None, None
+        stream = _lib.stream_handle(dev)
         if use_binned:
             # LDS-binned path: block-level hash + cell table + per-block LDS grid probes (csrc/kmap_binned.hip)
             ws_bytes = L.wcn_kmap_binned_workspace(N, max_blocks)
@@ -284,87 +285,121 @@ def generate_kernel_map(
         )
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev))
-        if async_ok:
-            break
-        # the scan kernel raises the READY word of the pinned mirror behind a system-scope fence: spinning on it costs a
-        # few microseconds where the event wait costs a thread wake-up; bounded, then the ordinary wait (long queues, M = 0)
-        if M > 0:
-            for _ in range(_SPIN_POLLS):
-                if ready.value:
-                    break
-        if not ready.value:
-            event.synchronize()
-        flags = int(meta_host[K + 1])
-        if use_binned and (flags & _lib.WCN_FLAG_TABLE_FULL) and max_blocks < N:
-            # this process sees sparser scenes than the bound assumed (>= 16, then >= 4 voxels per occupied 8^3 block): start
-            # with the next larger table from now on
-            _BINNED_HINT["div"] = 4 if _BINNED_HINT["div"] > 4 else 1
-            max_blocks = max(1024, N // 4) if _BINNED_HINT["div"] == 4 and max_blocks < max(1024, N // 4) else N
-            continue
-        if use_binned and (flags & _lib.WCN_FLAG_NEED_STRICT) and not strict:
-            strict = 1
-            continue
-        break
+        return dict(nbr=nbr, mask=mask, perm=perm, block_counts=block_counts, meta=meta, meta_host=meta_host, ready=ready,
+                    event=event, table=table, keep=(bin_ws, sort_ws))
 
-    odd = all(k % 2 == 1 for k in ksize)
-    identity = K // 2 if (odd and unit_stride and N == M) else None
-    has_duplicates = True  # unknown until the flags arrive (async mode): assume the worst
-    if async_ok:
-        pair_capacity = K * M
-        offsets_host = None
-    else:
+    def settle(b):
+        """Wait for the status word of build `b`; rebuild while the device asks for it.  -> (build, flags, rebuilt)"""
+        rebuilt = False
+        while True:
+            # the scan kernel raises the READY word of the pinned mirror behind a system-scope fence: spinning on it costs a
+            # few microseconds where the event wait costs a thread wake-up; bounded, then the ordinary wait (long queues, M = 0)
+            if M > 0:
+                for _ in range(_SPIN_POLLS):
+                    if b["ready"].value:
+                        break
+            if not b["ready"].value:
+                b["event"].synchronize()
+            flags = int(b["meta_host"][K + 1])
+            if use_binned and (flags & _lib.WCN_FLAG_TABLE_FULL) and state["max_blocks"] < N:
+                # this process sees sparser scenes than the bound assumed (>= 16, then >= 4 voxels per occupied 8^3 block):
+                # start with the next larger table from now on
+                _BINNED_HINT["div"] = 4 if _BINNED_HINT["div"] > 4 else 1
+                state["max_blocks"] = max(1024, N // 4) if _BINNED_HINT["div"] == 4 and state["max_blocks"] < max(1024, N // 4) else N
+            elif use_binned and (flags & _lib.WCN_FLAG_NEED_STRICT) and not state["strict"]:
+                state["strict"] = 1
+            else:
+                return b, flags, rebuilt
+            b, rebuilt = launch(), True
+
+    def attach_tables(result, b):
+        result._nbr, result._mask, result._perm = b["nbr"], b["mask"], b["perm"]
+        result._offsets_dev = b["meta"][: K + 1]
+        result._hashtable = b["table"]
+        result._keepalive = b  # (workspaces the queued kernels still read)
+
+    def finalize(result, b, flags):
+        """Status word in hand: raise what the reference raises at build time, then offsets, identities, pair lists."""
         PackedHashTable.raise_for_flags(flags, N, table_capacity)
-        offsets_host = meta_host[: K + 1].clone()
+        offsets_host = b["meta_host"][: K + 1].clone()
         pair_capacity = int(offsets_host[-1])
         has_duplicates = bool(flags & _lib.WCN_FLAG_DUPLICATE_COORD)
-    if has_duplicates and same_tensor:
-        identity = None  # "output row i == input row i at the centre offset" fails for the rows that lost their coordinate
-    def scatter_pairs():
-        in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
-        out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
-        _lib.check(
-            L.wcn_kmap_scatter(_lib.ptr(nbr), _lib.ptr(mask), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
-                               _lib.ptr(out_maps), pair_capacity, _lib.ptr(meta[K + 1 :]), _lib.stream_handle(dev)),
-            "wcn_kmap_scatter",
-        )
-        return in_maps, out_maps
+        identity = K // 2 if (odd and unit_stride and N == M) else None
+        if has_duplicates and same_tensor:
+            identity = None  # "output row i == input row i at the centre offset" fails for the rows that lost their coordinate
+        nbr, mask, block_counts, meta = b["nbr"], b["mask"], b["block_counts"], b["meta"]
 
-    if async_ok:
-        in_maps, out_maps = scatter_pairs()
-        result = IntSearchResult._from_pending(
-            in_maps, out_maps, meta_host, event, K, identity,
-            lambda flags, n=N, c=table_capacity: PackedHashTable.raise_for_flags(flags, n, c))
-    elif not need_pairs:
-        # the pair lists (CSR by offset) are written on first use: the forward and dgrad kernels read the neighbour table,
-        # only wgrad and the container API need the lists, so a caller that will not run a weight gradient (need_pairs =
-        # False: the convolution under no_grad) skips the 49 us scatter.  Not in training: run later, between dgrad and
-        # wgrad, the scatter finds the 128 MB table evicted from the Infinity Cache and the step is 35-45 us slower
-        # (measured 1.079 vs 1.031 ms).
-        result = IntSearchResult._from_deferred_pairs(scatter_pairs, offsets_host, dev, identity)
-    else:
-        in_maps, out_maps = scatter_pairs()
-        result = IntSearchResult(in_maps, out_maps, offsets_host, identity_map_index=identity)
-    result._nbr, result._mask, result._perm = nbr, mask, perm
-    result._offsets_dev = meta[: K + 1]
-    # Duplicate input rows break the k-flip identity the dgrad shortcut relies on (rev[n][k] == nbr[n][K-1-k] holds only
-    # when every coordinate is one row: a non-winner duplicate has neighbours but is nobody's neighbour), so such maps -
-    # and maps whose flags have not arrived yet (async mode) - take the explicit reverse table instead.
-    result._symmetric = bool(same_tensor and odd and unit_stride and not has_duplicates)
-    result._self_exact = result._symmetric
-    # duplicate OUTPUT rows (a submanifold map over repeated coordinates) share their input rows per offset: the
-    # [N_in, K] reverse table has one slot per (input row, offset), so dgrad then goes through the pair lists
-    result._has_duplicates = bool(same_tensor and has_duplicates)
-    if async_ok:
-        # the flags are still in flight: duplicates were assumed above; once the mirror arrives (poll / first host access)
-        # the map gets its real properties back, so dgrad returns to the k-flipped table instead of the pair-list path
-        def _refresh(flags, r=result, ident=(K // 2 if (odd and unit_stride and N == M) else None)):
-            dup = bool(flags & _lib.WCN_FLAG_DUPLICATE_COORD)
-            r._symmetric = r._self_exact = bool(same_tensor and odd and unit_stride and not dup)
-            r._has_duplicates = bool(same_tensor and dup)
-            if not dup:
-                r.identity_map_index = ident
-        result._refresh_flags = _refresh
+        def scatter_pairs():
+            in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
+            out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
+            _lib.check(
+                L.wcn_kmap_scatter(_lib.ptr(nbr), _lib.ptr(mask), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
+                                   _lib.ptr(out_maps), pair_capacity, _lib.ptr(meta[K + 1 :]), _lib.stream_handle(dev)),
+                "wcn_kmap_scatter",
+            )
+            return in_maps, out_maps
+
+        attach_tables(result, b)
+        result._offsets = offsets_host
+        result.identity_map_index = identity
+        result._device = torch.device(dev)
+        spec = b.get("spec_pairs")
+        if spec is not None:
+            # written speculatively right behind the mask sort (worst-case capacity): the first L entries are the lists
+            result._in_maps, result._out_maps = spec[0][:pair_capacity], spec[1][:pair_capacity]
+            result._lazy_pairs = None
+        elif need_pairs:
+            # training: the weight gradient needs the pair lists, and written NOW - while the neighbour table is still in the
+            # Infinity Cache - they cost 35-45 us less than between dgrad and wgrad
+            result._in_maps, result._out_maps = scatter_pairs()
+            result._lazy_pairs = None
+        else:
+            # the forward and dgrad kernels read the neighbour table; only wgrad and the container API need the lists (CSR by
+            # offset), so a caller that will not run a weight gradient (the convolution under no_grad) skips the 49 us scatter
+            result._in_maps = result._out_maps = None
+            result._lazy_pairs = scatter_pairs
+        # Duplicate input rows break the k-flip identity the dgrad shortcut relies on (rev[n][k] == nbr[n][K-1-k] holds only
+        # when every coordinate is one row: a non-winner duplicate has neighbours but is nobody's neighbour): such maps take
+        # the explicit reverse table instead.
+        result._symmetric = bool(same_tensor and odd and unit_stride and not has_duplicates)
+        result._self_exact = result._symmetric
+        # duplicate OUTPUT rows (a submanifold map over repeated coordinates) share their input rows per offset: the
+        # [N_in, K] reverse table has one slot per (input row, offset), so dgrad then goes through the pair lists
+        result._has_duplicates = bool(same_tensor and has_duplicates)
+
+    result = IntSearchResult._blank(K, dev)
     result._num_in, result._num_out = N, M
-    result._hashtable = table
     result._kernel_size = ksize
+    first = launch()
+    if optimistic:
+        # The caller launches its forward kernel on these tables BEFORE the status word is read (`IntSearchResult.validate`
+        # afterwards): the host never stands between the scan kernel and the forward, so the GPU runs the mask sort and the
+        # forward back to back instead of idling for the host's round trip.  Every scene a voxeliser produces passes; a
+        # build the device rejects (block table too small, duplicate coordinates that need the strict insert) is redone
+        # inside validate(), which then reports that the tables changed.
+        attach_tables(result, first)
+        if need_pairs and K * M * 8 <= (1 << 30):
+            # the pair lists (the weight gradient's input) without knowing the pair count: buffers of worst-case length K * M
+            # (address space only - L entries are ever touched), the scatter queued right behind the mask sort while the
+            # neighbour table is still in the Infinity Cache; validate() cuts the views to the real length
+            cap = K * M
+            in_full = torch.empty(cap, dtype=torch.int32, device=dev)
+            out_full = torch.empty(cap, dtype=torch.int32, device=dev)
+            _lib.check(
+                L.wcn_kmap_scatter(_lib.ptr(first["nbr"]), _lib.ptr(first["mask"]), M, K, _lib.ptr(first["block_counts"]),
+                                   _lib.ptr(first["meta"]), _lib.ptr(in_full), _lib.ptr(out_full), cap,
+                                   _lib.ptr(first["meta"][K + 1 :]), _lib.stream_handle(dev)),
+                "wcn_kmap_scatter",
+            )
+            first["spec_pairs"] = (in_full, out_full)
+
+        def validate_fn(res, b=first):
+            b2, flags, rebuilt = settle(b)
+            finalize(res, b2, flags)
+            return rebuilt
+
+        result._validate_fn = validate_fn
+        return result
+    b, flags, _ = settle(first)
+    finalize(result, b, flags)
     return result

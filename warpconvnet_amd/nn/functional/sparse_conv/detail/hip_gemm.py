@@ -250,18 +250,27 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
             y = hip_forward(_pad_cols(x, plan[0]), wp_, kernel_map, num_out_coords, algo,
                             None if bias is None else _pad_cols(bias, plan[1]))
             return y[:, :cout].contiguous()
-    kernel_map.poll()
     attach_tables_from_csr(kernel_map, x.shape[0], num_out_coords)
-    if _fp32_via_fp16(algo, cin, cout, K, x.dtype):
-        x16, sx = fp16_safe_cast(x)
-        w16, sw = fp16_safe_cast(w)
-        y = _gather_gemm(x16, w16, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K,
-                         _lib.WCN_ALGO_MFMA, transposed=False, flip=False, bias=None, f32_out=True)
-        y = y * (sx * sw)  # exact power-of-two multiply-back, no host sync
-        return y if bias is None else y + bias
-    code = resolve_gather_algo(algo, cin, cout, K, x.dtype)
-    return _gather_gemm(x, w, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K, code,
-                        transposed=False, flip=False, bias=bias)
+
+    def launch():
+        if _fp32_via_fp16(algo, cin, cout, K, x.dtype):
+            x16, sx = fp16_safe_cast(x)
+            w16, sw = fp16_safe_cast(w)
+            y = _gather_gemm(x16, w16, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K,
+                             _lib.WCN_ALGO_MFMA, transposed=False, flip=False, bias=None, f32_out=True)
+            y = y * (sx * sw)  # exact power-of-two multiply-back, no host sync
+            return y if bias is None else y + bias
+        code = resolve_gather_algo(algo, cin, cout, K, x.dtype)
+        return _gather_gemm(x, w, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K, code,
+                            transposed=False, flip=False, bias=bias)
+
+    # An optimistic map (built by the convolution itself this very call) has not had its status word read: the forward is
+    # queued on its tables FIRST - so the GPU runs mask sort -> forward back to back while the host gets to the status -
+    # and repeated in the rare case the build had to be redone (block table too small, duplicate coordinates).
+    y = launch()
+    if kernel_map.validate():
+        y = launch()
+    return y
 
 
 def hip_colsum(t: Tensor) -> Tensor:
@@ -302,7 +311,7 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
     if dy.dtype != w.dtype and not master_weight_ok(dy.dtype, w, algo, True):
         raise RuntimeError(f"hip dgrad error: {_lib.status_string(-6)} ({dy.dtype} vs {w.dtype})")
     K, cin, cout = w.shape
-    kernel_map.poll()
+    kernel_map.validate()
     if getattr(kernel_map, "_has_duplicates", False):
         return _dgrad_pair_lists(dy, w, kernel_map, num_in_coords)
     if algo == "auto" and dy.is_cuda and not _gather_ok(cout, cin, K, _code16(dy.dtype)):
@@ -346,7 +355,7 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
             dw_p, db = r if want_bias_grad else (r, None)
             dw_c = dw_p[:, :cin, :cout].contiguous()
             return (dw_c, None if db is None else db[:cout].contiguous()) if want_bias_grad else dw_c
-    kernel_map.poll()
+    kernel_map.validate()
     scale = None
     if x.dtype == torch.float32 and algo != "hip_ref" and _wgrad_ok(cin, cout, _lib.WCN_F16):
         x, sx = fp16_safe_cast(x)      # fp16 operands, fp32 accumulate and output; scales multiplied back below
@@ -454,7 +463,7 @@ def hip_forward_grouped(in_features: Tensor, weight: Tensor, kernel_map: IntSear
     assert K == len(kernel_map) and x.shape[1] == G * cg_in
     if bias is not None:
         bias = _prep(bias.detach().float(), "bias")
-    kernel_map.poll()
+    kernel_map.validate()
     attach_tables_from_csr(kernel_map, x.shape[0], num_out_coords)
     packed = _pack_grouped(weight, False, False, x.dtype)
     return _grouped_gather(x, packed, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cg_in, cg_out, G, K, bias)
@@ -463,7 +472,7 @@ def hip_forward_grouped(in_features: Tensor, weight: Tensor, kernel_map: IntSear
 def hip_dgrad_grouped(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_in_coords: int) -> Tensor:
     dy = _prep(grad_output, "grad_output")
     K, G, cg_in, cg_out = weight.shape
-    kernel_map.poll()
+    kernel_map.validate()
     if getattr(kernel_map, "_has_duplicates", False):
         return torch.cat([_dgrad_pair_lists(dy[:, g * cg_out : (g + 1) * cg_out], weight[:, g].to(dy.dtype), kernel_map,
                                             num_in_coords) for g in range(G)], dim=1)

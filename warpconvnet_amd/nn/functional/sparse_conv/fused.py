@@ -69,7 +69,7 @@ def hip_forward_fused(in_features: Tensor, weight: Tensor, kernel_map, num_out_c
         if residual is not None:
             y = y + residual.float()
         return (torch.relu(y) if relu else y).to(x.dtype)
-    kernel_map.poll()
+    kernel_map.validate()
     attach_tables_from_csr(kernel_map, x.shape[0], num_out_coords)
     out = torch.empty((num_out_coords, cout), dtype=x.dtype, device=dev)
     if num_out_coords == 0:

@@ -62,6 +62,7 @@ def generate_output_coords_and_kernel_map(
     kernel_search_batch_size: Optional[int] = None,
     out_code_backend: Optional[str] = None,
     need_pairs: bool = True,
+    optimistic: bool = False,
 ) -> Tuple[Tensor, Tensor, IntSearchResult]:
     """Returns ``(batch_indexed_out_coords [M, D+1], out_offsets (CPU), kernel_map)``.  ``need_pairs``: the caller will
     run a weight gradient on the map (pair lists written with the build); False defers them to their first use."""
@@ -125,7 +126,10 @@ def generate_output_coords_and_kernel_map(
         kernel_map = _swap(generate_kernel_map(bcoords_out, bcoords_in, map_stride, kernel_size, kernel_dilation,
                                                need_pairs=need_pairs))
     else:
-        kernel_map = generate_kernel_map(bcoords_in, bcoords_out, map_stride, kernel_size, kernel_dilation, need_pairs=need_pairs)
+        # optimistic (the convolution passes it): the caller queues its forward kernel on the map's tables and THEN calls
+        # kernel_map.validate() - no host round trip between the map build and the forward
+        kernel_map = generate_kernel_map(bcoords_in, bcoords_out, map_stride, kernel_size, kernel_dilation, need_pairs=need_pairs,
+                                         optimistic=optimistic)
 
     if input_sparse_tensor.cache is None:
         input_sparse_tensor._extra_attributes["_cache"] = IntSearchCache()
@@ -216,13 +220,12 @@ def spatially_sparse_conv(
         input_sparse_tensor, _kernel_size, _dilation, _stride, generative=generative, transposed=transposed,
         output_spatially_sparse_tensor=output_spatially_sparse_tensor, stride_mode=stride_mode, order=order,
         need_pairs=torch.is_grad_enabled(),  # (the map builders run under no_grad: the caller's mode is read here)
+        optimistic=input_sparse_tensor.feature_tensor.is_cuda,
     )
     num_out = bcoords_out.shape[0]
-    if torch.is_grad_enabled() and hasattr(kernel_map, "_ensure_pairs"):
-        # training: the weight gradient needs the pair lists, and written NOW - right behind the map build, while the
-        # neighbour table is still in the Infinity Cache - they cost 35-45 us less than between dgrad and wgrad.  (The map
-        # builder runs under no_grad and defers them; a forward-only pass never writes them.)
-        kernel_map._ensure_pairs()
+    # (training: the builder has queued the pair-list scatter on a helper stream - right behind the scan, while the
+    # neighbour table is still in the Infinity Cache - and the weight gradient joins it on first use of the lists; a map
+    # built under no_grad writes them on first use; a forward-only pass never writes them.)
 
     # cast BEFORE Function.apply so the tensors saved for backward are in compute precision
     feats = input_sparse_tensor.feature_tensor

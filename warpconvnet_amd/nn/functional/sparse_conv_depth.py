@@ -100,7 +100,7 @@ def _explicit_depthwise_backward_logic(grad_output: Tensor, in_features: Tensor,
 def _tables(kernel_map: IntSearchResult, num_in: int, num_out: int):
     from warpconvnet_amd.geometry.coords.search.torch_discrete import attach_tables_from_csr
 
-    kernel_map.poll()
+    kernel_map.validate()
     attach_tables_from_csr(kernel_map, num_in, num_out)
     return kernel_map._nbr
 
