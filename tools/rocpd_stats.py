@@ -71,7 +71,8 @@ def traffic(fetch_db, write_db):
         return {k: t / n for k, (n, t) in agg.items()}
 
     f, w = avg(fetch_db, "FETCH_SIZE"), avg(write_db, "WRITE_SIZE")
-    keys = {"fwd": "gather_gemm_mfma_kernelIDF16bLi64ELi128", "dgrad": "gather_gemm_mfma_kernelIDF16bLi64ELi64",
+    # (round 3: the 64 -> 128 forward and the 128 -> 64 dgrad run the channel-split kernels, template <T, CO, RBW, WR, MINW>)
+    keys = {"fwd": "gather_gemm_cs_kernelIDF16bLi128E", "dgrad": "gather_gemm_cs_kernelIDF16bLi64E",
             "wgrad": "wgrad_mfma_kernelIDF16bLi64ELi128ELb1"}
     out = {"unit": "bytes per launch", "fetch_correction": 2.0, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 20 --warmup 5 --no-cpu-baseline`"}
     for name, sub in keys.items():
