@@ -11,6 +11,8 @@ from typing import Literal, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+
+from warpconvnet_amd.utils.compile_guard import eager_unless_compiling
 from torch import Tensor
 
 from warpconvnet_amd import _lib
@@ -136,7 +138,7 @@ _SPIN_POLLS = 4000  # polls of the pinned READY word, ~0.1 us each: up to ~0.4 m
 _BINNED_HINT = {"div": 16}  # block-table bound = N / div (0.15 GB of workspace per million voxels), grown to N / 4 and N on TABLE_FULL
 
 
-@torch.compiler.disable
+@eager_unless_compiling
 @torch.no_grad()
 def generate_kernel_map(
     batch_indexed_in_coords: Tensor,

@@ -9,6 +9,8 @@ from typing import List, Optional, Tuple, Union
 
 import numpy as np
 import torch
+
+from warpconvnet_amd.utils.compile_guard import eager_unless_compiling
 from torch import Tensor
 
 from warpconvnet_amd.constants import get_fp16_accum
@@ -48,7 +50,7 @@ def _cpu_kernel_map(in_coords: Tensor, out_coords: Tensor, stride, kernel_size, 
 
 
 @torch.no_grad()
-@torch.compiler.disable
+@eager_unless_compiling
 def generate_output_coords_and_kernel_map(
     input_sparse_tensor: Voxels,
     kernel_size: Tuple[int, ...],
@@ -137,7 +139,7 @@ def generate_output_coords_and_kernel_map(
     return bcoords_out, out_offsets, kernel_map
 
 
-@torch.compiler.disable
+@eager_unless_compiling
 def spatially_sparse_conv(
     input_sparse_tensor: Geometry,
     weight: Tensor,

@@ -17,6 +17,8 @@ from enum import Enum
 from typing import List, Optional, Tuple, Union
 
 import torch
+
+from warpconvnet_amd.utils.compile_guard import eager_unless_compiling
 from torch import Tensor
 from torch.autograd import Function
 
@@ -216,7 +218,7 @@ class UnifiedSpatiallySparseDepthwiseConvFunction(Function):
         return grad_in, grad_w, None, None, None, None, None
 
 
-@torch.compiler.disable
+@eager_unless_compiling
 def spatially_sparse_depthwise_conv(
     in_features: Tensor,
     weight: Tensor,

@@ -12,6 +12,8 @@ directions are deterministic.  The map is cached under the same key as a strided
 from typing import Optional, Tuple, Union
 
 import torch
+
+from warpconvnet_amd.utils.compile_guard import eager_unless_compiling
 from torch import Tensor
 from torch.autograd import Function
 
@@ -108,7 +110,7 @@ def _pool_map(voxels: Voxels, kernel_size: Tuple[int, ...], stride: Tuple[int, .
     return bcoords_out, out_offsets, kernel_map
 
 
-@torch.compiler.disable
+@eager_unless_compiling
 def sparse_reduce(voxels: Voxels, kernel_size: Union[int, Tuple[int, ...]],
                   stride: Optional[Union[int, Tuple[int, ...]]] = None,
                   reduction: Union[REDUCTIONS, str] = REDUCTIONS.MAX, order=None) -> Voxels:
@@ -141,7 +143,7 @@ def sparse_avg_pool(voxels: Voxels, kernel_size, stride=None) -> Voxels:
     return sparse_reduce(voxels, kernel_size, stride, reduction=REDUCTIONS.MEAN)
 
 
-@torch.compiler.disable
+@eager_unless_compiling
 def sparse_unpool(pooled_voxels: Voxels, unpooled_voxels: Voxels, kernel_size, stride,
                   concat_unpooled_voxels: bool = False) -> Voxels:
     """Copy every pooled feature back to the fine voxels of its window (the map of the matching ``sparse_reduce`` /
