@@ -151,13 +151,6 @@ int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_off
                         int32_t* status, int32_t* host_mirror, int32_t* perm, void* sort_workspace,
                         size_t sort_workspace_bytes, const int32_t* coords, void* binned_workspace, int64_t binned_n,
                         int64_t max_blocks, wcn_stream_t stream);
-/* The same with the sort passes behind the scan queued on `sort_stream` (ordered behind the scan by an event): work queued on
- * `stream` afterwards - the pair-list scatter - overlaps with them; the caller makes `stream` wait for `sort_stream` before
- * `perm` is consumed.  sort_stream == stream is wcn_kmap_tally_sort. */
-int wcn_kmap_tally_sort_forked(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* counts,
-                               int32_t* offsets, int32_t* status, int32_t* host_mirror, int32_t* perm, void* sort_workspace,
-                               size_t sort_workspace_bytes, const int32_t* coords, void* binned_workspace, int64_t binned_n,
-                               int64_t max_blocks, wcn_stream_t stream, wcn_stream_t sort_stream);
 /* counts[k][b] = pairs of offset k in the 256-row tile b (k-major, from the masks); counts = wcn_kmap_counts_bytes bytes.
  * reference: _C.cuhash.postprocess_count (cuhash_kernel_map.cu:508-544). */
 int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream);

@@ -70,11 +70,6 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
          c_void_p, c_void_p, c_int64, c_int64, c_void_p],
     ),
-    "wcn_kmap_tally_sort_forked": (
-        c_int,
-        [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-         c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p],
-    ),
     "wcn_kmap_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scan_to_host": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -464,14 +464,6 @@ int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_off
                         int32_t* status, int32_t* host_mirror, int32_t* perm, void* sort_workspace,
                         size_t sort_workspace_bytes, const int32_t* coords, void* binned_workspace, int64_t binned_n,
                         int64_t max_blocks, wcn_stream_t stream) {
-  return wcn_kmap_tally_sort_forked(mask, nbr, m, num_offsets, counts, offsets, status, host_mirror, perm, sort_workspace,
-                                    sort_workspace_bytes, coords, binned_workspace, binned_n, max_blocks, stream, stream);
-}
-
-int wcn_kmap_tally_sort_forked(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* counts,
-                               int32_t* offsets, int32_t* status, int32_t* host_mirror, int32_t* perm, void* sort_workspace,
-                               size_t sort_workspace_bytes, const int32_t* coords, void* binned_workspace, int64_t binned_n,
-                               int64_t max_blocks, wcn_stream_t stream, wcn_stream_t sort_stream) {
   if (m < 0 || !valid_k(num_offsets) || !counts || !offsets || !status) return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
   if (m == 0) {  // no rows: offsets are all zero, nothing to sort
@@ -496,17 +488,7 @@ int wcn_kmap_tally_sort_forked(uint32_t* mask, int32_t* nbr, int64_t m, int32_t 
               plan.totals, s);
   RsLaunch l[12];
   const int count = sort_launches(plan, mask, wcn_kmap_mask_words(num_offsets), m, perm, true, l);
-  hipStream_t ss = (hipStream_t)sort_stream;
-  if (ss != s) {
-    // the remaining sort passes (small, latency-bound launches) on their own stream behind the scan: whatever the caller
-    // queues on `stream` next - the pair-list scatter - runs beside them.  The caller joins `sort_stream` before `perm` is read.
-    hipEvent_t ev;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
-    const bool ok = hipEventRecord(ev, s) == hipSuccess && hipStreamWaitEvent(ss, ev, 0) == hipSuccess;
-    (void)hipEventDestroy(ev);  // released once the recorded work has completed
-    if (!ok) return WCN_ERROR_KERNEL_EXECUTION;
-  }
-  sort_run_range(l, 0, count, ss);
+  sort_run_range(l, 0, count, s);
   return launch_status();
 }
 

@@ -131,16 +131,6 @@ def _first_half(full: IntSearchResult) -> IntSearchResult:
     return IntSearchResult(full.in_maps_device[:n].clone(), full.out_maps_device[:n].clone(), offs, identity_map_index=c)
 
 
-_SIDE_STREAMS = {}  # device index -> helper stream of the mask sort's tail (see generate_kernel_map: launch)
-
-
-def _side_stream(dev) -> "torch.cuda.Stream":
-    s = _SIDE_STREAMS.get(dev.index)
-    if s is None:
-        s = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-    return s
-
-
 _SPIN_POLLS = 4000  # polls of the pinned READY word, ~0.1 us each: up to ~0.4 ms of spinning before the ordinary event wait
 
 
@@ -250,8 +240,6 @@ def generate_kernel_map(
     # 28, surfaces: ~64); sparser ones raise TABLE_FULL on the device and are rebuilt with one block per voxel (always
     # enough).  `strict`: see wcn.h.
     state = {"max_blocks": max(1024, N // _BINNED_HINT["div"]) if _BINNED_HINT["div"] > 1 else max(N, 1), "strict": 0}
-    spec_pairs_ok = optimistic and need_pairs and K * M * 8 <= (1 << 30)
-    fork_sort = spec_pairs_ok and os.environ.get("WCN_FORK_SORT", "1") != "0"
     odd = all(k % 2 == 1 for k in ksize)
 
     def launch():
@@ -290,29 +278,17 @@ def generate_kernel_map(
         ready.value = 0
         sort_bytes = L.wcn_kmap_tally_sort_workspace(M)
         sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
-        # optimistic builds with a speculative pair scatter: the sort's remaining passes (seven small launches, 57 us of mostly
-        # latency) go to a helper stream behind the scan, the scatter (49 us, all CUs) is queued on this stream beside them
-        fork = fork_sort and M > 0 and not torch.cuda.is_current_stream_capturing()
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if fork else None
         _lib.check(
-            L.wcn_kmap_tally_sort_forked(_lib.ptr(mask), _lib.ptr(nbr), M, K, _lib.ptr(block_counts), _lib.ptr(meta),
-                                         _lib.ptr(meta[K + 1 :]), ctypes.c_void_p(meta_host.data_ptr()), _lib.ptr(perm),
-                                         _lib.ptr(sort_ws), sort_bytes, _lib.ptr(in_coords) if use_binned else None,
-                                         _lib.ptr(bin_ws), N if use_binned else 0, max_blocks if use_binned else 0, stream,
-                                         ctypes.c_void_p(side.cuda_stream) if fork else stream),
-            "wcn_kmap_tally_sort_forked",
+            L.wcn_kmap_tally_sort(_lib.ptr(mask), _lib.ptr(nbr), M, K, _lib.ptr(block_counts), _lib.ptr(meta),
+                                  _lib.ptr(meta[K + 1 :]), ctypes.c_void_p(meta_host.data_ptr()), _lib.ptr(perm),
+                                  _lib.ptr(sort_ws), sort_bytes, _lib.ptr(in_coords) if use_binned else None,
+                                  _lib.ptr(bin_ws), N if use_binned else 0, max_blocks if use_binned else 0, stream),
+            "wcn_kmap_tally_sort",
         )
         event = torch.cuda.Event()
-        event.record(main)  # (behind tally + scan: the status word's event)
-        join = None
-        if fork:
-            join = torch.cuda.Event()
-            join.record(side)
-            for t_ in (mask, perm, sort_ws):
-                t_.record_stream(side)
+        event.record(torch.cuda.current_stream(dev))
         return dict(nbr=nbr, mask=mask, perm=perm, block_counts=block_counts, meta=meta, meta_host=meta_host, ready=ready,
-                    event=event, table=table, keep=(bin_ws, sort_ws), join=join)
+                    event=event, table=table, keep=(bin_ws, sort_ws))
 
     def settle(b):
         """Wait for the status word of build `b`; rebuild while the device asks for it.  -> (build, flags, rebuilt)"""
@@ -337,8 +313,6 @@ def generate_kernel_map(
             else:
                 return b, flags, rebuilt
             b, rebuilt = launch(), True
-            if b["join"] is not None:
-                torch.cuda.current_stream(dev).wait_event(b["join"])
 
     def attach_tables(result, b):
         result._nbr, result._mask, result._perm = b["nbr"], b["mask"], b["perm"]
@@ -406,7 +380,7 @@ def generate_kernel_map(
         # build the device rejects (block table too small, duplicate coordinates that need the strict insert) is redone
         # inside validate(), which then reports that the tables changed.
         attach_tables(result, first)
-        if spec_pairs_ok:
+        if need_pairs and K * M * 8 <= (1 << 30):
             # the pair lists (the weight gradient's input) without knowing the pair count: buffers of worst-case length K * M
             # (address space only - L entries are ever touched), the scatter queued right behind the mask sort while the
             # neighbour table is still in the Infinity Cache; validate() cuts the views to the real length
@@ -420,8 +394,6 @@ def generate_kernel_map(
                 "wcn_kmap_scatter",
             )
             first["spec_pairs"] = (in_full, out_full)
-        if first["join"] is not None:
-            torch.cuda.current_stream(dev).wait_event(first["join"])  # `perm` is complete before anything queued from here on
 
         def validate_fn(res, b=first):
             b2, flags, rebuilt = settle(b)
