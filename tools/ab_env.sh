@@ -4,7 +4,7 @@ SCENES=$1; shift
 mkdir -p gpurun_out/ab
 for scene in $SCENES; do
 for envs in "$@"; do
-  tag=$(echo "$envs" | tr ' =' '__')
+  tag=$(echo "$envs" | tr ' =/.' '____' | tail -c 60)
   f=gpurun_out/ab/bench_${scene}_$tag.json
   env $envs python bench.py --steps 40 --warmup 5 --no-secondary --no-cpu-baseline --scene $scene > $f 2> ${f%.json}.err
   python - "$f" "$scene [$envs]" <<'PY'
