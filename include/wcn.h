@@ -376,6 +376,14 @@ int wcn_pointconv_edge_backward(const float* in_feats, const float* q_feats, con
                                 const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
                                 int32_t linear_shortcut, const float* grad_out, float* d_in, float* d_q, float* d_params,
                                 void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+/* Bitwise-reproducible variant (uniform lists): per-EDGE input gradients d_edge [n_query * k][cin] by plain stores instead of
+ * the fp32 atomics on d_in; the caller sums the rows of each input point in a fixed order.  Used when the framework asks
+ * for deterministic algorithms; reference: autograd of `features[neighbors]` (point_conv.py:243-246) is an index_add. */
+int wcn_pointconv_edge_backward_peredge(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                                        const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
+                                        const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
+                                        int32_t linear_shortcut, const float* grad_out, float* d_edge, float* d_q,
+                                        float* d_params, void* workspace, size_t workspace_bytes, wcn_stream_t stream);
 
 /* The same pipeline over RAGGED neighbour lists (radius search, warpconvnet/geometry/coords/search/radius.py): `nbr`
  * [n_edges] = the lists of the queries behind each other, `edge_q` [n_edges] the query of every edge (non-decreasing, i.e.

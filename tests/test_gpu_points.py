@@ -472,3 +472,43 @@ def test_pointconv_fused_edge_kernel_other_query_sets(kind):
     for (name, p), (_, pr) in zip(conv.named_parameters(), ref.named_parameters()):
         err = float((p.grad.cpu().double() - pr.grad).abs().max()) / (float(pr.grad.abs().max()) + 1e-12)
         assert err < 1e-3, f"{name}: relative max error {err:.2e}"
+
+
+@pytest.mark.gpu
+def test_pointconv_backward_bitwise_repeatable_when_deterministic():
+    """The input gradient of the one-kernel PointConv backward is a scatter-add over the neighbour lists: fp32 atomics by
+    default (like `index_add` in the reference's autograd).  Under `torch.use_deterministic_algorithms(True)` the kernel
+    writes per-edge rows instead and the rows of every input point are added in ascending edge order: two runs are
+    bitwise identical, and equal to the atomic path within fp32 summation error."""
+    from warpconvnet_amd.geometry.coords.search.search_configs import RealSearchConfig
+    from warpconvnet_amd.geometry.types.points import Points
+    from warpconvnet_amd.nn.modules import PointConv
+
+    dev = _dev()
+    n, cin, cout, k = 6000, 32, 64, 16
+    g = torch.Generator().manual_seed(11)
+    coords = (torch.rand(n, 3, generator=g) * 6.0).to(dev)
+    feats = torch.randn(n, cin, generator=g).to(dev)
+    torch.manual_seed(3)
+    conv = PointConv(cin, cout, RealSearchConfig(mode="knn", knn_k=k), reductions=("mean",)).to(dev)
+    dy = torch.randn(n, cout, generator=g).to(dev)
+
+    def grads(deterministic):
+        conv.zero_grad(set_to_none=True)
+        x = feats.clone().requires_grad_(True)
+        prev = torch.are_deterministic_algorithms_enabled()
+        torch.use_deterministic_algorithms(deterministic)
+        try:
+            out = conv(Points(coords, x, offsets=torch.tensor([0, n]))).feature_tensor
+            out.backward(dy)
+        finally:
+            torch.use_deterministic_algorithms(prev)
+        return x.grad.clone(), [p.grad.clone() for p in conv.parameters()]
+
+    a, pa = grads(True)
+    b, pb = grads(True)
+    assert torch.equal(a, b), "deterministic input gradient differs between two runs"
+    for u, v in zip(pa, pb):
+        assert torch.equal(u, v)  # parameter gradients: fixed-order partial sums in both modes
+    c, _ = grads(False)
+    assert (a - c).abs().max() <= 1e-4 * max(1.0, float(c.abs().max()))

@@ -174,6 +174,12 @@ SIGNATURES = {
                                                       c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                       c_void_p],
     ),
+    "wcn_pointconv_edge_backward_peredge": (
+        c_int,
+        [c_void_p] * 5 + [c_int64] + [c_int32] * 4 + [c_void_p, c_int32, c_int32, ctypes.c_float, ctypes.c_float, c_int32,
+                                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                      c_void_p],
+    ),
     "wcn_pointconv_edge_forward_ragged": (
         c_int,
         [c_void_p] * 7 + [c_int64, c_int64] + [c_int32] * 3 + [c_void_p, c_int32, c_int32, ctypes.c_float, ctypes.c_float,

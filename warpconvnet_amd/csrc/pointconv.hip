@@ -105,6 +105,8 @@ struct PcArgs {
   float* out;                  // forward:  [n_query][co_t]
   const float* grad_out;       // backward: [n_query][co_t]
   float* d_in;                 //           [n_in][cin], zero-filled by the caller (accumulated with atomics)
+  float* d_edge;               //           deterministic mode (uniform lists): [n_edges][cin] per-edge input gradients, plain
+                               //           stores instead of the atomics on d_in; the caller sums them per input row
   float* d_q;                  //           [n_query][cq]
   float* partial;              //           [grid][grad floats] per-workgroup parameter-gradient partials
 };
@@ -677,10 +679,18 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void pointconv_edge_kernel(const 
           }
         }
     __syncthreads();  // 5: dxt
-    for (int i = tid; i < 32 * a.cin; i += 256) {
-      const int ee = i / a.cin, c = i - ee * a.cin;
-      const int32_t jj = jt[ee];
-      if (jj >= 0) unsafeAtomicAdd(a.d_in + (int64_t)jj * a.cin + c, dxt[ee * (EIN + 1) + c]);  // hardware fp32 add, no CAS loop
+    if (a.d_edge) {  // deterministic mode: the tile's 32 rows, whole rows by adjacent lanes
+      for (int i = tid; i < 32 * a.cin; i += 256) {
+        const int ee = i / a.cin, c = i - ee * a.cin;
+        const int64_t E = tile * 32 + ee;
+        if (E < n_edges) a.d_edge[E * a.cin + c] = jt[ee] >= 0 ? dxt[ee * (EIN + 1) + c] : 0.f;
+      }
+    } else {
+      for (int i = tid; i < 32 * a.cin; i += 256) {
+        const int ee = i / a.cin, c = i - ee * a.cin;
+        const int32_t jj = jt[ee];
+        if (jj >= 0) unsafeAtomicAdd(a.d_in + (int64_t)jj * a.cin + c, dxt[ee * (EIN + 1) + c]);  // hardware fp32 add, no CAS loop
+      }
     }
     if (ragged) {  // query-side gradient: segments as in the forward reduction, added to the (zero-filled) rows
       for (int i = tid; i < 4 * a.cq; i += 256) {
@@ -1196,6 +1206,7 @@ static int fill_args(PcArgs& a, const float* in_feats, const float* q_feats, con
   a.n_query = n_query; a.log2k = log2_exact(k); a.cin = cin; a.cq = cq; a.nrel = nrel;
   a.packed = packed; a.ein_t = cin + cq + nrel; a.hid_t = hidden; a.co_t = cout;
   a.eps1 = eps1; a.eps2 = eps2; a.scale = mean ? 1.f / (float)k : 1.f; a.lin_sc = linear_shortcut ? 1 : 0;
+  a.d_edge = nullptr;
   return WCN_SUCCESS;
 }
 
@@ -1253,6 +1264,23 @@ int wcn_pointconv_edge_backward(const float* in_feats, const float* q_feats, con
                            eps2, mean, linear_shortcut);
   if (rc != WCN_SUCCESS) return rc;
   return run_backward(a, grad_out, d_in, d_q, d_params, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Bitwise-reproducible variant for uniform lists: the input gradient of every EDGE goes to `d_edge` [n_query * k][cin] with
+// plain stores (no atomics; `d_in` is not touched), the caller adds the rows of each input point in a fixed order (sorted
+// edge ids).  Everything else - d_q, the parameter gradients - is deterministic in both variants.
+int wcn_pointconv_edge_backward_peredge(const float* in_feats, const float* q_feats, const float* in_xyz, const float* q_xyz,
+                                        const int32_t* nbr, int64_t n_query, int32_t k, int32_t cin, int32_t cq, int32_t nrel,
+                                        const float* packed, int32_t hidden, int32_t cout, float eps1, float eps2, int32_t mean,
+                                        int32_t linear_shortcut, const float* grad_out, float* d_edge, float* d_q,
+                                        float* d_params, void* workspace, size_t workspace_bytes, void* stream) {
+  PcArgs a;
+  const int rc = fill_args(a, in_feats, q_feats, in_xyz, q_xyz, nbr, n_query, k, cin, cq, nrel, packed, hidden, cout, eps1,
+                           eps2, mean, linear_shortcut);
+  if (rc != WCN_SUCCESS) return rc;
+  if (!d_edge) return WCN_ERROR_INVALID_PARAMETERS;
+  a.d_edge = d_edge;
+  return run_backward(a, grad_out, d_edge, d_q, d_params, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // Ragged neighbour lists (radius search): `nbr` [n_edges] with the lists of the queries behind each other, `edge_q`

@@ -105,9 +105,29 @@ class _FusedEdge(torch.autograd.Function):
         dev = in_feats.device
         ein = cin + cq + nrel
         grad_out = grad_out.contiguous().float()
-        d_in = torch.zeros_like(in_feats)
         grads = torch.empty(L.wcn_pointconv_grad_floats(ein, hid, co, lin), dtype=torch.float32, device=dev)
-        if edge_q is None:
+        if edge_q is None and torch.are_deterministic_algorithms_enabled():
+            # bitwise-reproducible input gradient: per-edge rows by plain stores, then the rows of every input point added in
+            # ascending edge order (stable sort of the neighbour ids + CSR segment sum) - no fp32 atomics anywhere
+            from warpconvnet_amd.ops.reductions import row_reduction
+
+            d_q = torch.empty_like(q_feats)
+            d_edge = torch.empty(M * k, cin, dtype=torch.float32, device=dev)
+            ws_bytes = L.wcn_pointconv_backward_workspace(M, k, ein, hid, co, lin)
+            ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+            _lib.check(L.wcn_pointconv_edge_backward_peredge(
+                _lib.ptr(in_feats), _lib.ptr(q_feats), _lib.ptr(in_xyz), _lib.ptr(q_xyz), _lib.ptr(nbr), M, k, cin, cq, nrel,
+                _lib.ptr(packed), hid, co, eps1, eps2, mean, lin, _lib.ptr(grad_out), _lib.ptr(d_edge), _lib.ptr(d_q),
+                _lib.ptr(grads), _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)), "wcn_pointconv_edge_backward_peredge")
+            ids = nbr.reshape(-1).long()
+            valid = ids >= 0
+            order = torch.sort(torch.where(valid, ids, torch.full_like(ids, in_feats.shape[0])), stable=True).indices
+            counts = torch.bincount(ids[valid], minlength=in_feats.shape[0])
+            splits = torch.zeros(in_feats.shape[0] + 1, dtype=torch.int64, device=dev)
+            splits[1:] = counts.cumsum(0)
+            d_in = row_reduction(d_edge[order[: int(splits[-1])]], splits, "sum")
+        elif edge_q is None:
+            d_in = torch.zeros_like(in_feats)
             d_q = torch.empty_like(q_feats)
             ws_bytes = L.wcn_pointconv_backward_workspace(M, k, ein, hid, co, lin)
             ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
@@ -116,6 +136,7 @@ class _FusedEdge(torch.autograd.Function):
                 _lib.ptr(packed), hid, co, eps1, eps2, mean, lin, _lib.ptr(grad_out), _lib.ptr(d_in), _lib.ptr(d_q),
                 _lib.ptr(grads), _lib.ptr(ws), ws_bytes, _lib.stream_handle(dev)), "wcn_pointconv_edge_backward")
         else:
+            d_in = torch.zeros_like(in_feats)
             d_q = torch.zeros_like(q_feats)
             E = nbr.numel()
             ws_bytes = L.wcn_pointconv_backward_workspace(E, 1, ein, hid, co, lin)
