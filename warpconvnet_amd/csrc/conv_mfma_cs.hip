@@ -16,8 +16,12 @@
 //     (the register-gather kernel gives a wave the rows and lets it idle at the barrier when its rows lack the offset);
 //   * rows that lack the offset read a 128-B zero row in LDS instead of their stage slot (one address select per
 //     32-row block and step; no zero fills, no per-fragment selects).
-// Workgroup = 4 waves = WR row groups x WC channel slices, WC = CO / 32, tile = 128 rows for every width:
-//   CO = 128: 1 x 4, a wave holds 4 row blocks x 32 channels;  CO = 64: 2 x 2, 2 row blocks;  CO = 32: 4 x 1, 1 row block.
+// Workgroup = WR row groups x WC channel slices waves, WC = CO / 32 (shapes measured in DESIGN.md section 4.2a):
+//   CO = 128: 4 waves, 128-row tile, a wave holds 4 row blocks x 32 channels;  CO = 96: 3 waves, 96-row tile;
+//   CO = 64: 2 waves, 64-row tile.  cin % 64 == 32: the last chunk requests the four pieces that exist, the packed image
+//   carries zero weights for the rest.  Three workgroups per CU (CO = 128: 157 VGPRs, 47.7 KB of LDS).
+// What was measured on top of this structure and NOT kept (ring depth 3 with counted waits, persistent workgroups with a
+// pipelined prologue, dense packing of a step's rows, 128-channel steps, 64-row tiles): DESIGN.md section 4.2a.
 //
 // Math and epilogue exactly as conv_mfma.hip (same C-ABI entry points pick the kernel by shape):
 //   out[r] = act((sum_k in[nbr[r][k]] . W[k] + bias) * scale + shift + residual).
