@@ -432,12 +432,13 @@ size_t wcn_bn_workspace(int32_t channels);
 /*   wcn_bn_stats_fold       wcn_bn_stats plus, in the same launches, everything a training step derives from the
  *                           statistics: rstd = 1/sqrt(var + eps), scale = gamma * rstd, shift = beta - mean * scale (gamma /
  *                           beta may be NULL) and the in-place update of the fp32 running statistics (NULL: none) with
- *                           `momentum` and the unbiased variance - the ~10 tiny framework kernels of a BatchNorm step.
+ *                           `momentum` and the unbiased variance - the ~10 tiny framework kernels of a BatchNorm step;
+ *                           `num_batches_tracked` (device int64 scalar, NULL: none) is incremented by one.
  *   wcn_bn_fold             inference: mean / rstd / scale / shift from the running statistics, one launch. */
 int wcn_bn_stats_fold(const void* x, int64_t n, int32_t channels, int32_t dtype, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, float* mean, float* var,
-                      float* rstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
-                      wcn_stream_t stream);
+                      float* rstd, float* scale, float* shift, int64_t* num_batches_tracked, void* workspace,
+                      size_t workspace_bytes, wcn_stream_t stream);
 int wcn_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
                 int32_t channels, float* mean, float* rstd, float* scale, float* shift, wcn_stream_t stream);
 int wcn_bn_stats(const void* x, int64_t n, int32_t channels, int32_t dtype, float* mean, float* var, void* workspace,

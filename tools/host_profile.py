@@ -56,6 +56,8 @@ pr = cProfile.Profile()
 pr.enable()
 losses = [fwd() for _ in range(5)]
 pr.disable()
+os.makedirs("gpurun_out", exist_ok=True)
+pr.dump_stats("gpurun_out/host_fwd.pstats")
 print("---- forward (5 iterations), by tottime")
 pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 print("---- forward (5 iterations), by cumulative time")
@@ -79,6 +81,7 @@ threading.setprofile(None)
 torch.cuda.synchronize()
 for tid, p in profs.items():
     p.disable()
+    p.dump_stats(f"gpurun_out/host_bwd_{len(profs)}_{tid}.pstats")
     print(f"---- backward thread {tid} (5 iterations), by tottime")
     try:
         pstats.Stats(p).sort_stats("tottime").print_stats(25)

@@ -44,7 +44,7 @@ SIGNATURES = {
     "wcn_bn_workspace": (c_size_t, [c_int32]),
     "wcn_bn_stats": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wcn_bn_stats_fold": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float,
-                                  ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                   c_void_p]),
     "wcn_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int32, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),

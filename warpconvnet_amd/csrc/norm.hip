@@ -140,6 +140,7 @@ struct BnFold {  // optional tail of the statistics pass: everything a training 
   float* rstd = nullptr;          // [c] out (null: only mean / var are produced)
   float* scale = nullptr;         // [c] out: gamma * rstd
   float* shift = nullptr;         // [c] out: beta - mean * scale
+  long long* batches = nullptr;   // nn.BatchNorm's num_batches_tracked (int64 scalar), += 1, or null
 };
 
 template <typename T, int MODE>
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(64) void norm_final_kernel(const float* __restrict_
           f.running_mean[ch] = (1.0f - f.momentum) * f.running_mean[ch] + f.momentum * mean;
           f.running_var[ch] = (1.0f - f.momentum) * f.running_var[ch] + f.momentum * var * unbias;
         }
+        if (f.batches && ch == 0) *f.batches += 1;
       }
     } else {
       out0[ch] = t0;
@@ -344,14 +346,15 @@ int wcn_bn_stats(const void* x, int64_t n, int32_t channels, int32_t dtype, floa
 
 int wcn_bn_stats_fold(const void* x, int64_t n, int32_t channels, int32_t dtype, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, float* mean, float* var,
-                      float* rstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
-                      wcn_stream_t stream) {
+                      float* rstd, float* scale, float* shift, int64_t* num_batches_tracked, void* workspace,
+                      size_t workspace_bytes, wcn_stream_t stream) {
   if (n < 1 || channels < 1 || !bn_dtype_ok(dtype) || !x || !mean || !var || !rstd || !scale || !shift || !workspace ||
       workspace_bytes < wcn_bn_workspace(channels) || ((running_mean == nullptr) != (running_var == nullptr)))
     return WCN_ERROR_INVALID_PARAMETERS;
   BnFold f;
   f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var;
   f.momentum = momentum; f.eps = eps; f.rstd = rstd; f.scale = scale; f.shift = shift;
+  f.batches = reinterpret_cast<long long*>(num_batches_tracked);
   hipStream_t s = (hipStream_t)stream;
   float* p = (float*)workspace;
   switch (dtype) {

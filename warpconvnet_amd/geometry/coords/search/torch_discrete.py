@@ -215,7 +215,7 @@ def generate_kernel_map(
     ksize = ntuple(kernel_size, 3)
     stride = ntuple(in_to_out_stride_ratio, 3)
     dilation = ntuple(kernel_dilation if kernel_dilation is not None else 1, 3)
-    K = int(np.prod(ksize))
+    K = ksize[0] * ksize[1] * ksize[2]
 
     in_coords = batch_indexed_in_coords.contiguous()
     out_coords = in_coords if same_tensor else batch_indexed_out_coords.contiguous()

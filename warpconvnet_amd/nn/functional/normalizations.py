@@ -7,6 +7,7 @@ same function (training: batch statistics, running-statistics update with the un
 cumulative average; eval: running statistics) as four streaming passes, with the ReLU that follows in a ConvBlock
 fused into the apply pass and its mask into the backward passes.  fp32 statistics, fixed-order reductions.
 """
+import os
 from typing import Optional
 
 import torch
@@ -18,8 +19,6 @@ from warpconvnet_amd import _lib
 
 def hip_batch_norm_supported(x: Tensor) -> bool:
     """2-D non-empty f32 / f16 / bf16 GPU tensor, and not switched off with WARPCONVNET_AMD_HIP_BATCHNORM=0."""
-    import os
-
     return (x.is_cuda and x.ndim == 2 and x.shape[0] > 0
             and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
             and os.environ.get("WARPCONVNET_AMD_HIP_BATCHNORM", "1") not in ("0", "false"))
@@ -53,7 +52,8 @@ def _apply(x: Tensor, scale: Tensor, shift: Tensor, relu: bool) -> Tensor:
 class _HipBatchNorm(Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], running_mean: Optional[Tensor],
-                running_var: Optional[Tensor], training: bool, momentum: float, eps: float, relu: bool) -> Tensor:
+                running_var: Optional[Tensor], training: bool, momentum: float, eps: float, relu: bool,
+                batches: Optional[Tensor] = None) -> Tensor:
         x = x.contiguous()
         n, c = x.shape
         dev = x.device
@@ -74,8 +74,8 @@ class _HipBatchNorm(Function):
                 L.wcn_bn_stats_fold(_lib.ptr(x), n, c, _lib.dtype_code(x.dtype), _lib.ptr(gamma), _lib.ptr(beta),
                                     _lib.ptr(running_mean) if fused_running else None,
                                     _lib.ptr(running_var) if fused_running else None, momentum, eps, _lib.ptr(mean),
-                                    _lib.ptr(var), _lib.ptr(rstd), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(ws), ws.numel(),
-                                    _lib.stream_handle(dev)),
+                                    _lib.ptr(var), _lib.ptr(rstd), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(batches), _lib.ptr(ws),
+                                    ws.numel(), _lib.stream_handle(dev)),
                 "wcn_bn_stats_fold",
             )
             if running_mean is not None and not fused_running:  # in place, like F.batch_norm: unbiased variance
@@ -128,32 +128,44 @@ class _HipBatchNorm(Function):
             )
         dw = sum_dy_xhat.to(ctx.wdtype) if (ctx.wdtype is not None and ctx.needs_input_grad[1]) else None
         db = sum_dy.to(ctx.bdtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def hip_batch_norm(x: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], weight: Optional[Tensor] = None,
                    bias: Optional[Tensor] = None, training: bool = False, momentum: float = 0.1, eps: float = 1e-5,
-                   relu: bool = False) -> Tensor:
+                   relu: bool = False, num_batches_tracked: Optional[Tensor] = None) -> Tensor:
     """``F.batch_norm`` for ``[N, C]`` GPU features (+ optional fused ReLU).  ``training`` without running statistics uses
-    batch statistics only; eval needs running statistics."""
+    batch statistics only; eval needs running statistics.  ``num_batches_tracked`` (training, int64 scalar on the same
+    device): incremented by the statistics kernel instead of a launch of its own."""
     if not hip_batch_norm_supported(x):
         raise RuntimeError(f"hip_batch_norm needs a non-empty 2-D f32/f16/bf16 GPU tensor, got {tuple(x.shape)} {x.dtype} {x.device}")
     if not training and (running_mean is None or running_var is None):
         raise ValueError("hip_batch_norm in eval mode needs running statistics")
     if training and x.shape[0] == 1:  # same refusal as F.batch_norm: a single row has no variance
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
-    return _HipBatchNorm.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), bool(relu))
+    if num_batches_tracked is not None and not (training and num_batches_tracked.dtype == torch.int64
+                                                and num_batches_tracked.device == x.device and num_batches_tracked.numel() == 1):
+        raise ValueError("num_batches_tracked must be an int64 scalar on the features' device, training mode only")
+    return _HipBatchNorm.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), bool(relu),
+                               num_batches_tracked)
 
 
 def batch_norm_module_forward(norm: torch.nn.modules.batchnorm._BatchNorm, x: Tensor, relu: bool = False) -> Tensor:
     """``nn.BatchNorm1d.forward`` on ``[N, C]`` features through the HIP kernels: the module's bookkeeping
     (``num_batches_tracked``, cumulative average when ``momentum is None``) followed by :func:`hip_batch_norm`."""
     momentum = 0.0 if norm.momentum is None else norm.momentum
+    counter = None
     if norm.training and norm.track_running_stats and norm.num_batches_tracked is not None:
-        norm.num_batches_tracked.add_(1)
-        if norm.momentum is None:
-            momentum = 1.0 / float(norm.num_batches_tracked)
+        nbt = norm.num_batches_tracked
+        if (norm.momentum is not None and nbt.dtype == torch.int64 and nbt.device == x.device
+                and norm.running_mean is not None and norm.running_mean.dtype == torch.float32
+                and norm.running_var.dtype == torch.float32 and norm.running_mean.is_contiguous() and norm.running_var.is_contiguous()):
+            counter = nbt  # the statistics kernel adds the one (it updates the running statistics in the same place)
+        else:
+            nbt.add_(1)
+            if norm.momentum is None:
+                momentum = 1.0 / float(nbt)
     use_batch_stats = norm.training or (norm.running_mean is None and norm.running_var is None)
     rm = norm.running_mean if (not norm.training or norm.track_running_stats) else None
     rv = norm.running_var if (not norm.training or norm.track_running_stats) else None
-    return hip_batch_norm(x, rm, rv, norm.weight, norm.bias, use_batch_stats, momentum, norm.eps, relu)
+    return hip_batch_norm(x, rm, rv, norm.weight, norm.bias, use_batch_stats, momentum, norm.eps, relu, counter)

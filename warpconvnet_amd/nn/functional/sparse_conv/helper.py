@@ -7,7 +7,8 @@ Counterpart of `warpconvnet/nn/functional/sparse_conv/helper.py:147-567` (``spat
 from enum import Enum
 from typing import List, Optional, Tuple, Union
 
-import numpy as np
+import math
+
 import torch
 
 from warpconvnet_amd.utils.compile_guard import eager_unless_compiling
@@ -175,7 +176,7 @@ def spatially_sparse_conv(
     _stride = ntuple(stride, ndim=nd)
 
     # 1x1 kernel, stride 1: a plain matmul on the features (reference helper.py:206-213)
-    if int(np.prod(_kernel_size)) == 1 and int(np.prod(_stride)) == 1:
+    if math.prod(_kernel_size) == 1 and math.prod(_stride) == 1:
         from warpconvnet_amd.nn.functional.sparse_conv.pointwise import pointwise_conv
 
         feats = input_sparse_tensor.feature_tensor
@@ -222,7 +223,7 @@ def spatially_sparse_conv(
         input_sparse_tensor, _kernel_size, _dilation, _stride, generative=generative, transposed=transposed,
         output_spatially_sparse_tensor=output_spatially_sparse_tensor, stride_mode=stride_mode, order=order,
         need_pairs=torch.is_grad_enabled(),  # (the map builders run under no_grad: the caller's mode is read here)
-        optimistic=input_sparse_tensor.feature_tensor.is_cuda,
+        optimistic=input_sparse_tensor.batched_features.batched_tensor.is_cuda,  # (not feature_tensor: that casts under autocast)
     )
     num_out = bcoords_out.shape[0]
     # (training: the builder has queued the pair-list scatter on a helper stream - right behind the scan, while the
@@ -253,6 +254,8 @@ def spatially_sparse_conv(
         out_coords = IntCoords(bcoords_out[:, 1:], offsets=out_offsets_cpu)
         if bcoords_out.dtype == torch.int32 and bcoords_out.is_contiguous():
             out_coords.__dict__["_bcoords"] = bcoords_out  # (base/coords.py: the cached batch-indexed form)
+    if out_coords is input_sparse_tensor.batched_coordinates and input_sparse_tensor.tensor_stride == out_tensor_stride:
+        return input_sparse_tensor.replace(batched_features=out_feats)  # nothing but the features changed: no re-validation
     return input_sparse_tensor.replace(
         batched_coordinates=out_coords,
         batched_features=out_feats,

@@ -6,13 +6,22 @@ import torch
 
 def ntuple(x: Union[int, Sequence[int], torch.Tensor], ndim: int) -> Tuple[int, ...]:
     """Broadcast an int (or validate a sequence) to an ``ndim``-tuple of ints."""
+    if type(x) is tuple:  # the per-layer case (module attributes): one dict lookup
+        hit = _NTUPLES.get((x, ndim))
+        if hit is not None:
+            return hit
     if isinstance(x, torch.Tensor):
         x = [int(v) for v in x.reshape(-1).tolist()]
     if isinstance(x, int):
         return (x,) * ndim
     out = tuple(int(v) for v in x)
     assert len(out) == ndim, f"expected {ndim} values, got {out}"
+    if type(x) is tuple and len(_NTUPLES) < 4096:
+        _NTUPLES[(x, ndim)] = out
     return out
+
+
+_NTUPLES = {}
 
 
 def _pad_values(number_of_outputs: int, *values: Any) -> Tuple[Any, ...]:
