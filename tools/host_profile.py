@@ -1,6 +1,6 @@
 """Dev tool: where the HOST time of a MinkUNet-14 iteration goes (the network is host-bound below ~1 M voxels).
-Prints forward / backward host-enqueue time and a cProfile table of the forward (main thread) and of the backward
-(autograd worker thread, profiled through threading.setprofile).  GPU box only.
+Prints forward / backward host-enqueue time and cProfile tables of the forward and of the backward (run with the autograd
+engine's worker threads off, so its nodes execute under the profiler); the .pstats files land in gpurun_out/.  GPU box only.
 
     python tools/host_profile.py [voxels]
 """
@@ -8,7 +8,6 @@ import cProfile
 import os
 import pstats
 import sys
-import threading
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -63,27 +62,14 @@ pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 print("---- forward (5 iterations), by cumulative time")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
 
-profs = {}
-
-
-def hook(frame, event, arg):  # per-thread profiler for the autograd worker
-    tid = threading.get_ident()
-    if tid not in profs:
-        profs[tid] = cProfile.Profile()
-        profs[tid].enable()
-    return None
-
-
-threading.setprofile(hook)
-for l in losses:
-    l.backward()
-threading.setprofile(None)
+# backward: with the engine's worker threads switched off the backward nodes run on this thread, under this profiler
+pb = cProfile.Profile()
+with torch.autograd.set_multithreading_enabled(False):
+    pb.enable()
+    for l in losses:
+        l.backward()
+    pb.disable()
 torch.cuda.synchronize()
-for tid, p in profs.items():
-    p.disable()
-    p.dump_stats(f"gpurun_out/host_bwd_{len(profs)}_{tid}.pstats")
-    print(f"---- backward thread {tid} (5 iterations), by tottime")
-    try:
-        pstats.Stats(p).sort_stats("tottime").print_stats(25)
-    except Exception as e:
-        print("no data", e)
+pb.dump_stats("gpurun_out/host_bwd.pstats")
+print("---- backward (5 iterations, single-threaded engine), by tottime")
+pstats.Stats(pb).sort_stats("tottime").print_stats(25)

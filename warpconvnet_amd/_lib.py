@@ -215,8 +215,8 @@ class _GuardedLib:
     def __getattr__(self, name):
         fn = getattr(self._h, name)
         argtypes = fn.argtypes or []
-        if not argtypes or argtypes[-1] is not c_void_p or name in _HOST_ONLY:
-            setattr(self, name, fn)
+        if not argtypes or argtypes[-1] is not c_void_p or name in _HOST_ONLY or _single_gpu():
+            setattr(self, name, fn)  # (one visible GPU: there is no other device to be current)
             return fn
 
         def guarded(*args, _fn=fn):
@@ -229,6 +229,13 @@ class _GuardedLib:
         guarded.__name__ = name
         setattr(self, name, guarded)
         return guarded
+
+
+def _single_gpu() -> bool:
+    try:
+        return torch.cuda.is_available() and torch.cuda.device_count() == 1
+    except Exception:
+        return False
 
 
 _HOST_ONLY = {"wcn_status_string"}

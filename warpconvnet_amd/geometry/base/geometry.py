@@ -14,12 +14,6 @@ from warpconvnet_amd.geometry.base.features import Features
 from warpconvnet_amd.geometry.features.cat import to_batched_features
 
 
-def _autocast_dtype() -> Optional[torch.dtype]:
-    if torch.is_autocast_enabled():
-        return torch.get_autocast_dtype("cuda")
-    return None
-
-
 class Geometry:
     def __init__(self, batched_coordinates: Union[Coords, Tensor], batched_features, **kwargs):
         offsets = kwargs.pop("offsets", None)
@@ -54,8 +48,11 @@ class Geometry:
     @property
     def feature_tensor(self) -> Tensor:
         t = self.batched_features.batched_tensor
-        amp = _autocast_dtype()
-        return t.to(dtype=amp) if amp is not None else t
+        if torch.is_autocast_enabled():
+            amp = torch.get_autocast_dtype("cuda")
+            if t.dtype != amp:
+                return t.to(dtype=amp)
+        return t
 
     features = feature_tensor
     feats = feature_tensor
