@@ -112,6 +112,16 @@ __global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__
   packed[e] = ci < cin ? (TD)w[src] : (TD)0;
 }
 
+#ifdef WCN_PROF
+// dev build (`make prof`, tools/prof_phases.py): thread 0 of every 4th workgroup stamps its phases - per slot: prologue, step
+// loop, epilogue clocks | 1 | steps | in-loop wait + barrier, request issue, LDS reads + MFMAs
+__device__ unsigned long long g_csprof[2048 * 8];
+#define CS_CLK() __builtin_readcyclecounter()
+#define CS_PROF(stmt) do { if (cs_prof) { stmt; } } while (0)
+#else
+#define CS_PROF(stmt)
+#endif
+
 // ---- main kernel --------------------------------------------------------------------------------------------------------
 template <typename T, int CO, int RBW_, int WR_, int MINW>
 __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_kernel(const T* __restrict__ in, const T* __restrict__ wp,
@@ -140,6 +150,10 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   const int nchunk = (cin + kCsCIC - 1) / kCsCIC;
   const int last_pieces = (cin - (nchunk - 1) * kCsCIC) / 8;  // 16-B pieces of the last chunk that exist (8, or 4 when cin % 64 == 32)
   const int64_t row0 = (int64_t)blockIdx.x * TILE;
+#ifdef WCN_PROF
+  const bool cs_prof = tid == 0 && (blockIdx.x & 3) == 0 && (blockIdx.x >> 2) < 2048;
+  unsigned long long pt0 = CS_CLK(), pt1 = 0, pt2 = 0, pa = 0, pw = 0, pi = 0, pc = 0, pn = 0;
+#endif
 
   // ---- output row ids (through the mask-sorted permutation), masks, index slab ----
   if (tid < TILE) {
@@ -305,22 +319,32 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     frag_t Wa[4], Wb[4];
     int k0 = -1, c0 = 0, k1 = -1, c1 = 0;
     next_step(k0, c0);
+    CS_PROF(pt1 = CS_CLK());
     issue_rows(0, k0, c0);
     load_w(Wa, k0, c0);
     for (;;) {
       k1 = k0; c1 = c0;
       const bool has1 = next_step(k1, c1);
+      CS_PROF(pa = CS_CLK());
       sync_step();  // stage 0 has landed for every wave; every wave is done reading stage 1
+      CS_PROF(pw += CS_CLK() - pa; pa = CS_CLK());
       if (has1) { issue_rows(1, k1, c1); load_w(Wb, k1, c1); }
+      CS_PROF(pi += CS_CLK() - pa; pa = CS_CLK());
       compute(Wa, 0, k0);
+      CS_PROF(pc += CS_CLK() - pa; ++pn);
       if (!has1) break;
       k0 = k1; c0 = c1;
       const bool has0 = next_step(k0, c0);
+      CS_PROF(pa = CS_CLK());
       sync_step();
+      CS_PROF(pw += CS_CLK() - pa; pa = CS_CLK());
       if (has0) { issue_rows(0, k0, c0); load_w(Wa, k0, c0); }
+      CS_PROF(pi += CS_CLK() - pa; pa = CS_CLK());
       compute(Wb, 1, k1);
+      CS_PROF(pc += CS_CLK() - pa; ++pn);
       if (!has0) break;
     }
+    CS_PROF(pt2 = CS_CLK());
   }
 
   // ---- epilogue: lane (h, n) of wave (rg, cs) holds channels cs*32 + 16*h + q, q = 0..15, of row (rg, rb, n) ----
@@ -405,6 +429,13 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       }
     }
   }
+#ifdef WCN_PROF
+  if (cs_prof) {
+    unsigned long long* p = g_csprof + (size_t)(blockIdx.x >> 2) * 8;
+    const unsigned long long pt3 = CS_CLK();
+    p[0] += pt1 - pt0; p[1] += pt2 - pt1; p[2] += pt3 - pt2; p[3] += 1; p[4] += pn; p[5] += pw; p[6] += pi; p[7] += pc;
+  }
+#endif
 }
 
 template <typename T, int CO, int RBW, int WR, int MINW>
@@ -484,3 +515,13 @@ int pack_weight_cs(const void* w, int w_is_f32, int K, int cin, int cout, int dt
 }
 
 }  // namespace wcn
+
+#ifdef WCN_PROF
+extern "C" int wcn_debug_read_prof_cs(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wcn::g_csprof), bytes);
+}
+extern "C" int wcn_debug_reset_prof_cs(void) {
+  static unsigned long long zeros[2048 * 8];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(wcn::g_csprof), zeros, sizeof(zeros));
+}
+#endif
