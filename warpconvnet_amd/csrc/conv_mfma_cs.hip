@@ -425,7 +425,13 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
           }
         }
         // streamed once: non-temporal, so the output does not push the gathered input out of the caches
+#if defined(CS_ABL_NOSTORE)
+        if (o[0] == (T)12345.f) *reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * CO + piece * 8) = o;  // dev ablation
+#elif defined(CS_ABL_PLAINSTORE)
+        *reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * CO + piece * 8) = o;  // dev ablation
+#else
         __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * CO + piece * 8));
+#endif
       }
     }
   }
