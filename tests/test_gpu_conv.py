@@ -666,3 +666,80 @@ def test_config4_batch_of_lidar_scale_scenes():
     dXr, dWr = oconv.backward(g.double().cpu(), X, Wd, r["in_maps"], r["out_maps"], r["offsets"])
     assert rel_max_err(x.feature_tensor.grad, dXr) < 2e-2 and rel_max_err(conv.weight.grad, dWr) < 2e-2
     assert y.offsets.tolist() == vox.offsets.tolist() and len(vox.offsets) == 9
+
+
+@pytest.mark.parametrize("case", ["table_full", "duplicates_out_of_order"])
+def test_module_path_relaunches_after_a_rejected_optimistic_build(case):
+    """`SparseConv3d` under autocast queues its forward kernel on the tables of an OPTIMISTIC build and validates afterwards
+    (`hip_gemm.hip_forward`): when the device rejects the first build - (i) block table too small for a very sparse scene,
+    (ii) duplicate coordinates whose later copy won a cell - the map is rebuilt and the forward repeated.  Hints reset, so
+    the branch is taken whatever ran before; Y / dX / dW against the fp64 oracle on the oracle's map."""
+    from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import default_hints
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    rng = np.random.default_rng(17)
+    if case == "table_full":
+        cells = rng.permutation(36 * 36 * 36)[:24000]  # one voxel per 8^3 block, neighbours across block faces
+        c = np.stack([cells // 1296 * 8 + 7 * (cells % 2), cells // 36 % 36 * 8, cells % 36 * 8], 1).astype(np.int32)
+    else:
+        base = scene_u(5000, 31)[:, 1:]
+        c = np.concatenate([base[:400][::-1], base], 0).astype(np.int32)  # the LATER copy of 400 coordinates comes first
+    default_hints().reset()
+    seen = []
+    real_validate = IntSearchResult.validate
+
+    def spy(self):
+        r = real_validate(self)
+        seen.append(r)
+        return r
+
+    torch.manual_seed(0)
+    conv = SparseConv3d(64, 128, 3).to(dev)
+    feats = torch.randn(len(c), 64)
+    vox = Voxels([torch.from_numpy(c)], [feats], device=dev)
+    x = vox.replace(batched_features=vox.feature_tensor.detach().clone().requires_grad_(True))
+    IntSearchResult.validate = spy
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(x)
+        g = torch.randn(len(c), 128, device=dev)
+        y.feature_tensor.backward(g.to(y.feature_tensor.dtype))
+    finally:
+        IntSearchResult.validate = real_validate
+    if case == "table_full":
+        assert True in seen, "the sparse scene must have taken the TABLE_FULL rebuild"
+    bc = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    r = okmap.kernel_map(bc, bc, (3, 3, 3))
+    km = next(iter(x.cache.values()))
+    np.testing.assert_array_equal(km._pair_table.cpu().numpy(), r["found"])
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+    Wd = conv.weight.detach().to(torch.bfloat16).double().cpu()
+    X = feats.to(torch.bfloat16).double()
+    Yr = oconv.forward(X, Wd, r["in_maps"], r["out_maps"], r["offsets"], len(bc)) + conv.bias.detach().double().cpu()
+    assert rel_max_err(y.feature_tensor, Yr) < 2e-2
+    dY = g.to(torch.bfloat16).double().cpu()
+    dXr, dWr = oconv.backward(dY, X, Wd, r["in_maps"], r["out_maps"], r["offsets"])
+    assert rel_max_err(x.feature_tensor.grad, dXr) < 2e-2
+    assert rel_max_err(conv.weight.grad, dWr) < 2e-2
+
+
+def test_rejected_build_is_not_served_from_the_cache():
+    """A coordinate outside the packed range: the convolution raises ValueError (reference `_packed_base.py:102-122`), the
+    map it had cached optimistically is evicted, and a second call on the same tensor raises again instead of running on
+    half-built tables."""
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    c = scene_u(3000, 41)[:, 1:].copy()
+    c[7, 0] = 131072
+    conv = SparseConv3d(64, 128, 3).to(dev)
+    vox = Voxels([torch.from_numpy(c)], [torch.randn(len(c), 64)], device=dev)
+    for _ in range(2):
+        with pytest.raises(ValueError):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                conv(vox)
+        assert vox.cache is None or len(vox.cache) == 0

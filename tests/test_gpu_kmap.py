@@ -350,3 +350,46 @@ def test_optimistic_build_validates_and_rebuilds(kmap_method):
     km3 = generate_kernel_map(c, c, (1, 1, 1), (3, 3, 3), optimistic=True)
     with pytest.raises(ValueError):
         km3.validate()
+    # a build the device rejected for good stays rejected: every later use raises again (the reference raises at build time
+    # and never hands out the map), no accessor returns half-built state
+    with pytest.raises(ValueError):
+        km3.validate()
+    with pytest.raises(ValueError):
+        km3.offsets
+    with pytest.raises(ValueError):
+        km3.identity_map_index
+
+
+def test_build_hints_are_explicit_state():
+    """The sizing guesses of the builder live in a `BuildHints` object (argument of `generate_kernel_map`; one default object per
+    process): with a fresh object the TABLE_FULL retry and the short pair-capacity guess are reached whatever ran before, the
+    object learns from them, and the maps are the oracle's either way."""
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import BuildHints, generate_kernel_map
+
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    # one voxel per 8^3 block: 30 000 occupied blocks against a first-try bound of max(1024, N / 16)
+    cells = rng.permutation(40 * 40 * 40)[:30000]
+    sparse = np.stack([np.zeros_like(cells), cells // 1600 * 8, cells // 40 % 40 * 8, cells % 40 * 8], 1).astype(np.int32)
+    a = torch.from_numpy(sparse).to(dev)
+    hints = BuildHints()
+    km = generate_kernel_map(a, a, (1, 1, 1), (3, 3, 3), optimistic=True, hints=hints)
+    assert km.validate() is True and hints.div < 16  # the device asked for a larger block table; remembered
+    _check_against_oracle(km, sparse, sparse, (3, 3, 3))
+    km_b = generate_kernel_map(a, a, (1, 1, 1), (3, 3, 3), optimistic=True, hints=hints)
+    assert km_b.validate() is False  # the learned bound fits at once
+    # pair lists written before the pair count is known: a guess of 1 pair per row is short for a dense scene - the
+    # lists are rewritten at their exact length, the tables stay (validate() reports no rebuild)
+    s = scene_u(6000, 22)
+    b = torch.from_numpy(s).to(dev)
+    short = BuildHints(pairs_per_row=0.5)
+    km2 = generate_kernel_map(b, b, (1, 1, 1), (3, 3, 3), optimistic=True, hints=short)
+    assert km2.validate() is False and short.pairs_per_row > 2.0
+    _check_against_oracle(km2, s, s, (3, 3, 3))
+    assert km2.in_maps_device.shape[0] == int(km2.offsets[-1])
+    # a generous guess is trimmed: the cached map does not pin a worst-case buffer
+    wide = BuildHints(pairs_per_row=27.0)
+    km3 = generate_kernel_map(b, b, (1, 1, 1), (3, 3, 3), optimistic=True, hints=wide)
+    km3.validate()
+    assert km3.in_maps_device.untyped_storage().nbytes() <= 4 * int(km3.offsets[-1]) + 1024
+    _check_against_oracle(km3, s, s, (3, 3, 3))

@@ -21,8 +21,8 @@ def _unflatten(children, ctx) -> IntSearchResult:
     self._in_maps, self._out_maps, self._offsets = children
     self._lazy_pairs = None
     self._num_offsets = len(children[2]) - 1
-    self.identity_map_index = ctx["identity_map_index"]
     self._init_tables()  # device tables are rebuilt from the CSR form on first use
+    self.identity_map_index = ctx["identity_map_index"]
     return self
 
 

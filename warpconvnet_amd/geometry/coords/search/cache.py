@@ -66,5 +66,11 @@ class IntSearchCache(dict):
     def put(self, key: IntSearchCacheKey, value: IntSearchResult):
         super().__setitem__(key, value)
 
+    def evict(self, key: IntSearchCacheKey, value: Optional[IntSearchResult] = None) -> None:
+        """Drop `key` (only if it still maps to `value`, when given): a map whose optimistic build the device rejected must
+        not be served again - the reference never caches a failed build."""
+        if key in self and (value is None or super().get(key) is value):
+            super().__delitem__(key)
+
     def __repr__(self):
         return f"{self.__class__.__name__}({len(self)} keys)"

@@ -72,8 +72,8 @@ class IntSearchResult:
         self._offsets = offsets_cpu
         self._lazy_pairs = None
         self._num_offsets = len(offsets_cpu) - 1
-        self.identity_map_index = identity_map_index
         self._init_tables()
+        self.identity_map_index = identity_map_index
 
     def _init_tables(self):
         # build-specific device tables (see module docstring)
@@ -89,6 +89,10 @@ class IntSearchResult:
         self._num_out: Optional[int] = None
         self._pair_table_cache: Optional[Tensor] = None
         self._validate_fn = None  # optimistic builds: reads the status word, finishes / repeats the build (see validate)
+        self._validating = False
+        self._identity: Optional[int] = None
+        self._validate_error: Optional[Exception] = None  # a build the device rejected for good: raised by every validate()
+        self._on_invalid = None  # called once when validation fails (the convolution evicts the map from its cache)
 
     @classmethod
     def _blank(cls, num_offsets: int, device) -> "IntSearchResult":
@@ -100,8 +104,8 @@ class IntSearchResult:
         self._lazy_pairs = None
         self._device = torch.device(device)
         self._num_offsets = num_offsets
-        self.identity_map_index = None
         self._init_tables()
+        self.identity_map_index = None
         return self
 
     @classmethod
@@ -115,16 +119,47 @@ class IntSearchResult:
         self.identity_map_index = identity_map_index
         return self
 
+    @property
+    def identity_map_index(self) -> Optional[int]:
+        """Offset whose bucket is the identity (output row i pairs with input row i), or None.  Known once the status word of
+        an optimistic build has been read, so the getter validates first."""
+        if (self._validate_fn is not None or self._validate_error is not None) and not self._validating:
+            self.validate()
+        return self._identity
+
+    @identity_map_index.setter
+    def identity_map_index(self, value: Optional[int]) -> None:
+        self._identity = value
+
     def validate(self) -> bool:
         """Read the status word of an OPTIMISTIC build (`generate_kernel_map(..., optimistic=True)`): raises the build-time
         errors (coordinate range, table capacity), fills offsets / identities / pair lists, and rebuilds the tables if the
         device rejected the first attempt.  Returns True when the device tables were REPLACED - launches made on the old
         ones must be repeated.  Idempotent and free once done; a no-op for every other map."""
+        err = getattr(self, "_validate_error", None)
+        if err is not None:
+            raise err  # the reference raises at every use of a failed build; so does this container
         fn = getattr(self, "_validate_fn", None)
-        if fn is None:
+        if fn is None or self._validating:
             return False
+        self._validating = True
+        try:
+            rebuilt = bool(fn(self))
+        except Exception as e:
+            # the device rejected the build for good (coordinate range, table capacity): the container stays unusable - its
+            # tables hold defined "no neighbour" rows, its lists do not exist - and says so every time
+            self._validate_fn = None
+            self._validate_error = e
+            cb, self._on_invalid = getattr(self, "_on_invalid", None), None
+            if cb is not None:
+                cb()
+            raise
+        finally:
+            self._validating = False
+        # (an interrupt - KeyboardInterrupt - leaves _validate_fn in place: the next call settles the same build)
         self._validate_fn = None
-        return bool(fn(self))
+        self._on_invalid = None
+        return rebuilt
 
     def _ensure_pairs(self):
         self.validate()

@@ -78,6 +78,7 @@ def attach_tables_from_csr(kmap: IntSearchResult, num_in: int, num_out: int) -> 
     Role of the reference's `_build_pair_table` + `_build_mask_and_argsort`
     (`nn/functional/sparse_conv/detail/mask_gemm.py:127-254`).
     """
+    kmap.validate()  # an optimistic map another consumer left unvalidated: settle (and possibly rebuild) it first
     if kmap._nbr is not None:
         return kmap
     dev = kmap.in_maps_device.device
@@ -104,6 +105,7 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
 
     Role of `_build_reverse_mask_data` (`mask_gemm.py:279-350`).
     """
+    kmap.validate()
     if kmap._rev is None:
         dev = kmap.in_maps_device.device
         K = len(kmap)
@@ -134,8 +136,42 @@ def _first_half(full: IntSearchResult) -> IntSearchResult:
 _SPIN_POLLS = 4000  # polls of the pinned READY word, ~0.1 us each: up to ~0.4 ms of spinning before the ordinary event wait
 
 
-# binned builder: does this process see scenes with >= 4 voxels per occupied 8^3 block?  (size of the first-try block table)
-_BINNED_HINT = {"div": 16}  # block-table bound = N / div (0.15 GB of workspace per million voxels), grown to N / 4 and N on TABLE_FULL
+class BuildHints:
+    """What earlier builds taught about the scenes of this job - sizing guesses only, results never depend on them:
+
+    * ``div``: first-try bound of the binned builder's block table, N / div occupied 8^3 blocks (0.15 GB of workspace per
+      million voxels at 16); the device reports TABLE_FULL for sparser scenes and the bound moves to N / 4, then N;
+    * ``pairs_per_row``: pairs per output row of the last maps - sizes the pair lists an OPTIMISTIC build writes before the
+      host has read the pair count (an underestimate is caught on the host: the pair count exceeds the capacity, the
+      kernel wrote nothing past it, and the lists are written again at their exact length).
+
+    ``generate_kernel_map(..., hints=...)`` takes an explicit object (tests pass fresh ones so that the rebuild branches
+    are reached deterministically); the default is one object per process, `default_hints()`."""
+
+    def __init__(self, div: int = 16, pairs_per_row: float = 12.0):
+        self.div = int(div)
+        self.pairs_per_row = float(pairs_per_row)
+
+    def reset(self) -> None:
+        self.__init__()
+
+    def max_blocks(self, n: int) -> int:
+        return max(1024, n // self.div) if self.div > 1 else max(n, 1)
+
+    def pair_capacity(self, rows: int, num_offsets: int) -> int:
+        return int(min(num_offsets * rows, rows * self.pairs_per_row * 1.25 + 4096))
+
+    def observe_pairs(self, rows: int, pairs: int) -> None:
+        if rows > 0:
+            seen = pairs / rows
+            self.pairs_per_row = seen if seen > self.pairs_per_row else 0.5 * (self.pairs_per_row + seen)
+
+
+_DEFAULT_HINTS = BuildHints()
+
+
+def default_hints() -> BuildHints:
+    return _DEFAULT_HINTS
 
 
 @eager_unless_compiling
@@ -151,6 +187,7 @@ def generate_kernel_map(
     skip_symmetric_kernel_map: bool = False,
     need_pairs: bool = True,
     optimistic: bool = False,
+    hints: Optional[BuildHints] = None,
     **kwargs,
 ) -> IntSearchResult:
     """Kernel map between integer coordinate sets: ``in = out * stride + offset[k]``.
@@ -235,11 +272,12 @@ def generate_kernel_map(
     if method_env == "binned" and not use_binned and N > 0:
         raise RuntimeError("WARPCONVNET_AMD_KMAP_METHOD=binned needs a submanifold map (same coordinate tensor, stride 1, "
                            "halo <= 8, K % 32 != 0)")
+    hints = hints if hints is not None else _DEFAULT_HINTS
     table_capacity = _next_power_of_2(max(16, 2 * N))
     # binned path: capacity of the block table.  Most scenes have >= 4 voxels per occupied 8^3 block (uniform 12 % occupancy:
     # 28, surfaces: ~64); sparser ones raise TABLE_FULL on the device and are rebuilt with one block per voxel (always
     # enough).  `strict`: see wcn.h.
-    state = {"max_blocks": max(1024, N // _BINNED_HINT["div"]) if _BINNED_HINT["div"] > 1 else max(N, 1), "strict": 0}
+    state = {"max_blocks": hints.max_blocks(N), "strict": 0}
     odd = all(k % 2 == 1 for k in ksize)
 
     def launch():
@@ -290,6 +328,20 @@ def generate_kernel_map(
         return dict(nbr=nbr, mask=mask, perm=perm, block_counts=block_counts, meta=meta, meta_host=meta_host, ready=ready,
                     event=event, table=table, keep=(bin_ws, sort_ws))
 
+    def scatter(b, capacity):
+        """Pair lists of build `b` (buckets ordered by output row), `capacity` entries each; the kernel writes nothing past
+        the capacity."""
+        capacity = max(int(capacity), 0)
+        in_maps = torch.empty(capacity, dtype=torch.int32, device=dev)
+        out_maps = torch.empty(capacity, dtype=torch.int32, device=dev)
+        _lib.check(
+            L.wcn_kmap_scatter(_lib.ptr(b["nbr"]), _lib.ptr(b["mask"]), M, K, _lib.ptr(b["block_counts"]), _lib.ptr(b["meta"]),
+                               _lib.ptr(in_maps), _lib.ptr(out_maps), capacity, _lib.ptr(b["meta"][K + 1 :]),
+                               _lib.stream_handle(dev)),
+            "wcn_kmap_scatter",
+        )
+        return in_maps, out_maps, capacity
+
     def settle(b):
         """Wait for the status word of build `b`; rebuild while the device asks for it.  -> (build, flags, rebuilt)"""
         rebuilt = False
@@ -304,10 +356,10 @@ def generate_kernel_map(
                 b["event"].synchronize()
             flags = int(b["meta_host"][K + 1])
             if use_binned and (flags & _lib.WCN_FLAG_TABLE_FULL) and state["max_blocks"] < N:
-                # this process sees sparser scenes than the bound assumed (>= 16, then >= 4 voxels per occupied 8^3 block):
-                # start with the next larger table from now on
-                _BINNED_HINT["div"] = 4 if _BINNED_HINT["div"] > 4 else 1
-                state["max_blocks"] = max(1024, N // 4) if _BINNED_HINT["div"] == 4 and state["max_blocks"] < max(1024, N // 4) else N
+                # these scenes are sparser than the bound assumed (>= 16, then >= 4 voxels per occupied 8^3 block): start
+                # with the next larger table from now on
+                hints.div = 4 if hints.div > 4 else 1
+                state["max_blocks"] = max(1024, N // 4) if hints.div == 4 and state["max_blocks"] < max(1024, N // 4) else N
             elif use_binned and (flags & _lib.WCN_FLAG_NEED_STRICT) and not state["strict"]:
                 state["strict"] = 1
             else:
@@ -321,7 +373,9 @@ def generate_kernel_map(
         result._keepalive = b  # (workspaces the queued kernels still read)
 
     def finalize(result, b, flags):
-        """Status word in hand: raise what the reference raises at build time, then offsets, identities, pair lists."""
+        """Status word in hand: raise what the reference raises at build time, then offsets, identities, pair lists.
+        (The forward / dgrad kernels read the neighbour table only, so nothing queued on the tables has to be repeated
+        when the speculative pair lists turn out too short.)"""
         PackedHashTable.raise_for_flags(flags, N, table_capacity)
         offsets_host = b["meta_host"][: K + 1].clone()
         pair_capacity = int(offsets_host[-1])
@@ -329,37 +383,34 @@ def generate_kernel_map(
         identity = K // 2 if (odd and unit_stride and N == M) else None
         if has_duplicates and same_tensor:
             identity = None  # "output row i == input row i at the centre offset" fails for the rows that lost their coordinate
-        nbr, mask, block_counts, meta = b["nbr"], b["mask"], b["block_counts"], b["meta"]
-
-        def scatter_pairs():
-            in_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
-            out_maps = torch.empty(pair_capacity, dtype=torch.int32, device=dev)
-            _lib.check(
-                L.wcn_kmap_scatter(_lib.ptr(nbr), _lib.ptr(mask), M, K, _lib.ptr(block_counts), _lib.ptr(meta), _lib.ptr(in_maps),
-                                   _lib.ptr(out_maps), pair_capacity, _lib.ptr(meta[K + 1 :]), _lib.stream_handle(dev)),
-                "wcn_kmap_scatter",
-            )
-            return in_maps, out_maps
-
+        hints.observe_pairs(M, pair_capacity)
         attach_tables(result, b)
         result._offsets = offsets_host
         result.identity_map_index = identity
         result._device = torch.device(dev)
         spec = b.get("spec_pairs")
+        if spec is not None and spec[2] < pair_capacity:
+            spec = None  # the optimistic capacity (pairs per row of earlier maps) was short: exact lists below
         if spec is not None:
-            # written speculatively right behind the mask sort (worst-case capacity): the first L entries are the lists
-            result._in_maps, result._out_maps = spec[0][:pair_capacity], spec[1][:pair_capacity]
+            # written speculatively right behind the mask sort: the first L entries are the lists.  A guess far above the
+            # need (first build of a process) is copied to exact-size buffers instead of pinning the memory for the lifetime
+            # of the cached map.
+            in_full, out_full, cap = spec
+            if cap > 2 * pair_capacity + 65536:
+                in_full, out_full = in_full[:pair_capacity].clone(), out_full[:pair_capacity].clone()
+            result._in_maps, result._out_maps = in_full[:pair_capacity], out_full[:pair_capacity]
             result._lazy_pairs = None
+            b["spec_pairs"] = None
         elif need_pairs:
             # training: the weight gradient needs the pair lists, and written NOW - while the neighbour table is still in the
             # Infinity Cache - they cost 35-45 us less than between dgrad and wgrad
-            result._in_maps, result._out_maps = scatter_pairs()
+            result._in_maps, result._out_maps = scatter(b, pair_capacity)[:2]
             result._lazy_pairs = None
         else:
             # the forward and dgrad kernels read the neighbour table; only wgrad and the container API need the lists (CSR by
             # offset), so a caller that will not run a weight gradient (the convolution under no_grad) skips the 49 us scatter
             result._in_maps = result._out_maps = None
-            result._lazy_pairs = scatter_pairs
+            result._lazy_pairs = lambda: scatter(b, pair_capacity)[:2]
         # Duplicate input rows break the k-flip identity the dgrad shortcut relies on (rev[n][k] == nbr[n][K-1-k] holds only
         # when every coordinate is one row: a non-winner duplicate has neighbours but is nobody's neighbour): such maps take
         # the explicit reverse table instead.
@@ -379,21 +430,12 @@ def generate_kernel_map(
         # forward back to back instead of idling for the host's round trip.  Every scene a voxeliser produces passes; a
         # build the device rejects (block table too small, duplicate coordinates that need the strict insert) is redone
         # inside validate(), which then reports that the tables changed.
+        if need_pairs:
+            # the pair lists (the weight gradient's input) without knowing the pair count: capacity from the pairs per row of
+            # earlier maps (`hints`; the kernel writes nothing past it, validate() rewrites a short guess at the exact length),
+            # the scatter queued right behind the mask sort while the neighbour table is still in the Infinity Cache
+            first["spec_pairs"] = scatter(first, hints.pair_capacity(M, K))
         attach_tables(result, first)
-        if need_pairs and K * M * 8 <= (1 << 30):
-            # the pair lists (the weight gradient's input) without knowing the pair count: buffers of worst-case length K * M
-            # (address space only - L entries are ever touched), the scatter queued right behind the mask sort while the
-            # neighbour table is still in the Infinity Cache; validate() cuts the views to the real length
-            cap = K * M
-            in_full = torch.empty(cap, dtype=torch.int32, device=dev)
-            out_full = torch.empty(cap, dtype=torch.int32, device=dev)
-            _lib.check(
-                L.wcn_kmap_scatter(_lib.ptr(first["nbr"]), _lib.ptr(first["mask"]), M, K, _lib.ptr(first["block_counts"]),
-                                   _lib.ptr(first["meta"]), _lib.ptr(in_full), _lib.ptr(out_full), cap,
-                                   _lib.ptr(first["meta"][K + 1 :]), _lib.stream_handle(dev)),
-                "wcn_kmap_scatter",
-            )
-            first["spec_pairs"] = (in_full, out_full)
 
         def validate_fn(res, b=first):
             b2, flags, rebuilt = settle(b)

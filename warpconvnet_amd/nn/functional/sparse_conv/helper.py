@@ -136,7 +136,12 @@ def generate_output_coords_and_kernel_map(
 
     if input_sparse_tensor.cache is None:
         input_sparse_tensor._extra_attributes["_cache"] = IntSearchCache()
-    input_sparse_tensor.cache.put(key, kernel_map)
+    cache = input_sparse_tensor.cache
+    cache.put(key, kernel_map)
+    if getattr(kernel_map, "_validate_fn", None) is not None:
+        # an optimistic map is cached before its status word is read: if the device rejects the build for good, validate()
+        # raises (every time) and the entry goes away, so a retry on the same tensor builds - and fails - afresh
+        kernel_map._on_invalid = lambda: cache.evict(key, kernel_map)
     return bcoords_out, out_offsets, kernel_map
 
 
