@@ -439,6 +439,12 @@ def make_step(dev, world, coords, feats, grad_out, offsets, conv, params, attach
         y.batched_features.batched_tensor.backward(grad_out)
         if buckets is not None:
             buckets.finish()
+        # the parameter update of a training step (plain SGD, lr 1e-6): bumps the parameters' version counters, so the packed
+        # bf16 weight images are rebuilt next step like in any real training loop (two pack launches per step)
+        with torch.no_grad():
+            for p in params:
+                if p.grad is not None:
+                    p.add_(p.grad, alpha=-1e-6)
 
     return step, buckets
 

@@ -7,7 +7,11 @@
  *
  *   - plain C: raw device pointers, sizes, and a `hipStream_t` passed as `void*`; no torch types;
  *   - the CALLER allocates every buffer (outputs, workspaces); the library never allocates or frees
- *     device memory and keeps no global mutable state -> re-entrant and graph-capturable;
+ *     device memory; its only process-wide state is a per-device once-flag (kernel attributes), so the
+ *     entry points are re-entrant.  A single call is a fixed sequence of launches on the stream and may be
+ *     stream-captured; a kernel-map BUILD as the host drives it is not a capturable unit - the host reads
+ *     the status word / pair count (pinned mirror written by wcn_kmap_tally_sort) and may rebuild with a
+ *     larger block table or the strict insert, exactly as the reference syncs at torch_discrete.py:272;
  *   - every launch goes to the stream argument and is asynchronous; nothing here synchronises;
  *   - return value: 0 on success, negative `wcn_status` otherwise (same numbering as the reference's
  *     `GemmStatus`, warpconvnet/csrc/include/gemm_error_codes.h:7-15);

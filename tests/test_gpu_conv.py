@@ -743,3 +743,43 @@ def test_rejected_build_is_not_served_from_the_cache():
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 conv(vox)
         assert vox.cache is None or len(vox.cache) == 0
+
+
+def test_weight_gradient_lands_in_the_gradient_bucket_slot():
+    """`dist.GradientBuckets` publishes every parameter's view of the flat bucket as `_wcn_grad_slot`; with `.grad` None
+    the convolution's weight-gradient kernel writes there and autograd adopts the alias - same values as the plain path,
+    `.grad` storage inside the bucket, a second (accumulating) backward still adds."""
+    from warpconvnet_amd.dist import GradientBuckets
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    c = scene_u(4000, 51)[:, 1:]
+    torch.manual_seed(0)
+    conv = SparseConv3d(64, 128, 3).to(dev)
+    feats = torch.randn(len(c), 64, device=dev)
+    g = torch.randn(len(c), 128, device=dev).bfloat16()
+
+    def run():
+        x = Voxels([torch.from_numpy(c)], [feats], device=dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(x)
+        y.feature_tensor.backward(g)
+
+    run()
+    ref_w, ref_b = conv.weight.grad.clone(), conv.bias.grad.clone()
+    buckets = GradientBuckets(conv.parameters())
+    flat = buckets._buckets[0]["flat"]
+    buckets.zero_grad()
+    assert conv.weight.grad is None
+    flat.fill_(float("nan"))  # whatever is not written by this backward would show
+    run()
+    buckets.finish()
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    assert lo <= conv.weight.grad.data_ptr() < hi and lo <= conv.bias.grad.data_ptr() < hi
+    assert torch.equal(conv.weight.grad, ref_w) and torch.equal(conv.bias.grad, ref_b)
+    with buckets.no_sync():
+        run()  # .grad is set now: the ordinary accumulation path
+    assert torch.allclose(conv.weight.grad, 2 * ref_w, rtol=1e-6, atol=0)
+    buckets.remove()
+    assert not hasattr(conv.weight, "_wcn_grad_slot")

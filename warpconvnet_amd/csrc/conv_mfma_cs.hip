@@ -267,9 +267,6 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       const int npieces = chunk + 1 < nchunk ? 8 : last_pieces;  // pieces of this chunk that exist in the row
 #pragma unroll
       for (int it = 0; it < G::DMA_INSTR; ++it) {
-#ifdef CS_ABL_LOCAL
-        if (idx[it] >= 0) idx[it] &= 4095;  // dev ablation: every gather inside a 0.5-1 MB window (results are garbage)
-#endif
         if (idx[it] >= 0 && ((it & 1) ? piece_o : piece_e) < npieces) {
           const char* src = ((it & 1) ? gsrc_o : gsrc_e) + (uint64_t)(uint32_t)idx[it] * rowbytes + (uint32_t)(chunk * 128);
           glds16(src, dst + it * 1024);
@@ -425,13 +422,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
           }
         }
         // streamed once: non-temporal, so the output does not push the gathered input out of the caches
-#if defined(CS_ABL_NOSTORE)
-        if (o[0] == (T)12345.f) *reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * CO + piece * 8) = o;  // dev ablation
-#elif defined(CS_ABL_PLAINSTORE)
-        *reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * CO + piece * 8) = o;  // dev ablation
-#else
         __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * CO + piece * 8));
-#endif
       }
     }
   }

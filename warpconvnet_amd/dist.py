@@ -80,6 +80,10 @@ class GradientBuckets:
     * every parameter's ``.grad`` is a VIEW into one flat buffer per bucket - no ``cat`` before the collective, no copy
       back after it (a gradient that arrives as a fresh tensor, e.g. after ``zero_grad(set_to_none=True)``, is moved into
       its view by the hook);
+    * the view is also published as ``param._wcn_grad_slot``: a producer that can write its result anywhere - the sparse
+      convolution's weight-gradient kernels - writes STRAIGHT into the bucket when ``param.grad is None`` and hands autograd an
+      alias of the slot, which the engine adopts as ``.grad`` (no ``grad += dw`` launch per parameter, no copy by the hook).
+      ``zero_grad()`` therefore sets the gradients to None by default (``set_to_none=False`` zero-fills in place);
     * buckets are filled in REVERSE parameter order (the order the backward pass produces gradients) and a bucket's
       all-reduce is launched from the autograd hook of its last gradient, asynchronously, so RCCL works over xGMI while
       the remaining layers are still back-propagating;
@@ -130,6 +134,7 @@ class GradientBuckets:
             b["views"].append(v)
             self._where[id(p)] = (len(self._buckets), len(b["views"]) - 1)
             p.grad = v
+            p._wcn_grad_slot = v
             off += p.numel()
         self._buckets.append(b)
 
@@ -194,6 +199,9 @@ class GradientBuckets:
         for h in self._handles:
             h.remove()
         self._handles = []
+        for p in self.params:
+            if hasattr(p, "_wcn_grad_slot"):
+                del p._wcn_grad_slot
 
     @torch.no_grad()
     def finish(self) -> int:
@@ -220,8 +228,15 @@ class GradientBuckets:
         self._reset()
         return calls
 
-    def zero_grad(self):
-        """Zero the buckets in place (keeps the views attached; ``optimizer.zero_grad(set_to_none=False)`` does the same)."""
+    def zero_grad(self, set_to_none: bool = True):
+        """``set_to_none`` (default, what ``optimizer.zero_grad()`` does too): gradients become None - the next backward writes
+        the weight gradients of the sparse convolutions straight into their bucket slots, every other gradient is moved in by
+        the hook, parameters without a gradient contribute zeros (``finish``).  False: zero the buckets in place and keep the
+        views attached (gradient accumulation across ``no_sync()`` micro-steps needs neither)."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+            return
         for b in self._buckets:
             b["flat"].zero_()
         for p in self.params:

@@ -51,6 +51,7 @@ class BwdCtx:
     scratch: Optional[Dict[int, Any]] = None
     want_bias_grad: bool = False        # build extension: the caller would like sum_rows(grad_output) as well
     bias_grad: Optional[Tensor] = None  # set by a backend that produced it in the same pass (fp32 [Cout])
+    dw_out: Optional[Tensor] = None     # fp32 destination for the weight gradient (a gradient-bucket slot, dist.py)
 
 
 FwdFn = Callable[[FwdCtx], Any]
@@ -93,9 +94,10 @@ def _make_hip_bwd(algo: str) -> BwdFn:
             fuse_db = ctx.want_bias_grad and dy.dtype == ctx.grad_output.dtype
             if fuse_db:
                 dw, ctx.bias_grad = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape),
-                                                       algo, want_bias_grad=True)
+                                                       algo, want_bias_grad=True, out=getattr(ctx, "dw_out", None))
             else:
-                dw = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape), algo)
+                dw = hip_gemm.hip_wgrad(ctx.in_features.to(dt), dy, ctx.kernel_map, tuple(ctx.weight.shape), algo,
+                                        out=getattr(ctx, "dw_out", None))
             # stays fp32 here: the autograd function casts once to the dtype of the weight it was given
         return dx, dw
 

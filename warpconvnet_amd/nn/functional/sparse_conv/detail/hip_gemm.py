@@ -336,12 +336,15 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
 
 
 def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchResult, weight_shape, algo: str = "auto",
-              want_bias_grad: bool = False):
+              want_bias_grad: bool = False, out: Optional[Tensor] = None):
     """dw[k] = x[in_k]^T @ dy[out_k], fp32 [K, Cin, Cout].
 
     ``want_bias_grad``: returns ``(dw, bias_grad_or_None)``; the fp32 column sums of ``grad_output`` come out of the same
     kernel (ones-row MFMA on the centre bucket) when the map is a submanifold map over distinct coordinates and the
     MFMA tile layout supports it, else ``None`` (the caller then uses :func:`hip_colsum`).
+    ``out``: fp32 [K, Cin, Cout] destination (a gradient-bucket slot, `dist.GradientBuckets`): the kernel writes there and the
+    same tensor is returned; ignored on the paths that post-process the result (zero-padded channels, fp32 operands
+    through fp16).
     """
     x, dy = _prep(in_features, "in_features"), _prep(grad_output, "grad_output")
     if x.dtype != dy.dtype:
@@ -361,7 +364,11 @@ def hip_wgrad(in_features: Tensor, grad_output: Tensor, kernel_map: IntSearchRes
         x, sx = fp16_safe_cast(x)      # fp16 operands, fp32 accumulate and output; scales multiplied back below
         dy, sg = fp16_safe_cast(dy)
         scale = sx * sg
-    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    if out is not None and scale is None and out.shape == (K, cin, cout) and out.dtype == torch.float32 and out.is_contiguous() \
+            and out.device == dev:
+        dw = out
+    else:
+        dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
     if kernel_map._offsets_dev is None:
         kernel_map._offsets_dev = kernel_map.offsets.to(device=dev, dtype=torch.int32)
     L = _lib.lib()

@@ -111,9 +111,19 @@ class UnifiedSpatiallySparseConvFunction(Function):
         else:
             grad_output = grad_output.contiguous()
 
+            # data parallelism (`dist.GradientBuckets`): the parameter publishes its slot in the flat gradient bucket; with no
+            # gradient accumulated yet the weight-gradient kernel writes there directly and autograd adopts the alias
+            slot = getattr(weight, "_wcn_grad_slot", None)
+            if slot is not None and (weight.grad is not None or not need_dw or ctx.groups != 1 or slot.dtype != torch.float32
+                                     or ctx.weight_dtype != torch.float32 or slot.shape != weight.shape):
+                slot = None
+
             def _ctx(needs, want_db=False):
-                return BwdCtx(grad_output, in_features, weight, ctx.kernel_map, ctx.num_out_coords, ctx.compute_dtype,
-                              grad_output.device, needs, {}, None, ctx.groups, False, {}, want_db)
+                b = BwdCtx(grad_output, in_features, weight, ctx.kernel_map, ctx.num_out_coords, ctx.compute_dtype,
+                           grad_output.device, needs, {}, None, ctx.groups, False, {}, want_db)
+                if slot is not None and needs[1]:
+                    b.dw_out = slot.detach()  # a fresh alias: the engine may steal it as .grad (sole owner)
+                return b
 
             if ctx.dgrad_algo == ctx.wgrad_algo:
                 bctx = _ctx((need_dx, need_dw), need_db)
