@@ -174,6 +174,33 @@ int wcn_kmap_scan_to_host(int32_t* counts, int64_t num_blocks, int32_t num_offse
 int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets,
                      const int32_t* counts, const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
                      int32_t* status, wcn_stream_t stream);
+/* ---- strided layers from the cell table of the FINE set (no global hash table) ------------------------------------------
+ * `cells_workspace` = the workspace of a wcn_kmap_build_binned call on the fine coordinates (with its n and max_blocks)
+ * whose status word came back without TABLE_FULL / NEED_STRICT.
+ * Down-sampling (reference coords/ops/stride.py:18-56: floor-divide, hash de-duplicate, unique): strides 1 / 2 / 4 / 8 per
+ * axis, so that a coarse cell lies inside one 8^3 block (wcn_cells_stride_supported).
+ *   _count  flags = one bit per fine row: "first (smallest) row of its coarse cell" (uint64 per 64 rows); counts
+ *           [wcn_cells_stride_tiles(n) + 1] int32 = survivors in front of every 256-row tile, the last entry their total;
+ *           out_offsets[b] = survivors with a batch index < b, b = 0 .. num_batches (the batch offsets of the output; the
+ *           rows must be sorted by batch index, as everywhere)
+ *   _emit   out_coords [M, 4] = (b, x >> log2 sx, ...) of the survivors in input order; first_rows [M] (may be NULL) their
+ *           fine rows; nbr [M, kp] / mask [M] (both or neither): the kernel map of a convolution with kernel_size == stride,
+ *           dilation 1 - nbr[m][(i*sy + j)*sz + l] = fine row in cell (x0 + i, y0 + j, z0 + l) of the coarse cell, or -1
+ * wcn_kmap_probe_cells: wcn_kmap_probe answered from the cell table - same table / mask layout, same 18-bit wrap, the
+ * smallest row of a duplicated coordinate - for any kernel size, stride and dilation; replaces wcn_hash_insert +
+ * wcn_kmap_probe when the input set already has a cell table.  reference: cuhash_kernel_map.cu:93-134;
+ * coarse-to-fine search geometry/coords/search/hierarchical_search.py:25-66. */
+int wcn_cells_stride_supported(const int32_t stride[3]);
+int64_t wcn_cells_stride_tiles(int64_t n);
+int wcn_cells_stride_count(const void* cells_workspace, int64_t n, int64_t max_blocks, const int32_t* coords,
+                           const int32_t stride[3], uint64_t* flags, int32_t* counts, int32_t num_batches,
+                           int32_t* out_offsets, wcn_stream_t stream);
+int wcn_cells_stride_emit(const void* cells_workspace, int64_t n, int64_t max_blocks, const int32_t* coords,
+                          const int32_t stride[3], const uint64_t* flags, const int32_t* counts, int32_t* out_coords,
+                          int32_t* first_rows, int32_t* nbr, uint32_t* mask, wcn_stream_t stream);
+int wcn_kmap_probe_cells(const void* cells_workspace, int64_t n_in, int64_t max_blocks, const int32_t* query, int64_t m,
+                         const int32_t ksize[3], const int32_t stride[3], const int32_t dilation[3], int32_t* nbr,
+                         uint32_t* mask, wcn_stream_t stream);
 /* nbr [m,kp] -> pair_table [K,m]   (the reference layout, cuhash_kernel_map.cu:133) */
 int wcn_kmap_transpose(const int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* pair_table,
                        wcn_stream_t stream);

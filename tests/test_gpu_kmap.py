@@ -82,6 +82,39 @@ def test_strided_map_bit_exact(ksize, stride):
     assert km.identity_map_index is None and not km._symmetric
 
 
+@pytest.mark.parametrize("ksize,stride", [((2, 2, 2), (2, 2, 2)), ((3, 3, 3), (2, 2, 2)), ((2, 2, 2), (4, 4, 4)), ((3, 3, 3), (1, 2, 1)),
+                                          ((4, 2, 1), (4, 2, 1)), ((2, 2, 2), (8, 8, 8))])
+def test_strided_layers_from_the_cell_table(ksize, stride):
+    """The same contract as test_strided_map_bit_exact, answered from the cell table a (validated) submanifold build left
+    on the coordinate tensor (csrc/kmap_stride.hip): down-sampled coordinates + offsets bit-exact vs the oracle, the kernel
+    map bit-exact whether it comes out of the down-sampling pass (kernel_size == stride) or from the cell probe; duplicate
+    coordinates and negative coordinates included.  No global hash table is built on this path."""
+    from warpconvnet_amd.geometry.coords.ops.stride import stride_coords
+    from warpconvnet_amd.geometry.coords.search import packed_hashmap
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+    s = np.concatenate([scene_u(6000, 3, 0), scene_u(5000, 4, 1), scene_u(10, 5, 2)], 0)
+    s[:, 1:] -= 7
+    s = np.concatenate([s[:6000], s[100:160], s[6000:]], 0).astype(np.int32)  # 60 duplicated rows inside batch 0
+    a = torch.from_numpy(s).to(_dev())
+    sub = generate_kernel_map(a, a, (1, 1, 1), (3, 3, 3))  # the level's submanifold map: leaves the cell table on `a`
+    assert getattr(a, "_wcn_cells", None) is not None and sub._has_duplicates
+    want, _ = okmap.stride_coords(s, stride)
+    inserts = []
+    real_insert = packed_hashmap.PackedHashTable._launch_insert
+    packed_hashmap.PackedHashTable._launch_insert = lambda self, *x, **k: (inserts.append(1), real_insert(self, *x, **k))[1]
+    try:
+        got, offs = stride_coords(a, stride, num_batches=3, with_map=tuple(ksize) == tuple(stride))
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        np.testing.assert_array_equal(offs.numpy(), np.concatenate([[0], np.cumsum(np.bincount(want[:, 0], minlength=3))]))
+        km = generate_kernel_map(a, got, stride, ksize)
+    finally:
+        packed_hashmap.PackedHashTable._launch_insert = real_insert
+    assert not inserts, "the cell-table route must not build a hash table"
+    _check_against_oracle(km, s, want, ksize, stride)
+    assert km.identity_map_index is None and not km._symmetric
+
+
 def test_binned_edge_cases(kmap_method):
     """Duplicates (smallest row wins), coordinates at the limits of the packed range (18-bit wrap of the probe
     key, reference hash_functions.cuh:40-44), far-apart clusters, several batch indices."""

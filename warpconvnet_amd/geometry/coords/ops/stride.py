@@ -15,18 +15,67 @@ from warpconvnet_amd.utils.ntuple import device_const_i32, ntuple
 from warpconvnet_amd.utils.unique import unique_first_indices, unique_first_indices_with_offsets
 
 
+def _stride_coords_from_cells(bcoords: Tensor, stride: Tuple[int, ...], num_batches: int, with_map: bool):
+    """Down-sampling through the cell table the submanifold layers of this level built (`csrc/kmap_stride.hip`): one block
+    lookup + a few cell reads per voxel, four launches and ONE host read (the output offsets) - instead of a hash insert of
+    every candidate, a search, and a chain of torch ops with three reads.  -> (out [M, 4], CPU offsets [B + 1])"""
+    import ctypes
+
+    from warpconvnet_amd import _lib
+
+    ws, n_cells, max_blocks = bcoords._wcn_cells
+    n, dev = bcoords.shape[0], bcoords.device
+    L = _lib.lib()
+    stream = _lib.stream_handle(dev)
+    st = _lib.i3(stride)
+    ntile = int(L.wcn_cells_stride_tiles(n))
+    flags = torch.empty(max(1, (n + 63) // 64), dtype=torch.int64, device=dev)
+    counts = torch.empty(ntile + 1, dtype=torch.int32, device=dev)
+    out_offsets = torch.empty(num_batches + 1, dtype=torch.int32, device=dev)
+    _lib.check(L.wcn_cells_stride_count(_lib.ptr(ws), n, max_blocks, _lib.ptr(bcoords), st, _lib.ptr(flags), _lib.ptr(counts),
+                                        num_batches, _lib.ptr(out_offsets), stream), "wcn_cells_stride_count")
+    offsets = out_offsets.cpu()  # the one host read
+    m = int(offsets[-1])
+    out = torch.empty((m, 4), dtype=torch.int32, device=dev)
+    K = int(stride[0]) * int(stride[1]) * int(stride[2])
+    nbr = mask = None
+    if with_map and K <= 32 and m > 0:
+        nbr = torch.empty((m, int(L.wcn_kmap_row_pitch(K))), dtype=torch.int32, device=dev)
+        mask = torch.empty((m, 1), dtype=torch.int32, device=dev)
+    _lib.check(L.wcn_cells_stride_emit(_lib.ptr(ws), n, max_blocks, _lib.ptr(bcoords), st, _lib.ptr(flags), _lib.ptr(counts),
+                                       _lib.ptr(out), None, _lib.ptr(nbr), _lib.ptr(mask), stream), "wcn_cells_stride_emit")
+    if nbr is not None:
+        # the kernel map of a convolution with kernel_size == stride is exactly these cells: generate_kernel_map picks it up
+        out._wcn_stride_map = (bcoords.data_ptr(), n, tuple(int(v) for v in stride), nbr, mask)
+    return out, offsets
+
+
 @torch.no_grad()
-def stride_coords(batch_indexed_coords: Tensor, stride: Tuple[int, ...], order=None) -> Tuple[Tensor, Tensor]:
-    """[N, D+1] -> (unique floor(coords / stride) [M, D+1], CPU offsets [B+1])."""
+def stride_coords(batch_indexed_coords: Tensor, stride: Tuple[int, ...], order=None, num_batches: int = None,
+                  with_map: bool = False) -> Tuple[Tensor, Tensor]:
+    """[N, D+1] -> (unique floor(coords / stride) [M, D+1], CPU offsets [B+1]).
+
+    ``num_batches`` (known by the caller from the input's offsets) enables the cell-table route when the coordinate tensor
+    carries the table of an earlier submanifold build on it (`_wcn_cells`, set by `generate_kernel_map`); ``with_map``
+    additionally emits the kernel map of a convolution whose kernel is the stride window."""
     nd = batch_indexed_coords.shape[1] - 1
     stride = ntuple(stride, nd)
     if all(s == 1 for s in stride):
         return batch_indexed_coords, offsets_from_batch_index(batch_indexed_coords[:, 0])
-    div = device_const_i32([1, *stride], batch_indexed_coords.device)
-    coarse = torch.div(batch_indexed_coords, div, rounding_mode="floor").to(torch.int32)
     from warpconvnet_amd.geometry.coords.ops.serialization import POINT_ORDERING, encode, to_point_ordering
 
     order = to_point_ordering(order)
+    if (num_batches is not None and order == POINT_ORDERING.RANDOM and batch_indexed_coords.is_cuda
+            and batch_indexed_coords.shape[1] == 4 and batch_indexed_coords.shape[0] > 0
+            and batch_indexed_coords.dtype == torch.int32 and batch_indexed_coords.is_contiguous()
+            and getattr(batch_indexed_coords, "_wcn_cells", None) is not None
+            and batch_indexed_coords._wcn_cells[1] == batch_indexed_coords.shape[0]):
+        from warpconvnet_amd import _lib
+
+        if _lib.lib().wcn_cells_stride_supported(_lib.i3(stride)):
+            return _stride_coords_from_cells(batch_indexed_coords, stride, int(num_batches), with_map)
+    div = device_const_i32([1, *stride], batch_indexed_coords.device)
+    coarse = torch.div(batch_indexed_coords, div, rounding_mode="floor").to(torch.int32)
     if coarse.is_cuda and coarse.shape[1] == 4 and coarse.shape[0] > 0:
         idx, offsets = unique_first_indices_with_offsets(coarse)  # one host read for status, row count and batch counts
         out = coarse[idx].contiguous()

@@ -279,6 +279,17 @@ def generate_kernel_map(
     # enough).  `strict`: see wcn.h.
     state = {"max_blocks": hints.max_blocks(N), "strict": 0}
     odd = all(k % 2 == 1 for k in ksize)
+    # general maps: the cell table an earlier (validated) submanifold build left on the input coordinate tensor, or the
+    # table the down-sampling pass wrote next to the output coordinates
+    cells = prebuilt = None
+    if not use_binned and N > 0 and M > 0 and os.environ.get("WARPCONVNET_AMD_KMAP_METHOD", "auto").strip().lower() != "hash":
+        c = getattr(batch_indexed_in_coords, "_wcn_cells", None)
+        if c is not None and c[1] == N:
+            cells = c
+        pm = getattr(batch_indexed_out_coords, "_wcn_stride_map", None)
+        if (pm is not None and pm[0] == in_coords.data_ptr() and pm[1] == N and pm[2] == tuple(stride) == tuple(ksize)
+                and all(d == 1 for d in dilation) and pm[3].shape[0] == M):
+            prebuilt = (pm[3], pm[4])
 
     def launch():
         """Queue one build (tables + tally + scans + mask sort) on the current stream; nothing waits."""
@@ -299,6 +310,18 @@ def generate_kernel_map(
                                         _lib.ptr(bin_ws), ws_bytes, _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(meta[K + 1 :]),
                                         stream),
                 "wcn_kmap_build_binned",
+            )
+        elif prebuilt is not None:
+            # strided layer whose kernel is its stride window: the down-sampling pass (coords/ops/stride.py) read these very
+            # cells and wrote the table with the output coordinates
+            nbr, mask = prebuilt
+        elif cells is not None:
+            # the input set has the cell table of its submanifold layers (validated): every probe is a block-table lookup +
+            # one cell read, nothing is inserted (csrc/kmap_stride.hip)
+            _lib.check(
+                L.wcn_kmap_probe_cells(_lib.ptr(cells[0]), N, cells[2], _lib.ptr(out_coords), M, _lib.i3(ksize), _lib.i3(stride),
+                                       _lib.i3(dilation), _lib.ptr(nbr), _lib.ptr(mask), stream),
+                "wcn_kmap_probe_cells",
             )
         else:
             table = PackedHashTable(max(16, 2 * N), device=dev)
@@ -326,7 +349,7 @@ def generate_kernel_map(
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev))
         return dict(nbr=nbr, mask=mask, perm=perm, block_counts=block_counts, meta=meta, meta_host=meta_host, ready=ready,
-                    event=event, table=table, keep=(bin_ws, sort_ws))
+                    event=event, table=table, keep=(bin_ws, sort_ws, cells), max_blocks=max_blocks)
 
     def scatter(b, capacity):
         """Pair lists of build `b` (buckets ordered by output row), `capacity` entries each; the kernel writes nothing past
@@ -384,6 +407,13 @@ def generate_kernel_map(
         if has_duplicates and same_tensor:
             identity = None  # "output row i == input row i at the centre offset" fails for the rows that lost their coordinate
         hints.observe_pairs(M, pair_capacity)
+        if use_binned and not (flags & (_lib.WCN_FLAG_TABLE_FULL | _lib.WCN_FLAG_NEED_STRICT)):
+            # the cell table of this coordinate set is complete and keeps the smallest row of every coordinate: strided
+            # layers on the same tensor reuse it (down-sampling and their kernel maps, coords/ops/stride.py)
+            handle = (b["keep"][0], N, b["max_blocks"])
+            in_coords._wcn_cells = handle
+            if batch_indexed_in_coords is not in_coords and batch_indexed_in_coords.data_ptr() == in_coords.data_ptr():
+                batch_indexed_in_coords._wcn_cells = handle
         attach_tables(result, b)
         result._offsets = offsets_host
         result.identity_map_index = identity

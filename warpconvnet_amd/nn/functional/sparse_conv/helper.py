@@ -94,7 +94,11 @@ def generate_output_coords_and_kernel_map(
         if transposed:
             map_stride = tuple(1 for _ in stride)
     elif any(s != 1 for s in stride):
-        bcoords_out, out_offsets = stride_coords(bcoords_in, stride)
+        # (with the cell table of this level's submanifold layers on the coordinate tensor: no hash table, and for
+        # kernel_size == stride the kernel map comes out of the same pass - geometry/coords/ops/stride.py)
+        bcoords_out, out_offsets = stride_coords(
+            bcoords_in, stride, num_batches=len(input_sparse_tensor.offsets) - 1,
+            with_map=(not transposed and tuple(kernel_size) == tuple(stride) and all(d == 1 for d in kernel_dilation)))
     else:
         bcoords_out, out_offsets = bcoords_in, input_sparse_tensor.offsets
 
