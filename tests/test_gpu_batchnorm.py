@@ -111,3 +111,52 @@ def test_eval_mode_cumulative_momentum_and_sequential():
     wrap = BatchNorm(32).to(DEV)
     out = wrap(net(vox))
     assert out.feature_tensor.shape == (len(p), 32) and int(wrap.norm.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("cin,cout,ksize,stride,relu", [(64, 64, 3, 1, True), (64, 128, 3, 1, False), (32, 32, 2, 2, True), (96, 96, 3, 1, True),
+                                                       (128, 64, 3, 1, True), (3, 32, 1, 1, True), (192, 128, 1, 1, False)])
+def test_fused_conv_bn_relu_block_equals_the_module_chain(cin, cout, ksize, stride, relu):
+    """`Sequential(SparseConv3d, BatchNorm1d, ReLU)` runs as ONE autograd node with direct launches
+    (`nn/functional/sparse_conv/block.py`); a forward hook on the convolution sends the same modules down the general
+    path.  Same kernels in the same order: outputs, input / weight / BatchNorm gradients and the running statistics are
+    bit-identical, in training and in eval mode."""
+    import copy
+
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.functional.sparse_conv import block as blk
+    from warpconvnet_amd.nn.modules.sequential import Sequential
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = torch.device("cuda:0")
+    c = scene_u(9000, 71)[:, 1:]
+    torch.manual_seed(0)
+    fused = Sequential(SparseConv3d(cin, cout, ksize, stride, bias=False), nn.BatchNorm1d(cout), nn.ReLU() if relu else nn.Identity()).to(dev)
+    chain = copy.deepcopy(fused)
+    chain[0].register_forward_hook(lambda m, i, o: None)  # hooks present -> module-by-module path
+    feats = torch.randn(len(c), cin, device=dev)
+    calls = []
+    Fn = blk._PointwiseBnAct if ksize == 1 else blk._ConvBnAct
+    real = Fn.apply
+    Fn.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+    try:
+        res = []
+        for net in (fused, chain):
+            for mode in ("train", "eval"):
+                net.train(mode == "train")
+                x = Voxels([torch.from_numpy(c)], [feats], device=dev)
+                x = x.replace(batched_features=x.feature_tensor.detach().clone().requires_grad_(True))
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = net(x)
+                g = torch.randn(y.feature_tensor.shape, device=dev, generator=torch.Generator(dev).manual_seed(3)).to(y.feature_tensor.dtype)
+                net.zero_grad(set_to_none=True)
+                y.feature_tensor.backward(g)
+                res.append((y.feature_tensor.detach().clone(), x.batched_features.batched_tensor.grad.clone(),
+                            net[0].weight.grad.clone(), net[1].weight.grad.clone(), net[1].bias.grad.clone(),
+                            net[1].running_mean.clone(), net[1].running_var.clone(), int(net[1].num_batches_tracked)))
+    finally:
+        Fn.apply = real
+    assert len(calls) == 2, "the hook-free Sequential must take the fused node (train + eval), the hooked one must not"
+    for a, b in zip(res[:2], res[2:]):
+        for u, v in zip(a[:-1], b[:-1]):
+            assert torch.equal(u, v)
+        assert a[-1] == b[-1]

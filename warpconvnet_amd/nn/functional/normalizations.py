@@ -150,16 +150,18 @@ def hip_batch_norm(x: Tensor, running_mean: Optional[Tensor], running_var: Optio
                                num_batches_tracked)
 
 
-def batch_norm_module_forward(norm: torch.nn.modules.batchnorm._BatchNorm, x: Tensor, relu: bool = False) -> Tensor:
-    """``nn.BatchNorm1d.forward`` on ``[N, C]`` features through the HIP kernels: the module's bookkeeping
-    (``num_batches_tracked``, cumulative average when ``momentum is None``) followed by :func:`hip_batch_norm`."""
+def bn_module_state(norm: torch.nn.modules.batchnorm._BatchNorm, x: Tensor):
+    """The bookkeeping of ``nn.BatchNorm1d.forward`` (``num_batches_tracked``, cumulative average when ``momentum is None``,
+    which statistics to use) -> ``(use_batch_stats, momentum, eps, running_mean, running_var, counter, fused_running)``:
+    ``counter`` is the module's batch counter when the statistics kernel can bump it, ``fused_running`` says the running
+    statistics are fp32 and get updated inside that kernel."""
     momentum = 0.0 if norm.momentum is None else norm.momentum
     counter = None
+    rm_ok = (norm.running_mean is not None and norm.running_mean.dtype == torch.float32 and norm.running_var.dtype == torch.float32
+             and norm.running_mean.is_contiguous() and norm.running_var.is_contiguous())
     if norm.training and norm.track_running_stats and norm.num_batches_tracked is not None:
         nbt = norm.num_batches_tracked
-        if (norm.momentum is not None and nbt.dtype == torch.int64 and nbt.device == x.device
-                and norm.running_mean is not None and norm.running_mean.dtype == torch.float32
-                and norm.running_var.dtype == torch.float32 and norm.running_mean.is_contiguous() and norm.running_var.is_contiguous()):
+        if norm.momentum is not None and nbt.dtype == torch.int64 and nbt.device == x.device and rm_ok:
             counter = nbt  # the statistics kernel adds the one (it updates the running statistics in the same place)
         else:
             nbt.add_(1)
@@ -168,4 +170,13 @@ def batch_norm_module_forward(norm: torch.nn.modules.batchnorm._BatchNorm, x: Te
     use_batch_stats = norm.training or (norm.running_mean is None and norm.running_var is None)
     rm = norm.running_mean if (not norm.training or norm.track_running_stats) else None
     rv = norm.running_var if (not norm.training or norm.track_running_stats) else None
-    return hip_batch_norm(x, rm, rv, norm.weight, norm.bias, use_batch_stats, momentum, norm.eps, relu, counter)
+    if not use_batch_stats and not rm_ok:  # eval on non-fp32 running statistics: fp32 copies for the fold kernel
+        rm, rv = rm.float().contiguous(), rv.float().contiguous()
+    return bool(use_batch_stats), float(momentum), float(norm.eps), rm, rv, counter, bool(rm is not None and rm_ok)
+
+
+def batch_norm_module_forward(norm: torch.nn.modules.batchnorm._BatchNorm, x: Tensor, relu: bool = False) -> Tensor:
+    """``nn.BatchNorm1d.forward`` on ``[N, C]`` features through the HIP kernels: the module's bookkeeping
+    (``num_batches_tracked``, cumulative average when ``momentum is None``) followed by :func:`hip_batch_norm`."""
+    use_batch_stats, momentum, eps, rm, rv, counter, _ = bn_module_state(norm, x)
+    return hip_batch_norm(x, rm, rv, norm.weight, norm.bias, use_batch_stats, momentum, eps, relu, counter)

@@ -1,0 +1,298 @@
+"""``SparseConv3d -> BatchNorm1d (-> ReLU)`` as ONE autograd node with direct C-ABI launches.
+
+The reference's models run this chain as three modules (`warpconvnet/models/mink_unet.py:31-53`), each with its own
+orchestration (`nn/functional/sparse_conv/helper.py:147-358` -> `detail/unified.py:143-785` -> a backend) and its own
+autograd node.  Below ~1 M voxels a network is bound by exactly that host work: on the MI355X box one
+conv -> BN -> ReLU block costs 320 us of host time forward + backward for 11 kernel launches (55 us of launch calls;
+`tools/host_micro.py`), and MinkUNet-14 has 28 such blocks.  Here the chain is a single `torch.autograd.Function`:
+
+* forward: gather GEMM (queued on the tables of an optimistic map build BEFORE its status word is read, repeated in the
+  rare case the build had to be redone) -> BatchNorm statistics + fold -> apply (+ ReLU); the packed weight image comes
+  from the per-parameter cache of `hip_gemm.pack_weight`;
+* backward: BatchNorm reduce -> apply -> dgrad -> wgrad (written straight into a gradient-bucket slot when the parameter
+  publishes one, `dist.GradientBuckets`).
+
+Same kernels, same math and the same saved tensors as the three-module path; only the Python between the launches is
+gone.  The fast path takes the layers it can serve without any of the special cases of the general path - 16-bit compute
+dtype, shapes of the MFMA kernels in both directions, groups = 1, no convolution bias (it would be cancelled by the
+BatchNorm anyway), non-transposed, non-generative, no hooks - and returns ``None`` otherwise: `Sequential` then runs the
+modules one by one.
+"""
+import os
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from warpconvnet_amd import _lib
+from warpconvnet_amd.geometry.coords.search.torch_discrete import reverse_tables
+from warpconvnet_amd.nn.functional.normalizations import _workspace as _bn_workspace
+from warpconvnet_amd.nn.functional.normalizations import bn_module_state
+
+from .detail import hip_gemm
+
+
+class _Plan:
+    """Per-call constants of one fused block (plain attributes: cheaper than threading a dozen Function arguments)."""
+
+    __slots__ = ("km", "num_in", "num_out", "cin", "cout", "K", "code", "relu", "training", "momentum", "eps", "running_mean",
+                 "running_var", "counter", "fused_running")
+
+
+def _bn_forward(plan: _Plan, y: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor]):
+    """BatchNorm (+ ReLU) of the convolution's output ``y``: statistics + fold (training) or fold of the running statistics
+    (eval), then apply.  -> (out, stats [5, C] = mean, rstd, scale, shift, var)"""
+    L = _lib.lib()
+    dev = y.device
+    stream = _lib.stream_handle(dev)
+    M, cout, code = plan.num_out, plan.cout, plan.code
+    stats = torch.empty((5, cout), dtype=torch.float32, device=dev)
+    gp, bp, yp = _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y)
+    s0 = stats.data_ptr()
+    mean, rstd, scale, shift, var = (s0 + 4 * cout * i for i in range(5))
+    if plan.training:
+        ws = _bn_workspace(cout, dev)
+        fr = plan.fused_running
+        _lib.check(L.wcn_bn_stats_fold(yp, M, cout, code, gp, bp, _lib.ptr(plan.running_mean) if fr else None,
+                                       _lib.ptr(plan.running_var) if fr else None, plan.momentum, plan.eps, mean, var, rstd,
+                                       scale, shift, _lib.ptr(plan.counter), _lib.ptr(ws), ws.numel(), stream),
+                   "wcn_bn_stats_fold")
+        if plan.running_mean is not None and not fr:  # (non-fp32 running statistics: the module's own arithmetic)
+            unbias = float(M) / float(max(M - 1, 1))
+            plan.running_mean.mul_(1.0 - plan.momentum).add_(stats[0].to(plan.running_mean.dtype), alpha=plan.momentum)
+            plan.running_var.mul_(1.0 - plan.momentum).add_(stats[4].to(plan.running_var.dtype), alpha=plan.momentum * unbias)
+    else:
+        _lib.check(L.wcn_bn_fold(_lib.ptr(plan.running_mean), _lib.ptr(plan.running_var), gp, bp, plan.eps, cout, mean, rstd,
+                                 scale, shift, stream), "wcn_bn_fold")
+    out = torch.empty_like(y)
+    _lib.check(L.wcn_bn_apply(yp, M, cout, code, scale, shift, int(plan.relu), _lib.ptr(out), stream), "wcn_bn_apply")
+    return out, stats
+
+
+def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, out: Optional[Tensor], stats: Tensor, gamma: Optional[Tensor],
+                 need_dy: bool):
+    """-> (gradient of the convolution's output or None, sums [2, C] = sum_dy (bias gradient), sum_dy_xhat (weight gradient))"""
+    L = _lib.lib()
+    dev = y.device
+    stream = _lib.stream_handle(dev)
+    M, cout, code = plan.num_out, plan.cout, plan.code
+    g = grad_out.contiguous()
+    if g.dtype != y.dtype:
+        g = g.to(y.dtype)
+    sums = torch.empty((2, cout), dtype=torch.float32, device=dev)
+    s0 = stats.data_ptr()
+    mean, rstd = s0, s0 + 4 * cout
+    sum_dy, sum_dy_xhat = sums.data_ptr(), sums.data_ptr() + 4 * cout
+    ws = _bn_workspace(cout, dev)
+    gp, yp, op = _lib.ptr(g), _lib.ptr(y), _lib.ptr(out)
+    _lib.check(L.wcn_bn_backward_reduce(gp, yp, op, M, cout, code, mean, rstd, sum_dy, sum_dy_xhat, _lib.ptr(ws), ws.numel(),
+                                        stream), "wcn_bn_backward_reduce")
+    if not need_dy:
+        return None, sums
+    dyc = torch.empty_like(y)
+    if plan.training:
+        a0, a1 = sum_dy, sum_dy_xhat
+    else:  # eval: the statistics are constants
+        zeros = torch.zeros(cout, dtype=torch.float32, device=dev)
+        a0 = a1 = zeros.data_ptr()
+    _lib.check(L.wcn_bn_backward_apply(gp, yp, op, M, cout, code, mean, rstd, _lib.ptr(gamma), a0, a1, _lib.ptr(dyc), stream),
+               "wcn_bn_backward_apply")
+    return dyc, sums
+
+
+def _affine_grads(ctx, sums: Tensor):
+    dgamma = dbeta = None
+    if ctx.gdtype is not None and ctx.needs_input_grad[2]:
+        dgamma = sums[1] if ctx.gdtype == torch.float32 else sums[1].to(ctx.gdtype)
+    if ctx.bdtype is not None and ctx.needs_input_grad[3]:
+        dbeta = sums[0] if ctx.bdtype == torch.float32 else sums[0].to(ctx.bdtype)
+    return dgamma, dbeta
+
+
+class _ConvBnAct(Function):
+    """K > 1: gather GEMM on the kernel map."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], plan: _Plan) -> Tensor:
+        L = _lib.lib()
+        dev = x.device
+        stream = _lib.stream_handle(dev)
+        km, M, cin, cout, K, code = plan.km, plan.num_out, plan.cin, plan.cout, plan.K, plan.code
+        wp = hip_gemm.pack_weight(w, False, False, dtype=x.dtype)
+        y = torch.empty((M, cout), dtype=x.dtype, device=dev)
+        xp, wpp, yp = _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y)
+
+        def launch():
+            _lib.check(L.wcn_conv_gather_gemm(xp, wpp, yp, _lib.ptr(km._nbr), _lib.ptr(km._mask), _lib.ptr(km._perm), None,
+                                              plan.num_in, M, cin, cout, K, code, _lib.WCN_ALGO_MFMA, 0, 0, stream),
+                       "wcn_conv_gather_gemm")
+
+        launch()
+        if km.validate():  # an optimistic map whose build the device rejected: rebuilt - repeat on the new tables
+            launch()
+        out, stats = _bn_forward(plan, y, gamma, beta)
+        ctx.save_for_backward(x, w, y, out if plan.relu else None, stats, gamma)
+        ctx.plan = plan
+        ctx.gdtype = gamma.dtype if gamma is not None else None
+        ctx.bdtype = beta.dtype if beta is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        x, w, y, out, stats, gamma = ctx.saved_tensors
+        plan = ctx.plan
+        km, M, cin, cout, K, code = plan.km, plan.num_out, plan.cin, plan.cout, plan.K, plan.code
+        L = _lib.lib()
+        dev = y.device
+        stream = _lib.stream_handle(dev)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dyc, sums = _bn_backward(plan, grad_out, y, out, stats, gamma, need_dx or need_dw)
+        dx = dw = None
+        if need_dx:
+            if km._has_duplicates:  # (repeated coordinates: the general path's pair-list formulation)
+                dx = hip_gemm.hip_dgrad(dyc, w, km, plan.num_in, "auto")
+            else:
+                if km._symmetric:
+                    tbl, msk, perm, flip = km._nbr, km._mask, km._perm, True
+                else:
+                    tbl, msk, perm = reverse_tables(km, plan.num_in)
+                    flip = False
+                wpd = hip_gemm.pack_weight(w, True, flip, dtype=y.dtype)
+                dx = torch.empty((plan.num_in, cin), dtype=y.dtype, device=dev)
+                _lib.check(L.wcn_conv_gather_gemm(_lib.ptr(dyc), _lib.ptr(wpd), _lib.ptr(dx), _lib.ptr(tbl), _lib.ptr(msk),
+                                                  _lib.ptr(perm), None, M, plan.num_in, cout, cin, K, code, _lib.WCN_ALGO_MFMA, 1,
+                                                  int(flip), stream), "wcn_conv_gather_gemm")
+        if need_dw:
+            slot = getattr(w, "_wcn_grad_slot", None)
+            if slot is not None and w.grad is None and slot.dtype == torch.float32 and slot.shape == w.shape:
+                dw = slot.detach()  # data parallelism: straight into the gradient bucket (dist.GradientBuckets)
+            else:
+                dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+            ws_bytes = hip_gemm._wgrad_workspace(K, cin, cout, _lib.WCN_ALGO_MFMA)
+            wws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.wcn_conv_wgrad(_lib.ptr(x), _lib.ptr(dyc), _lib.ptr(dw), _lib.ptr(km.in_maps_device),
+                                        _lib.ptr(km.out_maps_device), _lib.ptr(km._offsets_dev), plan.num_in, M, cin, cout, K,
+                                        code, _lib.WCN_ALGO_MFMA, _lib.ptr(wws), ws_bytes, stream), "wcn_conv_wgrad")
+            if dw.dtype != w.dtype:
+                dw = dw.to(w.dtype)
+        dgamma, dbeta = _affine_grads(ctx, sums)
+        ctx.plan = None
+        return dx, dw, dgamma, dbeta, None
+
+
+class _PointwiseBnAct(Function):
+    """Kernel volume 1, stride 1: dense products on the feature tensor (reference shortcut `helper.py:206-213`); the weight
+    gradient through the sparse AtB kernel with the identity pair list (`pointwise.dense_wgrad`)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], plan: _Plan) -> Tensor:
+        w16 = w[0] if w.dtype == x.dtype else w[0].to(x.dtype)
+        y = x @ w16
+        out, stats = _bn_forward(plan, y, gamma, beta)
+        ctx.save_for_backward(x, w16, y, out if plan.relu else None, stats, gamma)
+        ctx.plan, ctx.wdtype = plan, w.dtype
+        ctx.gdtype = gamma.dtype if gamma is not None else None
+        ctx.bdtype = beta.dtype if beta is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        from .pointwise import dense_wgrad
+
+        x, w16, y, out, stats, gamma = ctx.saved_tensors
+        plan = ctx.plan
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dyc, sums = _bn_backward(plan, grad_out, y, out, stats, gamma, need_dx or need_dw)
+        dx = dw = None
+        if need_dx:
+            dx = dyc @ w16.t()
+        if need_dw:
+            dw = dense_wgrad(x, dyc).unsqueeze(0)
+            if dw.dtype != ctx.wdtype:
+                dw = dw.to(ctx.wdtype)
+        dgamma, dbeta = _affine_grads(ctx, sums)
+        ctx.plan = None
+        return dx, dw, dgamma, dbeta, None
+
+
+def _static_ok(conv, norm) -> int:
+    """Module properties that do not change between calls (memoised on the convolution): 0 = general path, 1 = gather GEMM,
+    2 = pointwise."""
+    from warpconvnet_amd.nn.functional.sparse_conv.helper import STRIDED_CONV_MODE
+    from warpconvnet_amd.nn.modules.sparse_conv import SpatiallySparseConv
+
+    if type(norm) is not torch.nn.BatchNorm1d or not isinstance(conv, SpatiallySparseConv):
+        return 0
+    if conv.groups != 1 or conv.bias is not None or conv.transposed or conv.generative or conv.weight.ndim != 3:
+        return 0
+    if conv.num_spatial_dims != 3 or conv.order is not None or conv.compute_dtype is not None:
+        return 0
+    if conv.stride_mode != STRIDED_CONV_MODE.STRIDE_ONLY:
+        return 0
+    for a in (conv.fwd_algo, conv.dgrad_algo, conv.wgrad_algo):
+        if str(getattr(a, "value", a)).lower() not in ("auto", "hip_mfma"):
+            return 0
+    if conv.weight.dtype != torch.float32 or norm.num_features != conv.out_channels:
+        return 0
+    if all(k == 1 for k in conv.kernel_size):
+        return 2 if all(s == 1 for s in conv.stride) else 0
+    return 1
+
+
+def conv_bn_act(x, conv, norm, relu: bool):
+    """``relu(norm(conv(x)))`` (``relu`` optional) through the fused node, or ``None`` when the layer needs the general path.
+
+    ``x``: Voxels on the GPU; the compute dtype is the autocast dtype (bf16 / fp16) or a 16-bit feature dtype."""
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.functional.sparse_conv.helper import generate_output_coords_and_kernel_map, wrap_conv_output
+
+    if os.environ.get("WARPCONVNET_AMD_FUSED_BLOCK", "1") == "0":
+        return None
+    ok = conv.__dict__.get("_wcn_block_ok")
+    if ok is None or ok[0] is not norm:
+        ok = conv.__dict__["_wcn_block_ok"] = (norm, _static_ok(conv, norm))
+    kind = ok[1]
+    if not kind or not isinstance(x, Voxels):
+        return None
+    raw = x.batched_features.batched_tensor
+    if not raw.is_cuda or raw.shape[0] < 2:
+        return None
+    dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else raw.dtype
+    if dtype not in (torch.bfloat16, torch.float16):
+        return None
+    if not norm.training and (norm.running_mean is None or norm.running_var is None):
+        return None
+    cin, cout = conv.in_channels, conv.out_channels
+    K = conv.weight.shape[0]
+    code = _lib.dtype_code(dtype)
+    plan = _Plan()
+    plan.cin, plan.cout, plan.K, plan.code, plan.relu = cin, cout, K, code, bool(relu)
+    if kind == 2:
+        feats = x.feature_tensor
+        if feats.dtype != dtype:
+            feats = feats.to(dtype)
+        feats = feats.contiguous()
+        plan.km, plan.num_in, plan.num_out = None, feats.shape[0], feats.shape[0]
+        (plan.training, plan.momentum, plan.eps, plan.running_mean, plan.running_var, plan.counter,
+         plan.fused_running) = bn_module_state(norm, feats)
+        return x.replace(batched_features=_PointwiseBnAct.apply(feats, conv.weight, norm.weight, norm.bias, plan))
+    if not (hip_gemm._gather_ok(cin, cout, K, code) and hip_gemm._gather_ok(cout, cin, K, code) and hip_gemm._wgrad_ok(cin, cout, code)):
+        return None
+    in_ts = x.tensor_stride or (1, 1, 1)
+    out_ts = tuple(o * s for o, s in zip(conv.stride, in_ts))
+    bcoords_out, out_offsets, km = generate_output_coords_and_kernel_map(
+        x, conv.kernel_size, conv.dilation, conv.stride, need_pairs=torch.is_grad_enabled(), optimistic=True)
+    M = bcoords_out.shape[0]
+    if M < 2 or km._nbr is None:
+        # degenerate sizes, or a map that only has its CSR form (user-made): the general path (it finds the map in the cache)
+        return None
+    feats = x.feature_tensor
+    if feats.dtype != dtype:
+        feats = feats.to(dtype)
+    feats = feats.contiguous()
+    plan.km, plan.num_in, plan.num_out = km, feats.shape[0], M
+    (plan.training, plan.momentum, plan.eps, plan.running_mean, plan.running_var, plan.counter,
+     plan.fused_running) = bn_module_state(norm, feats)
+    out = _ConvBnAct.apply(feats, conv.weight, norm.weight, norm.bias, plan)
+    return wrap_conv_output(x, bcoords_out, out_offsets, out, out_ts)

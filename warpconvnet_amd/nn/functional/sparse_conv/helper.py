@@ -254,6 +254,13 @@ def spatially_sparse_conv(
         groups, use_fp16_accum, bias,  # bias: fused epilogue + HIP column-sum gradient (reference: helper.py:339-342)
     )
 
+    return wrap_conv_output(input_sparse_tensor, bcoords_out, out_offsets, out_feats, out_tensor_stride)
+
+
+def wrap_conv_output(input_sparse_tensor: Voxels, bcoords_out: Tensor, out_offsets: Tensor, out_feats: Tensor,
+                     out_tensor_stride) -> Voxels:
+    """The output geometry of a convolution: the input's coordinate object when the output set is the input set, a new
+    ``IntCoords`` (with its batch-indexed form attached) otherwise."""
     if bcoords_out is input_sparse_tensor.batch_indexed_coordinates:
         # same output set (stride-1, non-generative layers): keep the coordinate object - no [N, 3] copy, no new batch-index
         # pass for the next layer, and the next map build recognises "same coordinate tensor" by pointer

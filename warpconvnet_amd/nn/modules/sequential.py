@@ -10,7 +10,10 @@ from warpconvnet_amd.geometry.base.geometry import Geometry
 
 from warpconvnet_amd.nn.functional.normalizations import batch_norm_module_forward, hip_batch_norm_supported
 
+from warpconvnet_amd.nn.functional.sparse_conv.block import conv_bn_act
+
 from .base_module import BaseSpatialModule
+from .sparse_conv import SpatiallySparseConv
 
 
 def _has_hooks(module: nn.Module) -> bool:
@@ -33,6 +36,17 @@ class Sequential(nn.Sequential, BaseSpatialModule):
             module = mods[i]
             i += 1
             spatial = isinstance(module, BaseSpatialModule)
+            if (spatial and i < len(mods) and type(mods[i]) is nn.BatchNorm1d and isinstance(x, Geometry)
+                    and isinstance(module, SpatiallySparseConv) and not _has_hooks(module) and not _has_hooks(mods[i])):
+                # SparseConv3d -> BatchNorm1d (-> ReLU): one autograd node, direct launches (functional/sparse_conv/block.py);
+                # None = a layer the fused node does not take, the modules then run one by one below
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                fuse_relu = type(nxt) is nn.ReLU and not _has_hooks(nxt)
+                y = conv_bn_act(x, module, mods[i], fuse_relu)
+                if y is not None:
+                    x = carrier = y
+                    i += 1 + int(fuse_relu)
+                    continue
             if not spatial and type(module) is nn.BatchNorm1d and not _has_hooks(module):
                 # BatchNorm1d on the feature tensor (and the ReLU behind it, the ConvBlock pattern of the reference's
                 # models) goes through the HIP kernels: same function, state and gradients (functional/normalizations.py)
