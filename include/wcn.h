@@ -190,6 +190,12 @@ int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_
  * smallest row of a duplicated coordinate - for any kernel size, stride and dilation; replaces wcn_hash_insert +
  * wcn_kmap_probe when the input set already has a cell table.  reference: cuhash_kernel_map.cu:93-134;
  * coarse-to-fine search geometry/coords/search/hierarchical_search.py:25-66. */
+/* the cell table alone (prepare + inserts + finish of wcn_kmap_build_binned, strict insert: the smallest row of a duplicated
+ * coordinate wins by construction) for a coordinate set that has no submanifold build yet - e.g. a network whose first
+ * spatial layer is strided.  `scratch`: n uint32.  status: WCN_FLAG_TABLE_FULL (retry with a larger max_blocks) /
+ * WCN_FLAG_COORD_RANGE.  workspace: wcn_kmap_binned_workspace(n, max_blocks). */
+int wcn_kmap_cells_build(const int32_t* coords, int64_t n, int64_t max_blocks, void* workspace, size_t workspace_bytes,
+                         uint32_t* scratch, int32_t* status, wcn_stream_t stream);
 int wcn_cells_stride_supported(const int32_t stride[3]);
 int64_t wcn_cells_stride_tiles(int64_t n);
 int wcn_cells_stride_count(const void* cells_workspace, int64_t n, int64_t max_blocks, const int32_t* coords,

@@ -82,9 +82,10 @@ def test_strided_map_bit_exact(ksize, stride):
     assert km.identity_map_index is None and not km._symmetric
 
 
+@pytest.mark.parametrize("prebuild", [True, False])
 @pytest.mark.parametrize("ksize,stride", [((2, 2, 2), (2, 2, 2)), ((3, 3, 3), (2, 2, 2)), ((2, 2, 2), (4, 4, 4)), ((3, 3, 3), (1, 2, 1)),
                                           ((4, 2, 1), (4, 2, 1)), ((2, 2, 2), (8, 8, 8))])
-def test_strided_layers_from_the_cell_table(ksize, stride):
+def test_strided_layers_from_the_cell_table(ksize, stride, prebuild):
     """The same contract as test_strided_map_bit_exact, answered from the cell table a (validated) submanifold build left
     on the coordinate tensor (csrc/kmap_stride.hip): down-sampled coordinates + offsets bit-exact vs the oracle, the kernel
     map bit-exact whether it comes out of the down-sampling pass (kernel_size == stride) or from the cell probe; duplicate
@@ -97,8 +98,10 @@ def test_strided_layers_from_the_cell_table(ksize, stride):
     s[:, 1:] -= 7
     s = np.concatenate([s[:6000], s[100:160], s[6000:]], 0).astype(np.int32)  # 60 duplicated rows inside batch 0
     a = torch.from_numpy(s).to(_dev())
-    sub = generate_kernel_map(a, a, (1, 1, 1), (3, 3, 3))  # the level's submanifold map: leaves the cell table on `a`
-    assert getattr(a, "_wcn_cells", None) is not None and sub._has_duplicates
+    if prebuild:
+        sub = generate_kernel_map(a, a, (1, 1, 1), (3, 3, 3))  # the level's submanifold map: leaves the cell table on `a`
+        assert getattr(a, "_wcn_cells", None) is not None and sub._has_duplicates
+    # (else: a strided FIRST layer - the down-sampling pass builds the table itself, strict insert)
     want, _ = okmap.stride_coords(s, stride)
     inserts = []
     real_insert = packed_hashmap.PackedHashTable._launch_insert
@@ -111,8 +114,32 @@ def test_strided_layers_from_the_cell_table(ksize, stride):
     finally:
         packed_hashmap.PackedHashTable._launch_insert = real_insert
     assert not inserts, "the cell-table route must not build a hash table"
+    assert getattr(a, "_wcn_cells", None) is not None
     _check_against_oracle(km, s, want, ksize, stride)
     assert km.identity_map_index is None and not km._symmetric
+
+
+def test_strided_first_layer_table_grows_and_range_errors_surface():
+    """Down-sampling that builds its own cell table: a scene with one voxel per 8^3 block overflows the first-try block bound
+    (TABLE_FULL -> larger table, remembered in the hints) and still gives the oracle's coordinates; a coordinate outside
+    the packed range raises ValueError like the hash path (reference packed_hashmap.py:66-82)."""
+    from warpconvnet_amd.geometry.coords.ops.stride import stride_coords
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import default_hints
+
+    rng = np.random.default_rng(9)
+    cells = rng.permutation(40 * 40 * 40)[:30000]
+    s = np.stack([np.zeros_like(cells), cells // 1600 * 8 + 3, cells // 40 % 40 * 8 + 1, cells % 40 * 8 + 6], 1).astype(np.int32)
+    default_hints().reset()
+    got, offs = stride_coords(torch.from_numpy(s).to(_dev()), (2, 2, 2), num_batches=1)
+    assert default_hints().div < 16
+    want, _ = okmap.stride_coords(s, (2, 2, 2))
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert offs.tolist() == [0, len(want)]
+    default_hints().reset()
+    bad = scene_u(3000, 5, 0)
+    bad[11, 3] = -131073
+    with pytest.raises(ValueError):
+        stride_coords(torch.from_numpy(bad).to(_dev()), (2, 2, 2), num_batches=1)
 
 
 def test_binned_edge_cases(kmap_method):

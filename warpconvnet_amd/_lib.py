@@ -77,6 +77,7 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     ),
+    "wcn_kmap_cells_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wcn_cells_stride_supported": (c_int, [_3I]),
     "wcn_cells_stride_tiles": (c_int64, [c_int64]),
     "wcn_cells_stride_count": (c_int, [c_void_p, c_int64, c_int64, c_void_p, _3I, c_void_p, c_void_p, c_int32, c_void_p,

@@ -440,6 +440,29 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
   }
 }
 
+// prepare -> sampled insert -> insert -> finish: the cell table of `coords` (and the halo list / neighbour-block ids of geometry g)
+static void launch_cell_table(const CellTable& t, const CellGeom& g, const int4* coords, int64_t n, int kp, int mw, int32_t* nbr,
+                              uint32_t* mask, int32_t* status, int strict, hipStream_t s) {
+  const int64_t capacity = t.capacity;
+  const uint32_t cmask = (uint32_t)(capacity - 1);
+  const int64_t max_blocks = t.max_blocks;
+  const int64_t prep = capacity > g.halo_cells ? capacity : g.halo_cells;
+  hipLaunchKernelGGL(cell_prepare_kernel, dim3((unsigned)ceil_div(prep, 256)), dim3(256), 0, s, (uint4*)t.slots, capacity,
+                     t.ctr, t.halo, g, status);
+  const int64_t n_first = ceil_div(n, kInsertSample);
+  hipLaunchKernelGGL(cell_insert_kernel<0>, dim3((unsigned)ceil_div(n_first, kInsertThreads)), dim3(kInsertThreads), 0, s, t.slots, cmask,
+                     coords, n, t, status, kp, mw, nbr, mask, strict);
+  hipLaunchKernelGGL(cell_insert_kernel<1>, dim3((unsigned)ceil_div(n, kInsertThreads)), dim3(kInsertThreads), 0, s, t.slots, cmask,
+                     coords, n, t, status, kp, mw, nbr, mask, strict);
+  {
+    const int64_t work = n > 64 * max_blocks ? n : 64 * max_blocks;  // voxels vs one wave per block
+    int64_t wgs = ceil_div(work, 256);
+    if (wgs > 8192) wgs = 8192;
+    hipLaunchKernelGGL(cell_finish_kernel, dim3((unsigned)wgs), dim3(256), 0, s, (const BSlot*)t.slots, cmask,
+                       coords, n, t, g, mw, (const uint32_t*)mask, strict);
+  }
+}
+
 static inline int lanes_per_row_b(int kp) {
   int l = 8;
   while (l < kp && l < 64) l <<= 1;
@@ -488,21 +511,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   const int64_t capacity = t.capacity;
   const uint32_t cmask = (uint32_t)(capacity - 1);
 
-  const int64_t prep = capacity > g.halo_cells ? capacity : g.halo_cells;
-  hipLaunchKernelGGL(cell_prepare_kernel, dim3((unsigned)ceil_div(prep, 256)), dim3(256), 0, s, (uint4*)t.slots, capacity,
-                     t.ctr, t.halo, g, status);
-  const int64_t n_first = ceil_div(n, kInsertSample);
-  hipLaunchKernelGGL(cell_insert_kernel<0>, dim3((unsigned)ceil_div(n_first, kInsertThreads)), dim3(kInsertThreads), 0, s, t.slots, cmask,
-                     (const int4*)coords, n, t, status, kp, mw, nbr, mask, (int)strict);
-  hipLaunchKernelGGL(cell_insert_kernel<1>, dim3((unsigned)ceil_div(n, kInsertThreads)), dim3(kInsertThreads), 0, s, t.slots, cmask,
-                     (const int4*)coords, n, t, status, kp, mw, nbr, mask, (int)strict);
-  {
-    const int64_t work = n > 64 * max_blocks ? n : 64 * max_blocks;  // voxels vs one wave per block
-    int64_t wgs = ceil_div(work, 256);
-    if (wgs > 8192) wgs = 8192;
-    hipLaunchKernelGGL(cell_finish_kernel, dim3((unsigned)wgs), dim3(256), 0, s, (const BSlot*)t.slots, cmask,
-                       (const int4*)coords, n, t, g, mw, (const uint32_t*)mask, (int)strict);
-  }
+  launch_cell_table(t, g, (const int4*)coords, n, kp, mw, nbr, mask, status, (int)strict, s);
   const int halo_pad = (g.halo_cells + 63) & ~63;
   // waves per workgroup: 4, fewer when halo list + one LDS grid per wave would not fit (halo 6..8: 20^3..24^3 cells)
   int nb_waves = kNbThreads / 64;
@@ -547,6 +556,20 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
     default: WCN_CELL_NB(64); break;
   }
 #undef WCN_CELL_NB
+  return launch_status();
+}
+
+int wcn_kmap_cells_build(const int32_t* coords, int64_t n, int64_t max_blocks, void* workspace, size_t workspace_bytes,
+                         uint32_t* scratch, int32_t* status, wcn_stream_t stream) {
+  if (n < 0 || !status || max_blocks < 1 || max_blocks > (1ll << 29)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n == 0) return WCN_SUCCESS;
+  if (n >= (1ll << 31) || !coords || !scratch || !workspace || workspace_bytes < wcn_kmap_binned_workspace(n, max_blocks))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  const CellTable t = carve_cells(workspace, n, max_blocks);
+  const int32_t one[3] = {1, 1, 1};
+  const CellGeom g = make_cell_geom(one, one);  // no halo: the table alone
+  // strict = 1: a duplicated coordinate keeps its smallest row by construction (nothing checks afterwards)
+  launch_cell_table(t, g, (const int4*)coords, n, 0, 1, nullptr, scratch, status, 1, (hipStream_t)stream);
   return launch_status();
 }
 

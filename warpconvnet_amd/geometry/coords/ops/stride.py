@@ -23,7 +23,9 @@ def _stride_coords_from_cells(bcoords: Tensor, stride: Tuple[int, ...], num_batc
 
     from warpconvnet_amd import _lib
 
-    ws, n_cells, max_blocks = bcoords._wcn_cells
+    from warpconvnet_amd.geometry.coords.search.packed_hashmap import PackedHashTable
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import default_hints
+
     n, dev = bcoords.shape[0], bcoords.device
     L = _lib.lib()
     stream = _lib.stream_handle(dev)
@@ -31,10 +33,36 @@ def _stride_coords_from_cells(bcoords: Tensor, stride: Tuple[int, ...], num_batc
     ntile = int(L.wcn_cells_stride_tiles(n))
     flags = torch.empty(max(1, (n + 63) // 64), dtype=torch.int64, device=dev)
     counts = torch.empty(ntile + 1, dtype=torch.int32, device=dev)
-    out_offsets = torch.empty(num_batches + 1, dtype=torch.int32, device=dev)
-    _lib.check(L.wcn_cells_stride_count(_lib.ptr(ws), n, max_blocks, _lib.ptr(bcoords), st, _lib.ptr(flags), _lib.ptr(counts),
-                                        num_batches, _lib.ptr(out_offsets), stream), "wcn_cells_stride_count")
-    offsets = out_offsets.cpu()  # the one host read
+    meta = torch.zeros(num_batches + 2, dtype=torch.int32, device=dev)  # [out_offsets (B + 1) | status of a table built here]
+    cells = getattr(bcoords, "_wcn_cells", None)
+    hints = default_hints()
+    while True:
+        built = cells is None
+        if built:
+            # no submanifold layer has run on these coordinates (a network whose first spatial layer is strided): the table
+            # alone, strict insert - four launches instead of a hash insert of every candidate
+            max_blocks = hints.max_blocks(n)
+            ws_bytes = L.wcn_kmap_binned_workspace(n, max_blocks)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            scratch = torch.empty(n, dtype=torch.int32, device=dev)
+            _lib.check(L.wcn_kmap_cells_build(_lib.ptr(bcoords), n, max_blocks, _lib.ptr(ws), ws_bytes, _lib.ptr(scratch),
+                                              _lib.ptr(meta[num_batches + 1 :]), stream), "wcn_kmap_cells_build")
+            cells = (ws, n, max_blocks)
+        ws, _, max_blocks = cells
+        _lib.check(L.wcn_cells_stride_count(_lib.ptr(ws), n, max_blocks, _lib.ptr(bcoords), st, _lib.ptr(flags), _lib.ptr(counts),
+                                            num_batches, _lib.ptr(meta), stream), "wcn_cells_stride_count")
+        host = meta.cpu()  # the one host read: output offsets (+ the status of a table built here)
+        status = int(host[-1])
+        if built and (status & _lib.WCN_FLAG_TABLE_FULL) and max_blocks < n:
+            hints.div = 4 if hints.div > 4 else 1  # sparser scenes than the bound assumed: larger table, remembered
+            cells = None
+            meta.zero_()
+            continue
+        PackedHashTable.raise_for_flags(status, n, 2 * n)
+        break
+    if built:
+        bcoords._wcn_cells = cells  # complete and validated: later layers on this tensor reuse it
+    offsets = host[: num_batches + 1].clone()
     m = int(offsets[-1])
     out = torch.empty((m, 4), dtype=torch.int32, device=dev)
     K = int(stride[0]) * int(stride[1]) * int(stride[2])
@@ -55,9 +83,9 @@ def stride_coords(batch_indexed_coords: Tensor, stride: Tuple[int, ...], order=N
                   with_map: bool = False) -> Tuple[Tensor, Tensor]:
     """[N, D+1] -> (unique floor(coords / stride) [M, D+1], CPU offsets [B+1]).
 
-    ``num_batches`` (known by the caller from the input's offsets) enables the cell-table route when the coordinate tensor
-    carries the table of an earlier submanifold build on it (`_wcn_cells`, set by `generate_kernel_map`); ``with_map``
-    additionally emits the kernel map of a convolution whose kernel is the stride window."""
+    ``num_batches`` (known by the caller from the input's offsets) enables the cell-table route: the table of an earlier
+    submanifold build on the coordinate tensor (`_wcn_cells`, set by `generate_kernel_map`) or, without one, a table built
+    here; ``with_map`` additionally emits the kernel map of a convolution whose kernel is the stride window."""
     nd = batch_indexed_coords.shape[1] - 1
     stride = ntuple(stride, nd)
     if all(s == 1 for s in stride):
@@ -68,8 +96,8 @@ def stride_coords(batch_indexed_coords: Tensor, stride: Tuple[int, ...], order=N
     if (num_batches is not None and order == POINT_ORDERING.RANDOM and batch_indexed_coords.is_cuda
             and batch_indexed_coords.shape[1] == 4 and batch_indexed_coords.shape[0] > 0
             and batch_indexed_coords.dtype == torch.int32 and batch_indexed_coords.is_contiguous()
-            and getattr(batch_indexed_coords, "_wcn_cells", None) is not None
-            and batch_indexed_coords._wcn_cells[1] == batch_indexed_coords.shape[0]):
+            and (getattr(batch_indexed_coords, "_wcn_cells", None) is None
+                 or batch_indexed_coords._wcn_cells[1] == batch_indexed_coords.shape[0])):
         from warpconvnet_amd import _lib
 
         if _lib.lib().wcn_cells_stride_supported(_lib.i3(stride)):
