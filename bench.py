@@ -322,14 +322,18 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
     # the dominant kernel = the GEMM with the largest IN-STEP time (stable: dgrad moves the most bytes)
     dom_key = max(("fwd", "dgrad", "wgrad"), key=lambda k: times[k])
     dom = entry(dom_key)
+    # HBM bytes per launch from the PMC passes (separate rocprofv3 runs of this same command, tools/collect_profiles.sh): a
+    # STATIC figure read from the newest committed summary, not a measurement of this run - labelled as such in the line
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
-    if N == 1_000_000 and args.scene == "uniform" and os.path.exists(pmc_file):
-        with open(pmc_file) as f:
+    prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    pmc_files = sorted(f for f in (os.listdir(prof_dir) if os.path.isdir(prof_dir) else []) if f.endswith("_pmc_traffic.json"))
+    if N == 1_000_000 and args.scene == "uniform" and pmc_files:
+        with open(os.path.join(prof_dir, pmc_files[-1])) as f:
             pmc = json.load(f)
         if dom_key in pmc:
             traffic = pmc[dom_key]["hbm_bytes"]
-            traffic_src = "profiles/r03_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+            traffic_src = (f"profiles/{pmc_files[-1]} (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this "
+                           "command; static: read from the committed summary)")
 
     # map-cached variant (networks amortise the map over the layers of a resolution level)
     x_cached = Voxels(coords, feats, offsets=offsets)
@@ -368,11 +372,14 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
         },
         "roofline": {
             "bound": "hbm", "kernel": names[dom_key], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["frac"], "compulsory_frac": dom["compulsory_frac"], "traffic": traffic, "traffic_source": traffic_src,
+            "frac": dom["frac"], "compulsory_frac": dom["compulsory_frac"], "traffic": traffic, "traffic_static": traffic is not None,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
             "timing": "HIP events on the launch stream between the phases of an unrolled step (map build -> fwd -> dgrad -> wgrad), "
-                      "i.e. in-step; profiles/r03_kernel_trace_stats.md is the rocprofv3 trace of this command",
+                      "i.e. in-step; the rocprofv3 trace of this command is the newest profiles/r*_kernel_trace_stats.md",
         },
+        "step_includes": "kernel-map build, forward, dgrad, wgrad + bias gradient, SGD parameter update (so both packed bf16 "
+                         "weight images are rebuilt every step)",
         "roofline_all": {names[k]: entry(k) for k in ("fwd", "dgrad", "wgrad", "kmap")},
         "phases_ms": {"kmap": round(t_kmap, 4), "fwd_kernel": round(tk_fwd, 4), "dgrad_kernel": round(tk_dgrad, 4),
                       "wgrad_kernels": round(tk_wgrad, 4), "sum": round(sum(in_step), 4)},
