@@ -400,7 +400,9 @@ def generate_kernel_map(
         (The forward / dgrad kernels read the neighbour table only, so nothing queued on the tables has to be repeated
         when the speculative pair lists turn out too short.)"""
         PackedHashTable.raise_for_flags(flags, N, table_capacity)
-        offsets_host = b["meta_host"][: K + 1].clone()
+        # (numpy copy, not Tensor.clone(): copying OUT of pinned memory goes through a stream-synchronising memcpy in torch -
+        # measured 380 us per call with work queued, i.e. the host waited for the forward kernel it had just launched)
+        offsets_host = torch.from_numpy(b["meta_host"].numpy()[: K + 1].copy())
         pair_capacity = int(offsets_host[-1])
         has_duplicates = bool(flags & _lib.WCN_FLAG_DUPLICATE_COORD)
         identity = K // 2 if (odd and unit_stride and N == M) else None
