@@ -253,14 +253,15 @@ int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype);
  * packs w[k]^T (dgrad); `flip`=1 additionally reverses k (dgrad of a submanifold map reuses the
  * forward table: rnbr[n][k] == nbr[n][K-1-k]).  Returns bytes needed / fills `packed`.  `cin` / `cout` are the kernel-side
  * roles (reduce over cin, produce cout); the image holds num_offsets * round_up(cin, 64) * cout elements (the channel-split
- * kernels reduce in 64-channel chunks and zero-pad a trailing 32-channel chunk) - size `packed` with wcn_packed_weight_bytes. */
+ * kernels reduce in 64-channel chunks and zero-pad a trailing 32-channel chunk) - size `packed` with wcn_packed_weight_bytes;
+ * `packed_bytes` = the size of the caller's buffer: WCN_ERROR_INVALID_PARAMETERS (nothing launched) if it is smaller than that. */
 size_t wcn_packed_weight_bytes(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose);
 int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype,
-                    int32_t transpose, int32_t flip, void* packed, wcn_stream_t stream);
+                    int32_t transpose, int32_t flip, void* packed, size_t packed_bytes, wcn_stream_t stream);
 /* the same packed image (`dtype` = WCN_F16 / WCN_BF16) straight from fp32 master weights, rounded to nearest even like the
  * framework's cast: one launch instead of cast + pack per convolution and direction. */
 int wcn_pack_weight_f32(const float* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose,
-                        int32_t flip, void* packed, wcn_stream_t stream);
+                        int32_t flip, void* packed, size_t packed_bytes, wcn_stream_t stream);
 
 /* y = gather-GEMM over a neighbour table.  Serves forward (x, packed w) and dgrad (dy, packed w^T).
  *   in   [n_in, cin]   out [n_out, cout]   nbr [n_out, kp]   mask [n_out, mw]   perm [n_out] or NULL

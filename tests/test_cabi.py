@@ -56,6 +56,12 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_mask_argsort_workspace(1000) > 3 * 4000 and L.wcn_kmap_binned_workspace(1000, 250) > 250 * 2048
     assert L.wcn_kmap_binned_supported(_lib.i3((4, 4, 2)), _lib.i3((1, 1, 1))) == 0  # K % 32 == 0: hash path
     assert L.wcn_kmap_tally_sort_workspace(1000) >= L.wcn_mask_argsort_workspace(1000)
+    # the packing entry points check the destination size (ABI 2): a short buffer is refused before any launch
+    import ctypes as _ct
+    buf = (_ct.c_char * 64)()
+    assert L.wcn_abi_version() >= 2
+    assert L.wcn_pack_weight(_ct.addressof(buf), 27, 64, 128, _lib.WCN_BF16, 0, 0, _ct.addressof(buf), 64, None) == -5
+    assert L.wcn_pack_weight_f32(_ct.addressof(buf), 27, 96, 96, _lib.WCN_BF16, 0, 0, _ct.addressof(buf), 27 * 96 * 96 * 2, None) == -5
     # parameter validation happens before any launch: bad arguments come back as status codes
     assert L.wcn_hash_prepare(None, 16, None) == -5
     assert L.wcn_hash_prepare(None, 17, None) == -5

@@ -102,11 +102,11 @@ SIGNATURES = {
     "wcn_packed_weight_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "wcn_pack_weight": (
         c_int,
-        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
+        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p],
     ),
     "wcn_pack_weight_f32": (
         c_int,
-        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
+        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p],
     ),
     "wcn_conv_gather_gemm": (
         c_int,

@@ -71,14 +71,16 @@ size_t wcn_packed_weight_bytes(int32_t num_offsets, int32_t cin, int32_t cout, i
 }
 
 int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose,
-                    int32_t flip, void* packed, wcn_stream_t stream) {
+                    int32_t flip, void* packed, size_t packed_bytes, wcn_stream_t stream) {
   if (!w || !packed || num_offsets < 1 || cin < 1 || cout < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  if (packed_bytes < wcn_packed_weight_bytes(num_offsets, cin, cout, dtype, transpose)) return WCN_ERROR_INVALID_PARAMETERS;
   return pack_weight_mfma(w, num_offsets, cin, cout, dtype, transpose, flip, packed, (hipStream_t)stream);
 }
 
 int wcn_pack_weight_f32(const float* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose,
-                        int32_t flip, void* packed, wcn_stream_t stream) {
+                        int32_t flip, void* packed, size_t packed_bytes, wcn_stream_t stream) {
   if (!w || !packed || num_offsets < 1 || cin < 1 || cout < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  if (packed_bytes < wcn_packed_weight_bytes(num_offsets, cin, cout, dtype, transpose)) return WCN_ERROR_INVALID_PARAMETERS;
   return pack_weight_mfma_f32(w, num_offsets, cin, cout, dtype, transpose, flip, packed, (hipStream_t)stream);
 }
 

@@ -228,7 +228,7 @@ using namespace wcn;
 
 extern "C" {
 
-int wcn_abi_version(void) { return 1; }
+int wcn_abi_version(void) { return 2; }  // 2: wcn_pack_weight[_f32] take the size of the destination buffer
 
 const char* wcn_status_string(int status) {
   switch (status) {

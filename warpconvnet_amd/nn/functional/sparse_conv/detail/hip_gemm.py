@@ -151,13 +151,15 @@ def _pack_weight_uncached(weight: Tensor, K: int, kin: int, kout: int, transpose
     if weight.dtype == torch.float32 and dtype != torch.float32:
         _lib.check(
             _lib.lib().wcn_pack_weight_f32(_lib.ptr(weight), K, kin, kout, _lib.dtype_code(dtype), int(transpose), int(flip),
-                                           _lib.ptr(packed), _lib.stream_handle(weight.device)),
+                                           _lib.ptr(packed), packed.numel() * packed.element_size(),
+                                           _lib.stream_handle(weight.device)),
             "wcn_pack_weight_f32",
         )
         return packed
     _lib.check(
         _lib.lib().wcn_pack_weight(_lib.ptr(weight), K, kin, kout, _lib.dtype_code(weight.dtype), int(transpose),
-                                   int(flip), _lib.ptr(packed), _lib.stream_handle(weight.device)),
+                                   int(flip), _lib.ptr(packed), packed.numel() * packed.element_size(),
+                                   _lib.stream_handle(weight.device)),
         "wcn_pack_weight",
     )
     return packed
