@@ -84,6 +84,7 @@ class IntSearchResult:
         self._symmetric: bool = False
         self._self_exact: bool = False  # symmetric AND no duplicate coordinates: nbr[r][K//2] == r for every row
         self._has_duplicates: bool = False  # submanifold map over repeated coordinates: dgrad goes through the pair lists
+        self._dup_symmetric: bool = False   # ... with an odd kernel at stride 1: dgrad on the gather kernels after all
         self._rev: Optional[Tuple[Tensor, Tensor, Tensor]] = None
         self._num_in: Optional[int] = None
         self._num_out: Optional[int] = None

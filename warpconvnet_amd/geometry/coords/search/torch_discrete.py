@@ -451,6 +451,7 @@ def generate_kernel_map(
         # duplicate OUTPUT rows (a submanifold map over repeated coordinates) share their input rows per offset: the
         # [N_in, K] reverse table has one slot per (input row, offset), so dgrad then goes through the pair lists
         result._has_duplicates = bool(same_tensor and has_duplicates)
+        result._dup_symmetric = bool(result._has_duplicates and odd and unit_stride)  # dgrad: `hip_gemm._dgrad_duplicates`
 
     result = IntSearchResult._blank(K, dev)
     result._num_in, result._num_out = N, M

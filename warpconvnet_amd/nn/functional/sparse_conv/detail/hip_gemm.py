@@ -295,7 +295,8 @@ def _dgrad_pair_lists(dy: Tensor, w: Tensor, kernel_map: IntSearchResult, num_in
     """Input gradient of a map built over REPEATED coordinates (degenerate input: `Voxels.unique()` removes it).  Several
     output rows then pair with one input row at the same offset, which neither the k-flipped forward table nor the
     one-slot-per-(row, offset) reverse table can express: scatter-add over the pair lists, fp32 accumulation - the
-    reference's own explicit formulation (`explicit.py:60-92`).  Correct, not fast."""
+    reference's own explicit formulation (`explicit.py:60-92`).  Correct, not fast; submanifold maps with an odd kernel
+    take `_dgrad_duplicates` (gather kernels) instead, this loop is left for the remaining shapes."""
     K, cin, cout = w.shape
     dx = torch.zeros(num_in, cin, dtype=torch.float32, device=dy.device)
     wf = w.float()
@@ -304,6 +305,27 @@ def _dgrad_pair_lists(dy: Tensor, w: Tensor, kernel_map: IntSearchResult, num_in
         if in_map.shape[0]:
             dx.index_add_(0, in_map.long(), dy[out_map.long()].float() @ wf[k].T)
     return dx.to(dy.dtype)
+
+
+def _dgrad_duplicates(dy: Tensor, w: Tensor, kernel_map: IntSearchResult, num_in: int, algo: str) -> Tensor:
+    """Input gradient of a SUBMANIFOLD map over repeated coordinates (odd kernel, stride 1) on the gather kernels, no loop
+    over the offsets and no host sync.  Every row of a coordinate has the same neighbours (the smallest row - the "winner" -
+    of each neighbouring coordinate), and only winners appear as inputs, so with ``dy'[w] = sum of dy over the rows at w's
+    coordinate`` (one index_add onto ``winner = nbr[:, K//2]``) the gradient of a winner row is the ordinary k-flipped
+    product ``dx[i] = sum_k dy'[nbr[i][K-1-k]] . W[k]^T`` and every other row gets zero.  Same pair sums as the reference's
+    explicit formulation (`explicit.py:60-92`)."""
+    K = len(kernel_map)
+    n = num_in
+    winner = kernel_map._nbr[:, K // 2].long()
+    dyp = torch.zeros((n, dy.shape[1]), dtype=torch.float32, device=dy.device).index_add_(0, winner, dy.float()).to(dy.dtype)
+    shadow = IntSearchResult._blank(K, dy.device)  # the same tables, seen as a map without duplicates
+    shadow._nbr, shadow._mask, shadow._perm = kernel_map._nbr, kernel_map._mask, kernel_map._perm
+    shadow._offsets_dev, shadow._offsets = kernel_map._offsets_dev, kernel_map._offsets
+    shadow._symmetric, shadow._has_duplicates = True, False
+    shadow._in_maps, shadow._out_maps = kernel_map._in_maps, kernel_map._out_maps
+    dx = hip_dgrad(dyp, w, shadow, n, algo)
+    keep = winner == torch.arange(n, device=dy.device)
+    return dx * keep.unsqueeze(1).to(dx.dtype)
 
 
 def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_in_coords: int,
@@ -315,6 +337,8 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
     K, cin, cout = w.shape
     kernel_map.validate()
     if getattr(kernel_map, "_has_duplicates", False):
+        if getattr(kernel_map, "_dup_symmetric", False) and kernel_map._nbr is not None and dy.shape[0] == num_in_coords:
+            return _dgrad_duplicates(dy, w, kernel_map, num_in_coords, algo)
         return _dgrad_pair_lists(dy, w, kernel_map, num_in_coords)
     if algo == "auto" and dy.is_cuda and not _gather_ok(cout, cin, K, _code16(dy.dtype)):
         plan = _pad_plan(cout, cin, K, dy.dtype)  # kernel-side roles: reduce over cout, produce cin
