@@ -463,8 +463,10 @@ int wcn_pool_select(const void* dy, const int32_t* arg, const int32_t* tbl, int6
  *   wcn_bn_stats            mean[c], var[c] (biased, /n) in one pass (sums around the pivot x[0][c]).
  *   wcn_bn_apply            y = x * scale[c] + shift[c]; relu != 0: max(., 0).  (training: scale = gamma * rstd,
  *                           shift = beta - mean * scale; inference: the same from the running statistics.)
- *   wcn_bn_backward_reduce  sum_dy[c] = sum_r g, sum_dy_xhat[c] = sum_r g * (x - mean) * rstd, where g = dy, or 0 where
- *                           y <= 0 when `y` (the forward output of a fused ReLU) is given; `y` may be NULL.
+ *   wcn_bn_backward_reduce  sum_dy[c] = sum_r g, sum_dy_xhat[c] = sum_r g * (x - mean) * rstd, where g = dy, or 0 where the
+ *                           fused ReLU of the forward pass stored a zero: `relu_scale` / `relu_shift` (both or neither) are the
+ *                           scale / shift the forward applied, the mask is recomputed from x with the same fused
+ *                           multiply-add and rounding - the forward output is not read again.
  *   wcn_bn_backward_apply   dx = gamma * rstd * (g - sum_dy / n - xhat * sum_dy_xhat / n); gamma may be NULL (= 1). */
 size_t wcn_bn_workspace(int32_t channels);
 /*   wcn_bn_stats_fold       wcn_bn_stats plus, in the same launches, everything a training step derives from the
@@ -483,12 +485,12 @@ int wcn_bn_stats(const void* x, int64_t n, int32_t channels, int32_t dtype, floa
                  size_t workspace_bytes, wcn_stream_t stream);
 int wcn_bn_apply(const void* x, int64_t n, int32_t channels, int32_t dtype, const float* scale, const float* shift,
                  int32_t relu, void* y, wcn_stream_t stream);
-int wcn_bn_backward_reduce(const void* dy, const void* x, const void* y, int64_t n, int32_t channels, int32_t dtype,
-                           const float* mean, const float* rstd, float* sum_dy, float* sum_dy_xhat, void* workspace,
-                           size_t workspace_bytes, wcn_stream_t stream);
-int wcn_bn_backward_apply(const void* dy, const void* x, const void* y, int64_t n, int32_t channels, int32_t dtype,
-                          const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
-                          const float* sum_dy_xhat, void* dx, wcn_stream_t stream);
+int wcn_bn_backward_reduce(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
+                           int32_t channels, int32_t dtype, const float* mean, const float* rstd, float* sum_dy,
+                           float* sum_dy_xhat, void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+int wcn_bn_backward_apply(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
+                          int32_t channels, int32_t dtype, const float* mean, const float* rstd, const float* gamma,
+                          const float* sum_dy, const float* sum_dy_xhat, void* dx, wcn_stream_t stream);
 
 #ifdef __cplusplus
 }

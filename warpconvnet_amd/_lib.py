@@ -49,10 +49,10 @@ SIGNATURES = {
     "wcn_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int32, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
     "wcn_bn_apply": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
-    "wcn_bn_backward_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wcn_bn_backward_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wcn_bn_backward_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_bn_backward_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wcn_pool_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     "wcn_pool_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

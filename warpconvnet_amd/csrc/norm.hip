@@ -8,7 +8,8 @@
 //                           p[c] = x[0][c] (a value from the distribution: no catastrophic cancellation in
 //                           E[d^2] - E[d]^2), fp32, fixed-order two-level reduction => deterministic.
 //   wcn_bn_apply            y = x * scale[c] + shift[c], optional ReLU.
-//   wcn_bn_backward_reduce  sum_dy[c], sum_dy_xhat[c] with dy masked by (y > 0) when the ReLU was fused.
+//   wcn_bn_backward_reduce  sum_dy[c], sum_dy_xhat[c] with dy masked where the fused ReLU stored a zero; the mask is
+//                           recomputed from x and the forward's scale / shift (bn_affine), the output y is not read again.
 //   wcn_bn_backward_apply   dx = gamma * rstd * (dy - sum_dy / N - xhat * sum_dy_xhat / N).
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
@@ -36,13 +37,23 @@ template <> struct NCvt<__hip_bfloat16> {
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) NVec { T v[VEC]; };
 
+// y = x * scale + shift as ONE fused multiply-add, in the forward pass and wherever the backward passes need to know whether
+// the ReLU behind it let a value through: the mask (stored y > 0) is recomputed from x with the very same operation instead
+// of reading the forward output again (a third of the backward passes' traffic).
+__device__ __forceinline__ float bn_affine(float xf, float sc, float sh) { return __builtin_fmaf(xf, sc, sh); }
+template <typename T>
+__device__ __forceinline__ bool bn_relu_passes(float xf, float sc, float sh) {
+  return NCvt<T>::ld(NCvt<T>::st(fmaxf(bn_affine(xf, sc, sh), 0.f))) > 0.f;  // what the forward stored, compared with zero
+}
+
 // Thread layout of the column reductions: lanes_c threads side by side cover one row (VEC channels each), the
 // remaining factor of the 256 threads covers different rows; a workgroup owns a contiguous range of rows.
 // MODE 0: a = x - pivot,                s0 += a,  s1 += a * a
-// MODE 1: g = dy (0 where y <= 0), xh = (x - mean) * rstd,   s0 += g,  s1 += g * xh
+// MODE 1: g = dy (0 where the fused ReLU stored a zero), xh = (x - mean) * rstd,   s0 += g,  s1 += g * xh
 template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                          const T* __restrict__ y, int64_t n, int c,
+                                                          const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                          int64_t n, int c,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           float* __restrict__ partial) {
   __shared__ float s_red[2][256 * VEC];
@@ -56,20 +67,23 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
   const int64_t r1 = (r0 + rows_per_block < n) ? (r0 + rows_per_block) : n;
   for (int g0 = 0; g0 < cgroups; g0 += lanes_c) {
     const int ch0 = (g0 + cc) * VEC;
-    float s0[VEC], s1[VEC], a[VEC], b[VEC];
+    float s0[VEC], s1[VEC], a[VEC], b[VEC], sc[VEC], sh[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; a[v] = 0.f; b[v] = 1.f; }
+    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; a[v] = 0.f; b[v] = 1.f; sc[v] = 0.f; sh[v] = 0.f; }
     const bool mine = rr < rsteps && g0 + cc < cgroups;
     if (mine) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         if (ch0 + v < c) {
           if (MODE == 0) a[v] = NCvt<T>::ld(x[ch0 + v]);  // pivot: row 0
-          else { a[v] = mean[ch0 + v]; b[v] = rstd[ch0 + v]; }
+          else {
+            a[v] = mean[ch0 + v]; b[v] = rstd[ch0 + v];
+            if (rscale) { sc[v] = rscale[ch0 + v]; sh[v] = rshift[ch0 + v]; }
+          }
         }
       }
       for (int64_t r = r0 + rr; r < r1; r += (int64_t)rsteps * kNormRowsInFlight) {
-        NVec<T, VEC> xv[kNormRowsInFlight], gv[kNormRowsInFlight], yv[kNormRowsInFlight];
+        NVec<T, VEC> xv[kNormRowsInFlight], gv[kNormRowsInFlight];
         // clamped addresses: the loads of all rows in flight are issued before the first one is used
 #pragma unroll
         for (int q = 0; q < kNormRowsInFlight; ++q) {
@@ -77,16 +91,10 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
           const int64_t at = (rq < r1 ? rq : r1 - 1) * c + ch0;
           if (VEC > 1) {
             xv[q] = *reinterpret_cast<const NVec<T, VEC>*>(x + at);
-            if (MODE == 1) {
-              gv[q] = *reinterpret_cast<const NVec<T, VEC>*>(dy + at);
-              if (y) yv[q] = *reinterpret_cast<const NVec<T, VEC>*>(y + at);
-            }
+            if (MODE == 1) gv[q] = *reinterpret_cast<const NVec<T, VEC>*>(dy + at);
           } else {
             xv[q].v[0] = x[at];
-            if (MODE == 1) {
-              gv[q].v[0] = dy[at];
-              if (y) yv[q].v[0] = y[at];
-            }
+            if (MODE == 1) gv[q].v[0] = dy[at];
           }
         }
 #pragma unroll
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
               s1[v] += d * d;
             } else {
               float g = NCvt<T>::ld(gv[q].v[v]);
-              if (y && !(NCvt<T>::ld(yv[q].v[v]) > 0.f)) g = 0.f;
+              if (rscale && !bn_relu_passes<T>(xf, sc[v], sh[v])) g = 0.f;
               s0[v] += g;
               s1[v] += g * ((xf - a[v]) * b[v]);
             }
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
     NVec<T, VEC> yv;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      float f = NCvt<T>::ld(xv.v[v]) * s_coef[ch0 + v] + s_coef[c + ch0 + v];
+      float f = bn_affine(NCvt<T>::ld(xv.v[v]), s_coef[ch0 + v], s_coef[c + ch0 + v]);
       if (relu) f = fmaxf(f, 0.f);
       yv.v[v] = NCvt<T>::st(f);
     }
@@ -232,12 +240,13 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
 // dx = gamma * rstd * (g - sum_dy / n - xhat * sum_dy_xhat / n) = A[c] * g + B[c] * x + C[c]
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                             const T* __restrict__ y, int64_t n, int c,
+                                                             const float* __restrict__ rscale,
+                                                             const float* __restrict__ rshift, int64_t n, int c,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ sum_dy,
                                                              const float* __restrict__ sum_dy_xhat, T* __restrict__ dx) {
-  extern __shared__ float s_coef[];  // [3][c]: A, B, C
+  extern __shared__ float s_coef[];  // [5][c]: A, B, C, and scale / shift of the forward pass (ReLU mask)
   const float inv_n = 1.0f / (float)n;
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     const float r = rstd[i], w = (gamma ? gamma[i] : 1.0f) * r;
@@ -245,6 +254,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     s_coef[i] = w;
     s_coef[c + i] = -w * k1;
     s_coef[2 * c + i] = w * (mean[i] * k1 - sum_dy[i] * inv_n);
+    s_coef[3 * c + i] = rscale ? rscale[i] : 0.f;
+    s_coef[4 * c + i] = rscale ? rshift[i] : 0.f;
   }
   __syncthreads();
   const int cv = c / VEC;
@@ -253,14 +264,14 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     const int ch0 = (int)(e % cv) * VEC;
     const NVec<T, VEC> gv = *reinterpret_cast<const NVec<T, VEC>*>(dy + e * VEC);
     const NVec<T, VEC> xv = *reinterpret_cast<const NVec<T, VEC>*>(x + e * VEC);
-    NVec<T, VEC> yv, ov;
-    if (y) yv = *reinterpret_cast<const NVec<T, VEC>*>(y + e * VEC);
+    NVec<T, VEC> ov;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const int ch = ch0 + v;
+      const float xf = NCvt<T>::ld(xv.v[v]);
       float g = NCvt<T>::ld(gv.v[v]);
-      if (y && !(NCvt<T>::ld(yv.v[v]) > 0.f)) g = 0.f;
-      ov.v[v] = NCvt<T>::st(s_coef[ch] * g + s_coef[c + ch] * NCvt<T>::ld(xv.v[v]) + s_coef[2 * c + ch]);
+      if (rscale && !bn_relu_passes<T>(xf, s_coef[3 * c + ch], s_coef[4 * c + ch])) g = 0.f;
+      ov.v[v] = NCvt<T>::st(s_coef[ch] * g + s_coef[c + ch] * xf + s_coef[2 * c + ch]);
     }
     *reinterpret_cast<NVec<T, VEC>*>(dx + e * VEC) = ov;
   }
@@ -272,7 +283,8 @@ static inline unsigned norm_grid(int64_t items) {  // grid-stride: a few workgro
 }
 
 template <typename T>
-static int bn_reduce_t(int mode, const void* x, const void* dy, const void* y, int64_t n, int c, const float* mean,
+static int bn_reduce_t(int mode, const void* x, const void* dy, const float* rscale, const float* rshift, int64_t n, int c,
+                       const float* mean,
                        const float* rstd, float* out0, float* out1, float* partial, hipStream_t s,
                        const BnFold& fold = BnFold()) {
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -280,7 +292,7 @@ static int bn_reduce_t(int mode, const void* x, const void* dy, const void* y, i
   const bool vec = c % VEC == 0;
 #define WCN_NR(V, M)                                                                                                  \
   hipLaunchKernelGGL((norm_reduce_kernel<T, V, M>), dim3(nblocks), dim3(256), 0, s, (const T*)x, (const T*)dy,          \
-                     (const T*)y, n, c, mean, rstd, partial)
+                     rscale, rshift, n, c, mean, rstd, partial)
   if (mode == 0) { if (vec) WCN_NR(VEC, 0); else WCN_NR(1, 0); }
   else { if (vec) WCN_NR(VEC, 1); else WCN_NR(1, 1); }
 #undef WCN_NR
@@ -307,16 +319,17 @@ static int bn_apply_t(const void* x, int64_t n, int c, const float* scale, const
 }
 
 template <typename T>
-static int bn_bwd_apply_t(const void* dy, const void* x, const void* y, int64_t n, int c, const float* mean,
+static int bn_bwd_apply_t(const void* dy, const void* x, const float* rscale, const float* rshift, int64_t n, int c,
+                          const float* mean,
                           const float* rstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat, void* dx,
                           hipStream_t s) {
   constexpr int VEC = 16 / (int)sizeof(T);
   if (c % VEC == 0)
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC>), dim3(norm_grid(n * (c / VEC))), dim3(256), (size_t)3 * c * 4, s,
-                       (const T*)dy, (const T*)x, (const T*)y, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC>), dim3(norm_grid(n * (c / VEC))), dim3(256), (size_t)5 * c * 4, s,
+                       (const T*)dy, (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx);
   else
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(norm_grid(n * c)), dim3(256), (size_t)3 * c * 4, s, (const T*)dy,
-                       (const T*)x, (const T*)y, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(norm_grid(n * c)), dim3(256), (size_t)5 * c * 4, s, (const T*)dy,
+                       (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx);
   return launch_status();
 }
 
@@ -338,9 +351,9 @@ int wcn_bn_stats(const void* x, int64_t n, int32_t channels, int32_t dtype, floa
   hipStream_t s = (hipStream_t)stream;
   float* p = (float*)workspace;
   switch (dtype) {
-    case WCN_F32: return bn_reduce_t<float>(0, x, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s);
-    case WCN_F16: return bn_reduce_t<__half>(0, x, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s);
-    default: return bn_reduce_t<__hip_bfloat16>(0, x, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s);
+    case WCN_F32: return bn_reduce_t<float>(0, x, nullptr, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s);
+    case WCN_F16: return bn_reduce_t<__half>(0, x, nullptr, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s);
+    default: return bn_reduce_t<__hip_bfloat16>(0, x, nullptr, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s);
   }
 }
 
@@ -358,9 +371,9 @@ int wcn_bn_stats_fold(const void* x, int64_t n, int32_t channels, int32_t dtype,
   hipStream_t s = (hipStream_t)stream;
   float* p = (float*)workspace;
   switch (dtype) {
-    case WCN_F32: return bn_reduce_t<float>(0, x, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s, f);
-    case WCN_F16: return bn_reduce_t<__half>(0, x, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s, f);
-    default: return bn_reduce_t<__hip_bfloat16>(0, x, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s, f);
+    case WCN_F32: return bn_reduce_t<float>(0, x, nullptr, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s, f);
+    case WCN_F16: return bn_reduce_t<__half>(0, x, nullptr, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s, f);
+    default: return bn_reduce_t<__hip_bfloat16>(0, x, nullptr, nullptr, nullptr, n, channels, nullptr, nullptr, mean, var, p, s, f);
   }
 }
 
@@ -387,33 +400,37 @@ int wcn_bn_apply(const void* x, int64_t n, int32_t channels, int32_t dtype, cons
   }
 }
 
-int wcn_bn_backward_reduce(const void* dy, const void* x, const void* y, int64_t n, int32_t channels, int32_t dtype,
-                           const float* mean, const float* rstd, float* sum_dy, float* sum_dy_xhat, void* workspace,
-                           size_t workspace_bytes, wcn_stream_t stream) {
+int wcn_bn_backward_reduce(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
+                           int32_t channels, int32_t dtype, const float* mean, const float* rstd, float* sum_dy,
+                           float* sum_dy_xhat, void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
   if (n < 1 || channels < 1 || !bn_dtype_ok(dtype) || !dy || !x || !mean || !rstd || !sum_dy || !sum_dy_xhat ||
-      !workspace || workspace_bytes < wcn_bn_workspace(channels))
+      !workspace || workspace_bytes < wcn_bn_workspace(channels) || ((relu_scale == nullptr) != (relu_shift == nullptr)))
     return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
   float* p = (float*)workspace;
   switch (dtype) {
-    case WCN_F32: return bn_reduce_t<float>(1, x, dy, y, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
-    case WCN_F16: return bn_reduce_t<__half>(1, x, dy, y, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
-    default: return bn_reduce_t<__hip_bfloat16>(1, x, dy, y, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
+    case WCN_F32: return bn_reduce_t<float>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
+    case WCN_F16: return bn_reduce_t<__half>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
+    default:
+      return bn_reduce_t<__hip_bfloat16>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
   }
 }
 
-int wcn_bn_backward_apply(const void* dy, const void* x, const void* y, int64_t n, int32_t channels, int32_t dtype,
-                          const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
-                          const float* sum_dy_xhat, void* dx, wcn_stream_t stream) {
-  if (n < 0 || channels < 1 || !bn_dtype_ok(dtype)) return WCN_ERROR_INVALID_PARAMETERS;
+int wcn_bn_backward_apply(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
+                          int32_t channels, int32_t dtype, const float* mean, const float* rstd, const float* gamma,
+                          const float* sum_dy, const float* sum_dy_xhat, void* dx, wcn_stream_t stream) {
+  if (n < 0 || channels < 1 || !bn_dtype_ok(dtype) || ((relu_scale == nullptr) != (relu_shift == nullptr)))
+    return WCN_ERROR_INVALID_PARAMETERS;
   if (n == 0) return WCN_SUCCESS;
   if (!dy || !x || !dx || !mean || !rstd || !sum_dy || !sum_dy_xhat) return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case WCN_F32: return bn_bwd_apply_t<float>(dy, x, y, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
-    case WCN_F16: return bn_bwd_apply_t<__half>(dy, x, y, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
+    case WCN_F32:
+      return bn_bwd_apply_t<float>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
+    case WCN_F16:
+      return bn_bwd_apply_t<__half>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
     default:
-      return bn_bwd_apply_t<__hip_bfloat16>(dy, x, y, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
+      return bn_bwd_apply_t<__hip_bfloat16>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
   }
 }
 

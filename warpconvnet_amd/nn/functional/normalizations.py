@@ -89,7 +89,8 @@ class _HipBatchNorm(Function):
                 "wcn_bn_fold",
             )
         y = _apply(x, scale, shift, relu)
-        ctx.save_for_backward(x, y if relu else None, mean, rstd, gamma)
+        # (the ReLU mask is recomputed from x and scale / shift in the backward passes: the output is not saved for it)
+        ctx.save_for_backward(x, stats, gamma)
         ctx.training, ctx.relu, ctx.has_bias = training, relu, bias is not None
         ctx.wdtype = weight.dtype if weight is not None else None
         ctx.bdtype = bias.dtype if bias is not None else None
@@ -97,7 +98,9 @@ class _HipBatchNorm(Function):
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
-        x, y, mean, rstd, gamma = ctx.saved_tensors
+        x, stats, gamma = ctx.saved_tensors
+        mean, rstd = stats[0], stats[1]
+        rsc, rsh = (stats[2], stats[3]) if ctx.relu else (None, None)
         n, c = x.shape
         dev = x.device
         L = _lib.lib()
@@ -108,7 +111,7 @@ class _HipBatchNorm(Function):
         sum_dy, sum_dy_xhat = sums[0], sums[1]
         ws = _workspace(c, dev)
         _lib.check(
-            L.wcn_bn_backward_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), n, c, _lib.dtype_code(x.dtype), _lib.ptr(mean),
+            L.wcn_bn_backward_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(rsc), _lib.ptr(rsh), n, c, _lib.dtype_code(x.dtype), _lib.ptr(mean),
                                      _lib.ptr(rstd), _lib.ptr(sum_dy), _lib.ptr(sum_dy_xhat), _lib.ptr(ws), ws.numel(),
                                      _lib.stream_handle(dev)),
             "wcn_bn_backward_reduce",
@@ -121,7 +124,7 @@ class _HipBatchNorm(Function):
             else:  # eval: the statistics are constants, dx = gamma * rstd * g
                 s0 = s1 = torch.zeros(c, dtype=torch.float32, device=dev)
             _lib.check(
-                L.wcn_bn_backward_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), n, c, _lib.dtype_code(x.dtype), _lib.ptr(mean),
+                L.wcn_bn_backward_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(rsc), _lib.ptr(rsh), n, c, _lib.dtype_code(x.dtype), _lib.ptr(mean),
                                         _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(s0), _lib.ptr(s1), _lib.ptr(dx),
                                         _lib.stream_handle(dev)),
                 "wcn_bn_backward_apply",

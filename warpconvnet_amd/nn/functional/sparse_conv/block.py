@@ -70,8 +70,7 @@ def _bn_forward(plan: _Plan, y: Tensor, gamma: Optional[Tensor], beta: Optional[
     return out, stats
 
 
-def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, out: Optional[Tensor], stats: Tensor, gamma: Optional[Tensor],
-                 need_dy: bool):
+def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, stats: Tensor, gamma: Optional[Tensor], need_dy: bool):
     """-> (gradient of the convolution's output or None, sums [2, C] = sum_dy (bias gradient), sum_dy_xhat (weight gradient))"""
     L = _lib.lib()
     dev = y.device
@@ -83,11 +82,13 @@ def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, out: Optional[Tensor]
     sums = torch.empty((2, cout), dtype=torch.float32, device=dev)
     s0 = stats.data_ptr()
     mean, rstd = s0, s0 + 4 * cout
+    # fused ReLU: the mask comes from y (the convolution's output) and the scale / shift the forward applied to it
+    rsc, rsh = (s0 + 8 * cout, s0 + 12 * cout) if plan.relu else (None, None)
     sum_dy, sum_dy_xhat = sums.data_ptr(), sums.data_ptr() + 4 * cout
     ws = _bn_workspace(cout, dev)
-    gp, yp, op = _lib.ptr(g), _lib.ptr(y), _lib.ptr(out)
-    _lib.check(L.wcn_bn_backward_reduce(gp, yp, op, M, cout, code, mean, rstd, sum_dy, sum_dy_xhat, _lib.ptr(ws), ws.numel(),
-                                        stream), "wcn_bn_backward_reduce")
+    gp, yp = _lib.ptr(g), _lib.ptr(y)
+    _lib.check(L.wcn_bn_backward_reduce(gp, yp, rsc, rsh, M, cout, code, mean, rstd, sum_dy, sum_dy_xhat, _lib.ptr(ws),
+                                        ws.numel(), stream), "wcn_bn_backward_reduce")
     if not need_dy:
         return None, sums
     dyc = torch.empty_like(y)
@@ -96,8 +97,8 @@ def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, out: Optional[Tensor]
     else:  # eval: the statistics are constants
         zeros = torch.zeros(cout, dtype=torch.float32, device=dev)
         a0 = a1 = zeros.data_ptr()
-    _lib.check(L.wcn_bn_backward_apply(gp, yp, op, M, cout, code, mean, rstd, _lib.ptr(gamma), a0, a1, _lib.ptr(dyc), stream),
-               "wcn_bn_backward_apply")
+    _lib.check(L.wcn_bn_backward_apply(gp, yp, rsc, rsh, M, cout, code, mean, rstd, _lib.ptr(gamma), a0, a1, _lib.ptr(dyc),
+                                       stream), "wcn_bn_backward_apply")
     return dyc, sums
 
 
@@ -132,7 +133,7 @@ class _ConvBnAct(Function):
         if km.validate():  # an optimistic map whose build the device rejected: rebuilt - repeat on the new tables
             launch()
         out, stats = _bn_forward(plan, y, gamma, beta)
-        ctx.save_for_backward(x, w, y, out if plan.relu else None, stats, gamma)
+        ctx.save_for_backward(x, w, y, stats, gamma)
         ctx.plan = plan
         ctx.gdtype = gamma.dtype if gamma is not None else None
         ctx.bdtype = beta.dtype if beta is not None else None
@@ -140,14 +141,14 @@ class _ConvBnAct(Function):
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
-        x, w, y, out, stats, gamma = ctx.saved_tensors
+        x, w, y, stats, gamma = ctx.saved_tensors
         plan = ctx.plan
         km, M, cin, cout, K, code = plan.km, plan.num_out, plan.cin, plan.cout, plan.K, plan.code
         L = _lib.lib()
         dev = y.device
         stream = _lib.stream_handle(dev)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dyc, sums = _bn_backward(plan, grad_out, y, out, stats, gamma, need_dx or need_dw)
+        dyc, sums = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw)
         dx = dw = None
         if need_dx:
             if km._has_duplicates:  # (repeated coordinates: the general path's pair-list formulation)
@@ -190,7 +191,7 @@ class _PointwiseBnAct(Function):
         w16 = w[0] if w.dtype == x.dtype else w[0].to(x.dtype)
         y = x @ w16
         out, stats = _bn_forward(plan, y, gamma, beta)
-        ctx.save_for_backward(x, w16, y, out if plan.relu else None, stats, gamma)
+        ctx.save_for_backward(x, w16, y, stats, gamma)
         ctx.plan, ctx.wdtype = plan, w.dtype
         ctx.gdtype = gamma.dtype if gamma is not None else None
         ctx.bdtype = beta.dtype if beta is not None else None
@@ -200,10 +201,10 @@ class _PointwiseBnAct(Function):
     def backward(ctx, grad_out: Tensor):
         from .pointwise import dense_wgrad
 
-        x, w16, y, out, stats, gamma = ctx.saved_tensors
+        x, w16, y, stats, gamma = ctx.saved_tensors
         plan = ctx.plan
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dyc, sums = _bn_backward(plan, grad_out, y, out, stats, gamma, need_dx or need_dw)
+        dyc, sums = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw)
         dx = dw = None
         if need_dx:
             dx = dyc @ w16.t()
