@@ -103,6 +103,46 @@ def traffic(fetch_db, write_db):
     print(json.dumps(out, indent=1))
 
 
+def roofline(trace_db, fetch_db, write_db, sq_db=None):
+    """Per kernel INSTANCE (template instantiation) of a whole workload: time from the kernel trace, HBM bytes from two separate
+    --pmc passes (FETCH_SIZE x 2 on gfx950, WRITE_SIZE; KiB), achieved HBM GB/s = bytes / time, fraction of 8 TB/s, and -
+    with an SQ pass - the share of wave-cycles parked in s_waitcnt / barriers."""
+    def per_kernel(path, counter):
+        db = sqlite3.connect(path)
+        agg = {}
+        for k, v in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            a = agg.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += v
+        return agg
+    t = sqlite3.connect(trace_db)
+    times = {}
+    for name, dur in t.execute("select name, (end - start) from kernels"):
+        a = times.setdefault(name, [0, 0, 0])
+        a[0] += 1
+        a[1] += dur
+        a[2] = max(a[2], dur)
+    fetch, write = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    parked = {}
+    if sq_db:
+        wc, wa = per_kernel(sq_db, "SQ_WAVE_CYCLES"), per_kernel(sq_db, "SQ_WAIT_ANY")
+        parked = {k: wa[k][1] / wc[k][1] for k in wc if k in wa and wc[k][1] > 0}
+    total = sum(a[1] for a in times.values())
+    print(f"# per-kernel-instance HBM roofline ({trace_db}; FETCH_SIZE x 2 + WRITE_SIZE from separate PMC passes)\n")
+    print(f"total kernel time {total / 1e6:.3f} ms over {sum(a[0] for a in times.values())} dispatches\n")
+    print("| kernel instance | calls | total ms | % of kernels | avg us | max us | HBM MB / call | GB/s | frac of 8 TB/s | parked |")
+    print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+    for name, (n, tt, hi) in sorted(times.items(), key=lambda kv: -kv[1][1]):
+        if tt / total < 0.004:
+            continue
+        f, w = fetch.get(name), write.get(name)
+        kib = (2.0 * f[1] / f[0] if f else 0.0) + (w[1] / w[0] if w else 0.0)
+        gbs = kib * 1024 / (tt / n) if tt else 0.0  # bytes per ns = GB/s
+        pk = f"{parked[name]:.2f}" if name in parked else ""
+        print(f"| `{short(name)}` | {n} | {tt / 1e6:.3f} | {100 * tt / total:.1f} | {tt / n / 1e3:.1f} | {hi / 1e3:.1f} | "
+              f"{kib / 1024:.1f} | {gbs:.0f} | {gbs / 8000:.3f} | {pk} |")
+
+
 def mfma(db):
     """Matrix-core utilisation per kernel from a `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES` pass:
     MFMA busy cycles (summed over SIMDs) / (4 SIMDs x CU busy cycles)."""
@@ -156,6 +196,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "mfma":
         mfma(sys.argv[1])
+        sys.exit(0)
+    if len(sys.argv) > 4 and sys.argv[1] == "roofline":
+        roofline(*sys.argv[2:6])
         sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3])

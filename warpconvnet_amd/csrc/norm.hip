@@ -156,11 +156,21 @@ __global__ __launch_bounds__(64) void norm_final_kernel(const float* __restrict_
                                                         const T* __restrict__ x, float* __restrict__ out0,
                                                         float* __restrict__ out1, const BnFold f) {
   const int ch = blockIdx.x, lane = threadIdx.x;
-  float t0 = 0.f, t1 = 0.f;
-  for (int b = lane; b < nblocks; b += 64) {
-    t0 += partial[((int64_t)b * 2 + 0) * c + ch];
-    t1 += partial[((int64_t)b * 2 + 1) * c + ch];
+  // all of a lane's partial sums requested before the first add (16 + 16 strided loads: issued one after the other they
+  // were 16 L2 round trips, 8-9 us for a kernel that moves a few KB), summed in the same fixed order
+  constexpr int kPer = kNormBlocks / 64;
+  float v0[kPer], v1[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const int b = lane + 64 * q;
+    const int bb = b < nblocks ? b : 0;
+    v0[q] = partial[((int64_t)bb * 2 + 0) * c + ch];
+    v1[q] = partial[((int64_t)bb * 2 + 1) * c + ch];
   }
+  float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q)
+    if (lane + 64 * q < nblocks) { t0 += v0[q]; t1 += v1[q]; }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     t0 += __shfl_down(t0, d);
@@ -288,7 +298,9 @@ static int bn_reduce_t(int mode, const void* x, const void* dy, const float* rsc
                        const float* rstd, float* out0, float* out1, float* partial, hipStream_t s,
                        const BnFold& fold = BnFold()) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  const int nblocks = (int)(n < kNormBlocks ? (n < 1 ? 1 : n) : kNormBlocks);
+  // first-level workgroups: at least 128 rows each (small tensors: fewer partial sums for the second level), 1 024 at most
+  int64_t nb = ceil_div(n < 1 ? 1 : n, 128);
+  const int nblocks = (int)(nb < kNormBlocks ? nb : kNormBlocks);
   const bool vec = c % VEC == 0;
 #define WCN_NR(V, M)                                                                                                  \
   hipLaunchKernelGGL((norm_reduce_kernel<T, V, M>), dim3(nblocks), dim3(256), 0, s, (const T*)x, (const T*)dy,          \
