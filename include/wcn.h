@@ -248,6 +248,11 @@ enum wcn_algo { WCN_ALGO_AUTO = 0, WCN_ALGO_REF = 1, WCN_ALGO_MFMA = 2 };
 /* 1 if the MFMA kernels cover the shape (so the caller can resolve "auto" without a trial launch). */
 int wcn_mfma_gather_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype);
 int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype);
+/* 1 x 1 x 1 convolutions (reference shortcut helper.py:206-213: feats @ weight[0]): wcn_conv_gather_gemm with num_offsets = 1
+ * and nbr = mask = perm = NULL treats every row as its own only neighbour - the dense [N, cin] x [cin, cout] product streamed
+ * through the gather kernel at its HBM rate (the vendor GEMM runs these skinny shapes at 0.15-0.33 of it,
+ * profiles/r04_unet_1M_roofline.md).  Shapes: cin % 32 == 0, cin >= 64, cout in {64, 96, 128}, f16 / bf16. */
+int wcn_conv_identity_supported(int32_t cin, int32_t cout, int32_t dtype);
 
 /* Packed weight image consumed by the MFMA kernels (fragment order, zero padding).  `transpose`=1
  * packs w[k]^T (dgrad); `flip`=1 additionally reverses k (dgrad of a submanifold map reuses the

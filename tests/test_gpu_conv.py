@@ -605,8 +605,39 @@ def test_generative_convolution_module(transposed, ksize, stride):
     assert rel_max_err(X.grad, dXr) < 1e-3 and rel_max_err(conv.weight.grad, dWr) < 1e-3
 
 
+@pytest.mark.parametrize("n", [1, 127, 70001])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (96, 128), (128, 96), (256, 128), (160, 64)])
+def test_dense_rows_through_the_identity_map(cin, cout, dtype, n):
+    """wcn_conv_gather_gemm with nbr = mask = NULL and one offset (include/wcn.h: wcn_conv_identity_supported) is the dense
+    product of a 1 x 1 x 1 convolution: x @ w and dy @ w.T vs fp64 on the same 16-bit values, within one rounding of the
+    output type (fp32 accumulation); shapes outside the kernel's return None (the caller keeps the vendor GEMM)."""
+    from warpconvnet_amd.nn.functional.sparse_conv.pointwise import dense_rows
+
+    dev = _dev()
+    torch.manual_seed(n + cin)
+    w = torch.randn(1, cin, cout, device=dev) / cin ** 0.5
+    x = torch.randn(n, cin, device=dev).to(dtype)
+    dy = torch.randn(n, cout, device=dev).to(dtype)
+    bias = torch.randn(cout, device=dev)
+    wq = w[0].to(dtype).double().cpu()
+    y = dense_rows(x, w, False, bias)
+    assert y is not None and y.dtype == dtype and y.shape == (n, cout)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    want = x.double().cpu() @ wq + bias.double().cpu()
+    assert float((y.double().cpu() - want).abs().max()) <= eps * float(want.abs().max()) + 1e-6
+    dx = dense_rows(dy, w, True)
+    if cin in (64, 96, 128) and cout >= 64:
+        want = dy.double().cpu() @ wq.t()
+        assert dx is not None and float((dx.double().cpu() - want).abs().max()) <= eps * float(want.abs().max()) + 1e-6
+    else:
+        assert dx is None
+    assert dense_rows(x[:, :48].contiguous(), w[:, :48].contiguous(), False) is None  # cin < 64: not this kernel's
+    assert dense_rows(x.float(), w, False) is None
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
-@pytest.mark.parametrize("cin,cout", [(96, 20), (32, 64), (3, 16), (256, 256)])
+@pytest.mark.parametrize("cin,cout", [(96, 20), (32, 64), (3, 16), (256, 256), (96, 64), (128, 128), (256, 96)])
 def test_pointwise_conv_gradients(cin, cout, dtype):
     """kernel_size = 1: forward / dX dense products, dW through the sparse AtB kernel with the identity pair list
     (channel counts outside the MFMA tiles zero-padded), bias gradient by column sum - vs fp64 on the same values."""

@@ -11,6 +11,7 @@ int conv_wgrad_ref(const void* x, const void* dy, float* dw, const int32_t* in_m
                    const int32_t* offsets, int cin, int cout, int K, int dtype, hipStream_t s);
 // conv_mfma.hip
 bool mfma_gather_supported(int cin, int cout, int K, int dtype);
+bool gather_gemm_cs_supported(int cin, int cout, int K, int dtype);  // conv_mfma_cs.hip
 int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
                           const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, int dtype,
                           float* out32, hipStream_t s);
@@ -59,6 +60,9 @@ extern "C" {
 int wcn_mfma_gather_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype) {
   return mfma_gather_supported(cin, cout, num_offsets, dtype) ? 1 : 0;
 }
+int wcn_conv_identity_supported(int32_t cin, int32_t cout, int32_t dtype) {
+  return gather_gemm_cs_supported(cin, cout, 1, dtype) ? 1 : 0;
+}
 int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype) {
   return mfma_wgrad_supported(cin, cout, dtype) ? 1 : 0;
 }
@@ -91,14 +95,18 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
   if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || !dtype_ok(dtype))
     return WCN_ERROR_INVALID_PARAMETERS;
   if (n_out == 0) return WCN_SUCCESS;
-  if (!w || !out || !nbr || (n_in > 0 && !in)) return WCN_ERROR_INVALID_PARAMETERS;
+  // nbr == mask == NULL with one offset: the identity map (row r pairs with row r) - the dense product of a 1 x 1 x 1
+  // convolution streamed through the channel-split gather kernel (shapes of wcn_conv_identity_supported)
+  const bool identity = !nbr && !mask && !perm && num_offsets == 1 && algo == WCN_ALGO_MFMA && n_in == n_out &&
+                        gather_gemm_cs_supported(cin, cout, 1, dtype);
+  if (!w || !out || (!nbr && !identity) || (n_in > 0 && !in)) return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
   switch (algo) {
     case WCN_ALGO_REF:
       return conv_gather_gemm_ref(in, w, out, nbr, bias, n_out, cin, cout, num_offsets, dtype, w_transposed, k_flip, s);
     case WCN_ALGO_MFMA:
       // `w` must be the packed image (wcn_pack_weight already applied transpose / flip)
-      if (!mask) return WCN_ERROR_INVALID_PARAMETERS;
+      if (!mask && !identity) return WCN_ERROR_INVALID_PARAMETERS;
       {
         ConvEpilogue epi;
         epi.bias = bias;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     uint32_t my_mask = 0;
     if (tid < TILE) {
       const int32_t r = s_rows[tid];
-      if (r >= 0) my_mask = mask[r];
+      if (r >= 0) my_mask = mask ? mask[r] : 1u;  // (no table: the identity map of a 1 x 1 x 1 kernel, see below)
       s_mask[tid] = my_mask;
       if (my_mask) atomicOr(&s_wmask[tid >> 5], my_mask);
     }
@@ -201,8 +201,12 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       vv[t] = make_int4(-1, -1, -1, -1);
       if (rr[t] >= 0 && c * 4 < kp) {  // read once: non-temporal
         typedef __attribute__((ext_vector_type(4))) int i32x4;
-        const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * kp) + c);
-        vv[t] = make_int4(q.x, q.y, q.z, q.w);
+        if (nbr) {
+          const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * kp) + c);
+          vv[t] = make_int4(q.x, q.y, q.z, q.w);
+        } else if (c == 0) {
+          vv[t].x = rr[t];  // nbr == null (K = 1): every row is its own only neighbour - a dense [N, cin] x [cin, cout] product
+        }
       }
     }
 #pragma unroll

@@ -188,8 +188,13 @@ class _PointwiseBnAct(Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], plan: _Plan) -> Tensor:
+        from .pointwise import dense_rows
+
         w16 = w[0] if w.dtype == x.dtype else w[0].to(x.dtype)
-        y = x @ w16
+        y = dense_rows(x, w, False)
+        if y is None:
+            y = x @ w16
+        ctx.w3 = w
         out, stats = _bn_forward(plan, y, gamma, beta)
         ctx.save_for_backward(x, w16, y, stats, gamma)
         ctx.plan, ctx.wdtype = plan, w.dtype
@@ -207,7 +212,11 @@ class _PointwiseBnAct(Function):
         dyc, sums = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw)
         dx = dw = None
         if need_dx:
-            dx = dyc @ w16.t()
+            from .pointwise import dense_rows
+
+            dx = dense_rows(dyc, ctx.w3, True)
+            if dx is None:
+                dx = dyc @ w16.t()
         if need_dw:
             dw = dense_wgrad(x, dyc).unsqueeze(0)
             if dw.dtype != ctx.wdtype:

@@ -189,8 +189,8 @@ def spatially_sparse_conv(
         from warpconvnet_amd.nn.functional.sparse_conv.pointwise import pointwise_conv
 
         feats = input_sparse_tensor.feature_tensor
-        if weight.ndim == 3:  # forward / dX: dense products; dW through the sparse AtB kernel (pointwise.py)
-            out = pointwise_conv(feats, weight[0], bias)
+        if weight.ndim == 3:  # forward / dX: dense products (streaming gather kernel where the shape allows); dW: sparse AtB kernel
+            out = pointwise_conv(feats, weight, bias)
         else:
             out = feats @ weight[0].to(feats.dtype)
             if bias is not None:

@@ -8,6 +8,8 @@ the AtB problem of the sparse path with the identity pair list, so it goes throu
 ranges + ordered slab reduction, deterministic): ~15 us.  Channel counts outside the MFMA tiles are zero-padded to the
 next multiple of 32 for that one product.
 """
+import functools
+import os
 from typing import Optional
 
 import torch
@@ -54,13 +56,57 @@ def dense_wgrad(x: Tensor, dy: Tensor) -> Tensor:
     return dw[0, :cin, :cout]
 
 
+@functools.lru_cache(maxsize=None)
+def _identity_ok(cin: int, cout: int, code: int) -> bool:
+    # WARPCONVNET_AMD_POINTWISE_GATHER=0: keep the vendor GEMM for every 1 x 1 x 1 product (A/B switch, tools/ab_unet.sh)
+    if os.environ.get("WARPCONVNET_AMD_POINTWISE_GATHER", "1") == "0":
+        return False
+    return bool(_lib.lib().wcn_conv_identity_supported(cin, cout, code))
+
+
+def dense_rows(x: Tensor, weight3: Tensor, transposed: bool, bias: Optional[Tensor] = None) -> Optional[Tensor]:
+    """``x @ weight3[0]`` (``transposed``: ``x @ weight3[0].T``) for 16-bit ``[N, C]`` GPU rows through the channel-split gather
+    kernel with the identity map - a streaming kernel at its HBM rate where the vendor GEMM serves these skinny shapes at
+    0.15-0.33 of it.  ``weight3`` is the convolution's ``[1, Cin, Cout]`` weight (its packed image is cached per parameter
+    version like every other layer's).  None when the shape is not one of the kernel's."""
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    _, cin, cout = weight3.shape
+    kin, kout = (cout, cin) if transposed else (cin, cout)
+    if (not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16) or x.shape[0] == 0 or x.shape[1] != kin
+            or not _identity_ok(kin, kout, _lib.dtype_code(x.dtype))):
+        return None
+    x = x.contiguous()
+    wp = hip_gemm.pack_weight(weight3, transposed, False, dtype=x.dtype)
+    n = x.shape[0]
+    out = torch.empty((n, kout), dtype=x.dtype, device=x.device)
+    if bias is not None:
+        bias = bias.detach().float().contiguous()
+    _lib.check(
+        _lib.lib().wcn_conv_gather_gemm(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(out), None, None, None, _lib.ptr(bias), n, n, kin, kout, 1,
+                                        _lib.dtype_code(x.dtype), _lib.WCN_ALGO_MFMA, int(transposed), 0,
+                                        _lib.stream_handle(x.device)),
+        "wcn_conv_gather_gemm",
+    )
+    return out
+
+
 class _PointwiseConv(Function):
     @staticmethod
     def forward(ctx, feats: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
-        w = weight if weight.dtype == feats.dtype else weight.to(feats.dtype)
+        """``weight``: ``[Cin, Cout]``, or the convolution's own ``[1, Cin, Cout]`` parameter (then the products take the
+        streaming kernel of `dense_rows` where the shape allows)."""
+        w3 = weight if weight.ndim == 3 else None
+        w2 = weight[0] if w3 is not None else weight
+        w = w2 if w2.dtype == feats.dtype else w2.to(feats.dtype)
+        ctx.w3 = w3
         ctx.save_for_backward(feats, w)
         ctx.weight_dtype, ctx.has_bias = weight.dtype, bias is not None
         ctx.bias_dtype = bias.dtype if bias is not None else None
+        if w3 is not None:
+            out = dense_rows(feats, w3, False, bias)
+            if out is not None:
+                return out
         out = feats @ w
         return out if bias is None else out + bias.to(out.dtype)
 
@@ -70,12 +116,16 @@ class _PointwiseConv(Function):
         dy = grad_out.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = dy @ w.t()
+            dx = dense_rows(dy, ctx.w3, True) if ctx.w3 is not None else None
+            if dx is None:
+                dx = dy @ w.t()
         if ctx.needs_input_grad[1]:
             if (dy.is_cuda and dy.dtype in (torch.float16, torch.bfloat16) and feats.dtype == dy.dtype and feats.shape[0] > 0):
                 dw = dense_wgrad(feats.contiguous(), dy).to(ctx.weight_dtype)
             else:
                 dw = (feats.t() @ dy).to(ctx.weight_dtype)
+            if ctx.w3 is not None:
+                dw = dw.unsqueeze(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if dy.is_cuda and dy.shape[0] > 0 and dy.dtype in (torch.float32, torch.float16, torch.bfloat16):
                 from warpconvnet_amd.nn.functional.sparse_conv.detail.hip_gemm import hip_colsum
