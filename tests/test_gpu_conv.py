@@ -63,8 +63,11 @@ def test_golden_vectors_fp32(golden_dir, name, algo):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (32, 32), (16, 32), (96, 96), (64, 256), (256, 64), (128, 128)])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (32, 32), (16, 32), (96, 96), (64, 256), (256, 64), (128, 128),
+                                      (256, 256), (192, 128), (96, 320), (128, 384)])
 def test_mfma_vs_oracle_submanifold(dtype, cin, cout):
+    """(outputs wider than 128 channels run as 128 / 96 / 64-wide column blocks of the channel-split kernel: 256 = 2 x 128,
+    192 = 2 x 96 (the dgrad of 192 -> 128), 320 = 5 x 64, 384 = 3 x 128)"""
     s = np.concatenate([scene_u(3000, 21, 0), scene_u(1500, 22, 1)], 0)
     km = _kmap(s, s, (3, 3, 3), same=True)
     r = okmap.kernel_map(s, s, (3, 3, 3))
@@ -157,8 +160,9 @@ def test_duplicate_rows_all_three_gemms_vs_oracle(dtype, method, monkeypatch):
     assert len(losers) > 0 and float(dX[torch.from_numpy(losers).to(dev)].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cout", [128, 256])
 @pytest.mark.parametrize("scale", [1.0, 3.0e5])
-def test_fp32_features_take_fp16_operand_kernels(scale):
+def test_fp32_features_take_fp16_operand_kernels(scale, cout):
     """fp32 features under `auto`: fp16 operands (exact power-of-two rescale beyond the fp16 range), fp32 accumulation and
     output - the reference's production treatment (mask_gemm.py:72-103); tolerance of its fp32 tests (1e-3).
     grad_output at 3e5 is the GradScaler case the reference documents: finite in, finite out."""
@@ -170,8 +174,8 @@ def test_fp32_features_take_fp16_operand_kernels(scale):
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(9)
     X = (torch.randn(len(s), 64, generator=g) * scale).to(dev)
-    W = (torch.randn(27, 64, 128, generator=g) * 0.05).to(dev)
-    dY = (torch.randn(len(s), 128, generator=g) * scale).to(dev)
+    W = (torch.randn(27, 64, cout, generator=g) * 0.05).to(dev)
+    dY = (torch.randn(len(s), cout, generator=g) * scale).to(dev)
     Y, dX, dW = _run_all(km, X, W, dY, "auto", len(s), len(s))
     assert Y.dtype == torch.float32 and dX.dtype == torch.float32 and dW.dtype == torch.float32
     assert torch.isfinite(Y).all() and torch.isfinite(dX).all() and torch.isfinite(dW).all()
@@ -607,7 +611,7 @@ def test_generative_convolution_module(transposed, ksize, stride):
 
 @pytest.mark.parametrize("n", [1, 127, 70001])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cin,cout", [(64, 64), (96, 128), (128, 96), (256, 128), (160, 64)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (96, 128), (128, 96), (256, 128), (160, 64), (128, 256), (192, 192), (64, 80)])
 def test_dense_rows_through_the_identity_map(cin, cout, dtype, n):
     """wcn_conv_gather_gemm with nbr = mask = NULL and one offset (include/wcn.h: wcn_conv_identity_supported) is the dense
     product of a 1 x 1 x 1 convolution: x @ w and dy @ w.T vs fp64 on the same 16-bit values, within one rounding of the
@@ -621,13 +625,19 @@ def test_dense_rows_through_the_identity_map(cin, cout, dtype, n):
     dy = torch.randn(n, cout, device=dev).to(dtype)
     bias = torch.randn(cout, device=dev)
     wq = w[0].to(dtype).double().cpu()
-    y = dense_rows(x, w, False, bias)
-    assert y is not None and y.dtype == dtype and y.shape == (n, cout)
+    from warpconvnet_amd import _lib
+
+    code = _lib.dtype_code(dtype)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
-    want = x.double().cpu() @ wq + bias.double().cpu()
-    assert float((y.double().cpu() - want).abs().max()) <= eps * float(want.abs().max()) + 1e-6
+    y = dense_rows(x, w, False, bias)
+    if _lib.lib().wcn_conv_identity_supported(cin, cout, code):  # cout: 64 / 96 / 128, or wider in blocks of those
+        assert cout != 80 and y is not None and y.dtype == dtype and y.shape == (n, cout)
+        want = x.double().cpu() @ wq + bias.double().cpu()
+        assert float((y.double().cpu() - want).abs().max()) <= eps * float(want.abs().max()) + 1e-6
+    else:
+        assert cout == 80 and y is None
     dx = dense_rows(dy, w, True)
-    if cin in (64, 96, 128) and cout >= 64:
+    if _lib.lib().wcn_conv_identity_supported(cout, cin, code):
         want = dy.double().cpu() @ wq.t()
         assert dx is not None and float((dx.double().cpu() - want).abs().max()) <= eps * float(want.abs().max()) + 1e-6
     else:

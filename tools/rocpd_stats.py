@@ -36,6 +36,43 @@ def main(path):
 
 
 
+def gaps(path, tail_frac=0.5, top=40):
+    """Idle time of the GPU between consecutive kernels over the last ``tail_frac`` of the trace (steady state): total, and the
+    largest gaps with the kernels on either side - where a host-bound stretch or a host read of device state stalls the queue."""
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    rows = rows[int(len(rows) * (1 - tail_frac)):]
+    busy = sum(e - s for _, s, e in rows)
+    span = rows[-1][2] - rows[0][1]
+    print(f"# GPU idle gaps ({path}; last {len(rows)} dispatches)\n")
+    print(f"span {span / 1e6:.3f} ms, kernels {busy / 1e6:.3f} ms, idle {(span - busy) / 1e6:.3f} ms ({100 * (span - busy) / span:.1f} %)\n")
+    g = []
+    last_end = rows[0][2]
+    for i in range(1, len(rows)):
+        gap = rows[i][1] - last_end
+        if gap > 0:
+            g.append((gap, i))
+        last_end = max(last_end, rows[i][2])
+    hist = {}
+    for gap, i in g:
+        b = "<5us" if gap < 5e3 else "5-20us" if gap < 2e4 else "20-100us" if gap < 1e5 else ">100us"
+        h = hist.setdefault(b, [0, 0])
+        h[0] += 1
+        h[1] += gap
+    for b in ("<5us", "5-20us", "20-100us", ">100us"):
+        if b in hist:
+            print(f"- gaps {b}: {hist[b][0]} totalling {hist[b][1] / 1e6:.3f} ms")
+    after = {}
+    for gap, i in g:
+        a = after.setdefault(short(rows[i][0])[:90], [0, 0])
+        a[0] += 1
+        a[1] += gap
+    print("\n| kernel AFTER the gap | gaps | total idle ms | avg us |")
+    print("|---|---:|---:|---:|")
+    for k, (n, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:top]:
+        print(f"| `{k}` | {n} | {t / 1e6:.3f} | {t / n / 1e3:.1f} |")
+
+
 def pmc(path):
     """Per-kernel average of every collected counter (``--pmc`` runs)."""
     db = sqlite3.connect(path)
@@ -202,6 +239,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3])
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "gaps":
+        gaps(sys.argv[1])
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "pmc":
         pmc(sys.argv[1])

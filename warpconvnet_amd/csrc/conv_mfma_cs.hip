@@ -89,14 +89,17 @@ struct CsCfg {
 //   ci = chunk*64 + 16*s + 8*h + j                      (the K index of the MFMA: natural channel order)
 //   co = cs*32 + 16*((m >> 2) & 1) + 4*(m >> 3) + (m & 3)
 // so that the C fragment of lane (h', n) holds output channels cs*32 + 16*h' + reg, reg = 0..15, of row n.
+// Outputs wider than 128 channels: `cout / cob` images of `cob` channels behind each other (column block on grid.y of the
+// main kernel), each the image of w[:, :, cb * cob : (cb + 1) * cob].
 template <typename TS, typename TD>
-__global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__ packed, int K, int cin, int cout,
+__global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__ packed, int K, int cin, int cout, int cob,
                                       int transpose, int flip) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int WC = cout / 32, nchunk = (cin + kCsCIC - 1) / kCsCIC;  // a last chunk of 32 channels is zero-padded to 64
-  const int64_t total = (int64_t)K * nchunk * kCsCIC * cout;
-  if (e >= total) return;
-  int64_t t = e;
+  const int WC = cob / 32, nchunk = (cin + kCsCIC - 1) / kCsCIC;  // a last chunk of 32 channels is zero-padded to 64
+  const int64_t image = (int64_t)K * nchunk * kCsCIC * cob;
+  if (e >= image * (cout / cob)) return;
+  const int cb = (int)(e / image);
+  int64_t t = e - cb * image;
   const int j = (int)(t % 8); t /= 8;
   const int lane = (int)(t % 64); t /= 64;
   const int s = (int)(t % 4); t /= 4;
@@ -105,7 +108,7 @@ __global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__
   const int k = (int)t;
   const int h = lane >> 5, m = lane & 31;
   const int ci = chunk * kCsCIC + 16 * s + 8 * h + j;
-  const int co = cs * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+  const int co = cb * cob + cs * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
   const int kw = flip ? (K - 1 - k) : k;
   // not transposed: w[kw][ci][co] ([K, cin, cout]); transposed: w is the forward weight [K, cout, cin]
   const int64_t src = transpose ? (((int64_t)kw * cout + co) * cin + ci) : (((int64_t)kw * cin + ci) * cout + co);
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
                                                                 const uint32_t* __restrict__ mask,
                                                                 const int32_t* __restrict__ perm, const ConvEpilogue epi,
                                                                 int64_t n_out, int cin, int K, int kp,
-                                                                float* __restrict__ out32) {
+                                                                float* __restrict__ out32, int ldc) {
+  // ldc: channels of an output (and residual) row; blockIdx.y: the CO-wide column block of it this workgroup produces
   typedef CsCfg<CO, RBW_, WR_> G;
   typedef typename CFrag<T>::type frag_t;
   constexpr int WC = G::WC, RBW = G::RBW, SP = kCsSlabPitch, TILE = G::TILE, NT = G::NT;
@@ -150,6 +154,8 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   const int nchunk = (cin + kCsCIC - 1) / kCsCIC;
   const int last_pieces = (cin - (nchunk - 1) * kCsCIC) / 8;  // 16-B pieces of the last chunk that exist (8, or 4 when cin % 64 == 32)
   const int64_t row0 = (int64_t)blockIdx.x * TILE;
+  const int col0 = blockIdx.y * CO;  // first output channel of this column block
+  wp += (size_t)blockIdx.y * ((size_t)K * nchunk * kCsCIC * CO);
 #ifdef WCN_PROF
   const bool cs_prof = tid == 0 && (blockIdx.x & 3) == 0 && (blockIdx.x >> 2) < 2048;
   unsigned long long pt0 = CS_CLK(), pt1 = 0, pt2 = 0, pa = 0, pw = 0, pi = 0, pc = 0, pn = 0;
@@ -171,9 +177,9 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   }
   // per-channel epilogue terms: requested first, used last (their latency is off the critical path)
   for (int c = tid; c < CO; c += NT) {
-    s_epi[c] = epi.bias ? epi.bias[c] : 0.f;
-    s_epi[CO + c] = epi.scale ? epi.scale[c] : 1.f;
-    s_epi[2 * CO + c] = epi.scale ? epi.shift[c] : 0.f;
+    s_epi[c] = epi.bias ? epi.bias[col0 + c] : 0.f;
+    s_epi[CO + c] = epi.scale ? epi.scale[col0 + c] : 1.f;
+    s_epi[2 * CO + c] = epi.scale ? epi.shift[col0 + c] : 0.f;
   }
   __syncthreads();
   {
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     for (int rb = 0; rb < RBW; ++rb) {
       const int32_t r = s_rows[(rg * RBW + rb) * 32 + n];
       if (r < 0) continue;
-      float* dst = out32 + (int64_t)r * CO + cbase;
+      float* dst = out32 + (int64_t)r * ldc + col0 + cbase;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const float4 bv = reinterpret_cast<const float4*>(s_epi + cbase)[v];
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
         for (int j = 0; j < kBatch; ++j)
           if (orow[j] >= 0)
             rv[j] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(
-                reinterpret_cast<const T*>(epi.residual) + (int64_t)orow[j] * CO + piece * 8));
+                reinterpret_cast<const T*>(epi.residual) + (int64_t)orow[j] * ldc + col0 + piece * 8));
       }
 #pragma unroll
       for (int j = 0; j < kBatch; ++j)
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
           }
         }
         // streamed once: non-temporal, so the output does not push the gathered input out of the caches
-        __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * CO + piece * 8));
+        __builtin_nontemporal_store(o, reinterpret_cast<frag_t*>(out + (int64_t)orow[j] * ldc + col0 + piece * 8));
       }
     }
   }
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
 
 template <typename T, int CO, int RBW, int WR, int MINW>
 static int launch_cs(const void* in, const void* wp, void* out, const int32_t* nbr, const uint32_t* mask,
-                     const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int K, float* out32,
+                     const int32_t* perm, const ConvEpilogue& epi, int64_t n_out, int cin, int cout, int K, float* out32,
                      hipStream_t s) {
   typedef CsCfg<CO, RBW, WR> G;
   static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
@@ -451,8 +457,9 @@ static int launch_cs(const void* in, const void* wp, void* out, const int32_t* n
   });
   if (rc != WCN_SUCCESS) return rc;
   const int kp = wcn_kmap_row_pitch(K);
-  hipLaunchKernelGGL((gather_gemm_cs_kernel<T, CO, RBW, WR, MINW>), dim3((unsigned)ceil_div(n_out, G::TILE)), dim3(G::NT),
-                     G::LDS_BYTES, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp, out32);
+  hipLaunchKernelGGL((gather_gemm_cs_kernel<T, CO, RBW, WR, MINW>), dim3((unsigned)ceil_div(n_out, G::TILE), (unsigned)(cout / CO)),
+                     dim3(G::NT), G::LDS_BYTES, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp,
+                     out32, cout);
   return launch_status();
 }
 
@@ -465,12 +472,21 @@ static int cs_mode() {
   return v;
 }
 
+// Width of the column blocks an output of `cout` channels is produced in (0: not this family's).  Up to 128 channels: one
+// block; wider: the widest of 128 / 96 / 64 that divides it (256 = 2 x 128, 192 = 2 x 96, 320 = 5 x 64) - the rows are gathered
+// once per block, which the coarse levels of a U-Net (a few thousand rows, 192 - 512 channels) repay with 2 - 4 x the workgroups.
+static int cs_col_block(int cout) {
+  if (cout <= 128) return (cout == 64 || cout == 96 || cout == 128) ? cout : 0;
+  if (cout > 1024) return 0;
+  return cout % 128 == 0 ? 128 : cout % 96 == 0 ? 96 : cout % 64 == 0 ? 64 : 0;
+}
+
 bool gather_gemm_cs_supported(int cin, int cout, int K, int dtype) {
   if (cs_mode() == 0) return false;
   if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
   if (K < 1 || K > kCsMaxK) return false;
   if (cin < kCsCIC || cin % 32 != 0) return false;  // (a last chunk of 32 channels runs zero-padded)
-  return cout == 64 || cout == 96 || cout == 128;
+  return cs_col_block(cout) != 0;
 }
 
 template <typename T>
@@ -480,10 +496,10 @@ static int dispatch_cs(const void* in, const void* wp, void* out, const int32_t*
   // Measured on the 1 M-voxel scenes (uniform / surface, in-step us): CO = 128 with 128-row tiles 208 / 251 vs 64-row tiles
   // 238 / 272 (twice the weight traffic per row); CO = 64 with 2 waves x 64 rows 256 / 374 vs 4 waves x 128 rows 264 / 378
   // vs 2 waves x 128 rows 275 / 392.
-  switch (cout) {
-    case 64: return launch_cs<T, 64, 2, 1, 4>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
-    case 96: return launch_cs<T, 96, 3, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);  // 3 waves x 96 rows
-    case 128: return launch_cs<T, 128, 4, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, K, out32, s);
+  switch (cs_col_block(cout)) {
+    case 64: return launch_cs<T, 64, 2, 1, 4>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+    case 96: return launch_cs<T, 96, 3, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);  // 3 waves x 96 rows
+    case 128: return launch_cs<T, 128, 4, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
@@ -501,16 +517,17 @@ int pack_weight_cs(const void* w, int w_is_f32, int K, int cin, int cout, int dt
   if (!gather_gemm_cs_supported(cin, cout, K, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   const int64_t total = (int64_t)K * ((cin + kCsCIC - 1) / kCsCIC) * kCsCIC * cout;  // = wcn_packed_weight_elements
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  const int cob = cs_col_block(cout);
   if (w_is_f32) {
     if (dtype == WCN_BF16)
       hipLaunchKernelGGL((pack_weight_cs_kernel<float, __bf16>), grid, block, 0, s, (const float*)w, (__bf16*)packed, K, cin,
-                         cout, transpose, flip);
+                         cout, cob, transpose, flip);
     else
       hipLaunchKernelGGL((pack_weight_cs_kernel<float, _Float16>), grid, block, 0, s, (const float*)w, (_Float16*)packed, K,
-                         cin, cout, transpose, flip);
+                         cin, cout, cob, transpose, flip);
   } else {
     hipLaunchKernelGGL((pack_weight_cs_kernel<uint16_t, uint16_t>), grid, block, 0, s, (const uint16_t*)w, (uint16_t*)packed,
-                       K, cin, cout, transpose, flip);
+                       K, cin, cout, cob, transpose, flip);
   }
   return launch_status();
 }
