@@ -496,6 +496,21 @@ int wcn_bn_backward_reduce(const void* dy, const void* x, const float* relu_scal
 int wcn_bn_backward_apply(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
                           int32_t channels, int32_t dtype, const float* mean, const float* rstd, const float* gamma,
                           const float* sum_dy, const float* sum_dy_xhat, void* dx, wcn_stream_t stream);
+/* The tail of a residual block, z = ReLU(BN(x) + r) - the reference runs it as three passes over the feature tensor
+ * (`models/mink_unet.py:160-172`: conv2's BatchNorm, `out += identity`, `relu(out)`).  Here it rides on the two BatchNorm passes:
+ *   wcn_bn_apply_residual          y = [ReLU](round(x * scale + shift) + residual), every intermediate rounded to the storage
+ *                                  type as the three modules would (bit-identical to them).
+ *   wcn_bn_backward_reduce_masked  as wcn_bn_backward_reduce with g = dy where the stored output z is positive, else 0.
+ *   wcn_bn_backward_apply_masked   as wcn_bn_backward_apply with that mask; `dres` (may be NULL) also receives g itself -
+ *                                  the gradient of the residual branch. */
+int wcn_bn_apply_residual(const void* x, const void* residual, int64_t n, int32_t channels, int32_t dtype, const float* scale,
+                          const float* shift, int32_t relu, void* y, wcn_stream_t stream);
+int wcn_bn_backward_reduce_masked(const void* dy, const void* x, const void* z, int64_t n, int32_t channels, int32_t dtype,
+                                  const float* mean, const float* rstd, float* sum_dy, float* sum_dy_xhat, void* workspace,
+                                  size_t workspace_bytes, wcn_stream_t stream);
+int wcn_bn_backward_apply_masked(const void* dy, const void* x, const void* z, int64_t n, int32_t channels, int32_t dtype,
+                                 const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
+                                 const float* sum_dy_xhat, void* dx, void* dres, wcn_stream_t stream);
 
 #ifdef __cplusplus
 }

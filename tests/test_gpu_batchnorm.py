@@ -160,3 +160,94 @@ def test_fused_conv_bn_relu_block_equals_the_module_chain(cin, cout, ksize, stri
         for u, v in zip(a[:-1], b[:-1]):
             assert torch.equal(u, v)
         assert a[-1] == b[-1]
+
+
+@pytest.mark.parametrize("cin,cout,block", [(64, 64, "BasicBlock"), (96, 128, "BasicBlock"), (128, 128, "BottleneckBlock")])
+def test_residual_tail_equals_the_module_chain(cin, cout, block):
+    """`models.mink_unet.BasicBlock`: conv2's BatchNorm, `out += identity` and the ReLU (reference `mink_unet.py:160-172`) ride
+    on the fused node's two BatchNorm passes (`wcn_bn_apply_residual`, `wcn_bn_backward_*_masked`).  With hooks on conv2 the same
+    block runs its modules one by one: outputs, every gradient (input - both branches meet there -, weights, BatchNorm
+    parameters) and the running statistics are bit-identical, in training and in eval mode.  (A bottleneck's last convolution is
+    1 x 1 x 1: it keeps the module chain, the test pins that it still computes the same.)"""
+    import copy
+
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.models import mink_unet
+    from warpconvnet_amd.nn.functional.sparse_conv import block as blk
+
+    dev = torch.device("cuda:0")
+    c = scene_u(7000, 72)[:, 1:]
+    torch.manual_seed(1)
+    fused = getattr(mink_unet, block)(cin, cout).to(dev)
+    chain = copy.deepcopy(fused)
+    last = chain.conv2 if block == "BasicBlock" else chain.conv3
+    last[0].register_forward_hook(lambda m, i, o: None)  # hooks present -> conv2 / add / ReLU as separate modules
+    feats = torch.randn(len(c), cin, device=dev)
+    with_res = []
+    real = blk._ConvBnAct.apply
+    blk._ConvBnAct.apply = staticmethod(lambda *a: (with_res.append(len(a) > 5 and a[5] is not None), real(*a))[1])
+    try:
+        res = []
+        for net in (fused, chain):
+            for mode in ("train", "eval"):
+                net.train(mode == "train")
+                x = Voxels([torch.from_numpy(c)], [feats], device=dev)
+                x = x.replace(batched_features=x.feature_tensor.detach().clone().requires_grad_(True))
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = net(x)
+                g = torch.randn(y.feature_tensor.shape, device=dev, generator=torch.Generator(dev).manual_seed(5)).to(y.feature_tensor.dtype)
+                net.zero_grad(set_to_none=True)
+                y.feature_tensor.backward(g)
+                out = [y.feature_tensor.detach().clone(), x.batched_features.batched_tensor.grad.clone()]
+                out += [p.grad.clone() for p in net.parameters()]
+                out += [b.clone() for b in net.buffers()]
+                res.append(out)
+    finally:
+        blk._ConvBnAct.apply = real
+    assert sum(with_res) == (2 if block == "BasicBlock" else 0), "the hook-free BasicBlock takes the residual tail (train + eval)"
+    assert (res[0][0] >= 0).all() and float(res[0][0].float().abs().max()) > 0
+    for a, b in zip(res[:2], res[2:]):
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+
+
+def test_minkunet14_module_matches_its_module_by_module_run():
+    """`models.mink_unet.MinkUNet14` end to end (stem, four stride-2 stages, transposed stages onto the encoder tensors,
+    concatenations, 1 x 1 x 1 head): the fused blocks against WARPCONVNET_AMD_FUSED_BLOCK=0 on the same weights - same logits and
+    the same gradients bit for bit; activation checkpointing leaves values and BatchNorm statistics unchanged."""
+    import copy
+    import os
+
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.models.mink_unet import MinkUNet14
+
+    dev = torch.device("cuda:0")
+    c = scene_u(30000, 73)[:, 1:]
+    torch.manual_seed(2)
+    net = MinkUNet14(3, 20).to(dev)
+    feats = torch.randn(len(c), 3, device=dev)
+
+    def run(model):
+        x = Voxels([torch.from_numpy(c)], [feats], device=dev)
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(x)
+        y.feature_tensor.float().square().mean().backward()
+        return ([y.feature_tensor.detach().clone()] + [p.grad.clone() for p in model.parameters()],
+                [b.clone() for b in model.buffers()])
+
+    a, abuf = run(copy.deepcopy(net))
+    os.environ["WARPCONVNET_AMD_FUSED_BLOCK"] = "0"
+    try:
+        b, bbuf = run(copy.deepcopy(net))
+    finally:
+        del os.environ["WARPCONVNET_AMD_FUSED_BLOCK"]
+    assert a[0].shape == (len(c), 20)
+    for u, v in zip(a + abuf, b + bbuf):
+        assert torch.equal(u, v)
+    ck = copy.deepcopy(net)
+    ck.gradient_checkpointing_enable()
+    cgrads, cbuf = run(ck)
+    for u, v in zip(a + abuf, cgrads + cbuf):
+        assert torch.equal(u, v)

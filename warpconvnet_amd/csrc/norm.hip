@@ -11,6 +11,10 @@
 //   wcn_bn_backward_reduce  sum_dy[c], sum_dy_xhat[c] with dy masked where the fused ReLU stored a zero; the mask is
 //                           recomputed from x and the forward's scale / shift (bn_affine), the output y is not read again.
 //   wcn_bn_backward_apply   dx = gamma * rstd * (dy - sum_dy / N - xhat * sum_dy_xhat / N).
+//   wcn_bn_apply_residual / wcn_bn_backward_{reduce,apply}_masked   the tail of a residual block, z = ReLU(BN(x) + r)
+//                           (reference models/mink_unet.py:160-172: `out += identity; out = relu(out)`), in the same two
+//                           passes: the forward adds r while it applies, the backward masks with the stored z and also
+//                           writes the masked gradient (the residual branch's share).
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
@@ -55,7 +59,8 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
                                                           const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                           int64_t n, int c,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial, const T* __restrict__ zmask) {
+  // zmask (MODE 1, instead of rscale / rshift): the stored output of ReLU(BN(x) + residual); g = dy where it is positive
   __shared__ float s_red[2][256 * VEC];
   const int tid = threadIdx.x;
   const int cgroups = (c + VEC - 1) / VEC;
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
         }
       }
       for (int64_t r = r0 + rr; r < r1; r += (int64_t)rsteps * kNormRowsInFlight) {
-        NVec<T, VEC> xv[kNormRowsInFlight], gv[kNormRowsInFlight];
+        NVec<T, VEC> xv[kNormRowsInFlight], gv[kNormRowsInFlight], zv[kNormRowsInFlight];
         // clamped addresses: the loads of all rows in flight are issued before the first one is used
 #pragma unroll
         for (int q = 0; q < kNormRowsInFlight; ++q) {
@@ -92,9 +97,11 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
           if (VEC > 1) {
             xv[q] = *reinterpret_cast<const NVec<T, VEC>*>(x + at);
             if (MODE == 1) gv[q] = *reinterpret_cast<const NVec<T, VEC>*>(dy + at);
+            if (MODE == 1 && zmask) zv[q] = *reinterpret_cast<const NVec<T, VEC>*>(zmask + at);
           } else {
             xv[q].v[0] = x[at];
             if (MODE == 1) gv[q].v[0] = dy[at];
+            if (MODE == 1 && zmask) zv[q].v[0] = zmask[at];
           }
         }
 #pragma unroll
@@ -109,7 +116,8 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
               s1[v] += d * d;
             } else {
               float g = NCvt<T>::ld(gv[q].v[v]);
-              if (rscale && !bn_relu_passes<T>(xf, sc[v], sh[v])) g = 0.f;
+              if (zmask) { if (!(NCvt<T>::ld(zv[q].v[v]) > 0.f)) g = 0.f; }
+              else if (rscale && !bn_relu_passes<T>(xf, sc[v], sh[v])) g = 0.f;
               s0[v] += g;
               s1[v] += g * ((xf - a[v]) * b[v]);
             }
@@ -224,7 +232,8 @@ __global__ void norm_fold_kernel(const float* __restrict__ mean_in, const float*
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, int64_t n, int c,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int relu, T* __restrict__ y) {
+                                                         int relu, T* __restrict__ y, const T* __restrict__ res) {
+  // res: y = [ReLU](round(x * scale + shift) + res) - the roundings of BatchNorm -> add -> ReLU run as three modules
   extern __shared__ float s_coef[];  // [2][c]: scale, shift
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     s_coef[i] = scale[i];
@@ -236,10 +245,12 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int ch0 = (int)(e % cv) * VEC;
     const NVec<T, VEC> xv = *reinterpret_cast<const NVec<T, VEC>*>(x + e * VEC);
-    NVec<T, VEC> yv;
+    NVec<T, VEC> yv, rv;
+    if (res) rv = *reinterpret_cast<const NVec<T, VEC>*>(res + e * VEC);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       float f = bn_affine(NCvt<T>::ld(xv.v[v]), s_coef[ch0 + v], s_coef[c + ch0 + v]);
+      if (res) f = NCvt<T>::ld(NCvt<T>::st(NCvt<T>::ld(NCvt<T>::st(f)) + NCvt<T>::ld(rv.v[v])));
       if (relu) f = fmaxf(f, 0.f);
       yv.v[v] = NCvt<T>::st(f);
     }
@@ -255,7 +266,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ sum_dy,
-                                                             const float* __restrict__ sum_dy_xhat, T* __restrict__ dx) {
+                                                             const float* __restrict__ sum_dy_xhat, T* __restrict__ dx,
+                                                             const T* __restrict__ zmask, T* __restrict__ dres) {
+  // zmask / dres: residual tail - the mask is the stored output's sign, the masked gradient is also the residual branch's
   extern __shared__ float s_coef[];  // [5][c]: A, B, C, and scale / shift of the forward pass (ReLU mask)
   const float inv_n = 1.0f / (float)n;
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
@@ -274,16 +287,20 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     const int ch0 = (int)(e % cv) * VEC;
     const NVec<T, VEC> gv = *reinterpret_cast<const NVec<T, VEC>*>(dy + e * VEC);
     const NVec<T, VEC> xv = *reinterpret_cast<const NVec<T, VEC>*>(x + e * VEC);
-    NVec<T, VEC> ov;
+    NVec<T, VEC> ov, zv, mv;
+    if (zmask) zv = *reinterpret_cast<const NVec<T, VEC>*>(zmask + e * VEC);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const int ch = ch0 + v;
       const float xf = NCvt<T>::ld(xv.v[v]);
       float g = NCvt<T>::ld(gv.v[v]);
-      if (rscale && !bn_relu_passes<T>(xf, s_coef[3 * c + ch], s_coef[4 * c + ch])) g = 0.f;
+      if (zmask) { if (!(NCvt<T>::ld(zv.v[v]) > 0.f)) g = 0.f; }
+      else if (rscale && !bn_relu_passes<T>(xf, s_coef[3 * c + ch], s_coef[4 * c + ch])) g = 0.f;
+      mv.v[v] = NCvt<T>::st(g);
       ov.v[v] = NCvt<T>::st(s_coef[ch] * g + s_coef[c + ch] * xf + s_coef[2 * c + ch]);
     }
     *reinterpret_cast<NVec<T, VEC>*>(dx + e * VEC) = ov;
+    if (dres) *reinterpret_cast<NVec<T, VEC>*>(dres + e * VEC) = mv;
   }
 }
 
@@ -296,7 +313,7 @@ template <typename T>
 static int bn_reduce_t(int mode, const void* x, const void* dy, const float* rscale, const float* rshift, int64_t n, int c,
                        const float* mean,
                        const float* rstd, float* out0, float* out1, float* partial, hipStream_t s,
-                       const BnFold& fold = BnFold()) {
+                       const BnFold& fold = BnFold(), const void* zmask = nullptr) {
   constexpr int VEC = 16 / (int)sizeof(T);
   // first-level workgroups: at least 128 rows each (small tensors: fewer partial sums for the second level), 1 024 at most
   int64_t nb = ceil_div(n < 1 ? 1 : n, 128);
@@ -304,7 +321,7 @@ static int bn_reduce_t(int mode, const void* x, const void* dy, const float* rsc
   const bool vec = c % VEC == 0;
 #define WCN_NR(V, M)                                                                                                  \
   hipLaunchKernelGGL((norm_reduce_kernel<T, V, M>), dim3(nblocks), dim3(256), 0, s, (const T*)x, (const T*)dy,          \
-                     rscale, rshift, n, c, mean, rstd, partial)
+                     rscale, rshift, n, c, mean, rstd, partial, (const T*)zmask)
   if (mode == 0) { if (vec) WCN_NR(VEC, 0); else WCN_NR(1, 0); }
   else { if (vec) WCN_NR(VEC, 1); else WCN_NR(1, 1); }
 #undef WCN_NR
@@ -319,14 +336,14 @@ static int bn_reduce_t(int mode, const void* x, const void* dy, const float* rsc
 
 template <typename T>
 static int bn_apply_t(const void* x, int64_t n, int c, const float* scale, const float* shift, int relu, void* y,
-                      hipStream_t s) {
+                      hipStream_t s, const void* res = nullptr) {
   constexpr int VEC = 16 / (int)sizeof(T);
   if (c % VEC == 0)
     hipLaunchKernelGGL((norm_apply_kernel<T, VEC>), dim3(norm_grid(n * (c / VEC))), dim3(256), (size_t)2 * c * 4, s,
-                       (const T*)x, n, c, scale, shift, relu, (T*)y);
+                       (const T*)x, n, c, scale, shift, relu, (T*)y, (const T*)res);
   else
     hipLaunchKernelGGL((norm_apply_kernel<T, 1>), dim3(norm_grid(n * c)), dim3(256), (size_t)2 * c * 4, s, (const T*)x, n, c,
-                       scale, shift, relu, (T*)y);
+                       scale, shift, relu, (T*)y, (const T*)res);
   return launch_status();
 }
 
@@ -334,14 +351,16 @@ template <typename T>
 static int bn_bwd_apply_t(const void* dy, const void* x, const float* rscale, const float* rshift, int64_t n, int c,
                           const float* mean,
                           const float* rstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat, void* dx,
-                          hipStream_t s) {
+                          hipStream_t s, const void* zmask = nullptr, void* dres = nullptr) {
   constexpr int VEC = 16 / (int)sizeof(T);
   if (c % VEC == 0)
     hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC>), dim3(norm_grid(n * (c / VEC))), dim3(256), (size_t)5 * c * 4, s,
-                       (const T*)dy, (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx);
+                       (const T*)dy, (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx,
+                       (const T*)zmask, (T*)dres);
   else
     hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(norm_grid(n * c)), dim3(256), (size_t)5 * c * 4, s, (const T*)dy,
-                       (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx);
+                       (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx, (const T*)zmask,
+                       (T*)dres);
   return launch_status();
 }
 
@@ -443,6 +462,56 @@ int wcn_bn_backward_apply(const void* dy, const void* x, const float* relu_scale
       return bn_bwd_apply_t<__half>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
     default:
       return bn_bwd_apply_t<__hip_bfloat16>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
+  }
+}
+
+// ---- residual tail: z = [ReLU](BN(x) + residual), reference models/mink_unet.py:160-172 ----
+
+int wcn_bn_apply_residual(const void* x, const void* residual, int64_t n, int32_t channels, int32_t dtype, const float* scale,
+                          const float* shift, int32_t relu, void* y, wcn_stream_t stream) {
+  if (n < 0 || channels < 1 || !bn_dtype_ok(dtype)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n == 0) return WCN_SUCCESS;
+  if (!x || !residual || !y || !scale || !shift) return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case WCN_F32: return bn_apply_t<float>(x, n, channels, scale, shift, relu, y, s, residual);
+    case WCN_F16: return bn_apply_t<__half>(x, n, channels, scale, shift, relu, y, s, residual);
+    default: return bn_apply_t<__hip_bfloat16>(x, n, channels, scale, shift, relu, y, s, residual);
+  }
+}
+
+int wcn_bn_backward_reduce_masked(const void* dy, const void* x, const void* z, int64_t n, int32_t channels, int32_t dtype,
+                                  const float* mean, const float* rstd, float* sum_dy, float* sum_dy_xhat, void* workspace,
+                                  size_t workspace_bytes, wcn_stream_t stream) {
+  if (n < 1 || channels < 1 || !bn_dtype_ok(dtype) || !dy || !x || !z || !mean || !rstd || !sum_dy || !sum_dy_xhat ||
+      !workspace || workspace_bytes < wcn_bn_workspace(channels))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  float* p = (float*)workspace;
+  const BnFold nf;
+  switch (dtype) {
+    case WCN_F32: return bn_reduce_t<float>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z);
+    case WCN_F16: return bn_reduce_t<__half>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z);
+    default:
+      return bn_reduce_t<__hip_bfloat16>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z);
+  }
+}
+
+int wcn_bn_backward_apply_masked(const void* dy, const void* x, const void* z, int64_t n, int32_t channels, int32_t dtype,
+                                 const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
+                                 const float* sum_dy_xhat, void* dx, void* dres, wcn_stream_t stream) {
+  if (n < 0 || channels < 1 || !bn_dtype_ok(dtype)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n == 0) return WCN_SUCCESS;
+  if (!dy || !x || !z || !dx || !mean || !rstd || !sum_dy || !sum_dy_xhat) return WCN_ERROR_INVALID_PARAMETERS;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case WCN_F32:
+      return bn_bwd_apply_t<float>(dy, x, nullptr, nullptr, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, z, dres);
+    case WCN_F16:
+      return bn_bwd_apply_t<__half>(dy, x, nullptr, nullptr, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, z, dres);
+    default:
+      return bn_bwd_apply_t<__hip_bfloat16>(dy, x, nullptr, nullptr, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, z,
+                                            dres);
   }
 }
 

@@ -40,9 +40,9 @@ class _Plan:
                  "running_var", "counter", "fused_running")
 
 
-def _bn_forward(plan: _Plan, y: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor]):
-    """BatchNorm (+ ReLU) of the convolution's output ``y``: statistics + fold (training) or fold of the running statistics
-    (eval), then apply.  -> (out, stats [5, C] = mean, rstd, scale, shift, var)"""
+def _bn_forward(plan: _Plan, y: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], residual: Optional[Tensor] = None):
+    """BatchNorm (+ residual) (+ ReLU) of the convolution's output ``y``: statistics + fold (training) or fold of the running
+    statistics (eval), then apply.  -> (out, stats [5, C] = mean, rstd, scale, shift, var)"""
     L = _lib.lib()
     dev = y.device
     stream = _lib.stream_handle(dev)
@@ -66,12 +66,18 @@ def _bn_forward(plan: _Plan, y: Tensor, gamma: Optional[Tensor], beta: Optional[
         _lib.check(L.wcn_bn_fold(_lib.ptr(plan.running_mean), _lib.ptr(plan.running_var), gp, bp, plan.eps, cout, mean, rstd,
                                  scale, shift, stream), "wcn_bn_fold")
     out = torch.empty_like(y)
-    _lib.check(L.wcn_bn_apply(yp, M, cout, code, scale, shift, int(plan.relu), _lib.ptr(out), stream), "wcn_bn_apply")
+    if residual is not None:
+        _lib.check(L.wcn_bn_apply_residual(yp, _lib.ptr(residual), M, cout, code, scale, shift, int(plan.relu), _lib.ptr(out),
+                                           stream), "wcn_bn_apply_residual")
+    else:
+        _lib.check(L.wcn_bn_apply(yp, M, cout, code, scale, shift, int(plan.relu), _lib.ptr(out), stream), "wcn_bn_apply")
     return out, stats
 
 
-def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, stats: Tensor, gamma: Optional[Tensor], need_dy: bool):
-    """-> (gradient of the convolution's output or None, sums [2, C] = sum_dy (bias gradient), sum_dy_xhat (weight gradient))"""
+def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, stats: Tensor, gamma: Optional[Tensor], need_dy: bool,
+                 z: Optional[Tensor] = None, need_dres: bool = False):
+    """-> (gradient of the convolution's output or None, sums [2, C] = sum_dy (bias gradient), sum_dy_xhat (weight gradient),
+    gradient of the residual or None).  ``z``: the stored output of a residual tail ReLU(BN(y) + r) - the ReLU mask is its sign."""
     L = _lib.lib()
     dev = y.device
     stream = _lib.stream_handle(dev)
@@ -87,19 +93,33 @@ def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, stats: Tensor, gamma:
     sum_dy, sum_dy_xhat = sums.data_ptr(), sums.data_ptr() + 4 * cout
     ws = _bn_workspace(cout, dev)
     gp, yp = _lib.ptr(g), _lib.ptr(y)
-    _lib.check(L.wcn_bn_backward_reduce(gp, yp, rsc, rsh, M, cout, code, mean, rstd, sum_dy, sum_dy_xhat, _lib.ptr(ws),
-                                        ws.numel(), stream), "wcn_bn_backward_reduce")
-    if not need_dy:
-        return None, sums
+    masked = z is not None and plan.relu  # (BN(y) + r without activation: the gradient reaches both branches unmasked)
+    if masked:
+        zp = _lib.ptr(z)
+        _lib.check(L.wcn_bn_backward_reduce_masked(gp, yp, zp, M, cout, code, mean, rstd, sum_dy, sum_dy_xhat, _lib.ptr(ws),
+                                                   ws.numel(), stream), "wcn_bn_backward_reduce_masked")
+    else:
+        _lib.check(L.wcn_bn_backward_reduce(gp, yp, rsc, rsh, M, cout, code, mean, rstd, sum_dy, sum_dy_xhat, _lib.ptr(ws),
+                                            ws.numel(), stream), "wcn_bn_backward_reduce")
+    if not need_dy and not (masked and need_dres):
+        return None, sums, (g if need_dres else None)
     dyc = torch.empty_like(y)
     if plan.training:
         a0, a1 = sum_dy, sum_dy_xhat
     else:  # eval: the statistics are constants
         zeros = torch.zeros(cout, dtype=torch.float32, device=dev)
         a0 = a1 = zeros.data_ptr()
-    _lib.check(L.wcn_bn_backward_apply(gp, yp, rsc, rsh, M, cout, code, mean, rstd, _lib.ptr(gamma), a0, a1, _lib.ptr(dyc),
-                                       stream), "wcn_bn_backward_apply")
-    return dyc, sums
+    dres = None
+    if masked:
+        dres = torch.empty_like(y) if need_dres else None
+        _lib.check(L.wcn_bn_backward_apply_masked(gp, yp, zp, M, cout, code, mean, rstd, _lib.ptr(gamma), a0, a1, _lib.ptr(dyc),
+                                                  _lib.ptr(dres), stream), "wcn_bn_backward_apply_masked")
+    else:
+        _lib.check(L.wcn_bn_backward_apply(gp, yp, rsc, rsh, M, cout, code, mean, rstd, _lib.ptr(gamma), a0, a1, _lib.ptr(dyc),
+                                           stream), "wcn_bn_backward_apply")
+        if need_dres:
+            dres = g
+    return dyc, sums, dres
 
 
 def _affine_grads(ctx, sums: Tensor):
@@ -115,7 +135,8 @@ class _ConvBnAct(Function):
     """K > 1: gather GEMM on the kernel map."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, w: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], plan: _Plan) -> Tensor:
+    def forward(ctx, x: Tensor, w: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], plan: _Plan,
+                residual: Optional[Tensor] = None) -> Tensor:
         L = _lib.lib()
         dev = x.device
         stream = _lib.stream_handle(dev)
@@ -132,8 +153,12 @@ class _ConvBnAct(Function):
         launch()
         if km.validate():  # an optimistic map whose build the device rejected: rebuilt - repeat on the new tables
             launch()
-        out, stats = _bn_forward(plan, y, gamma, beta)
-        ctx.save_for_backward(x, w, y, stats, gamma)
+        out, stats = _bn_forward(plan, y, gamma, beta, residual)
+        ctx.has_res = residual is not None
+        if ctx.has_res and plan.relu:
+            ctx.save_for_backward(x, w, y, stats, gamma, out)  # (the output's sign is the ReLU mask of a residual tail)
+        else:
+            ctx.save_for_backward(x, w, y, stats, gamma)
         ctx.plan = plan
         ctx.gdtype = gamma.dtype if gamma is not None else None
         ctx.bdtype = beta.dtype if beta is not None else None
@@ -141,14 +166,17 @@ class _ConvBnAct(Function):
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
-        x, w, y, stats, gamma = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        x, w, y, stats, gamma = saved[:5]
+        z = saved[5] if len(saved) > 5 else (y if ctx.has_res else None)  # (no ReLU: only the flag matters)
         plan = ctx.plan
         km, M, cin, cout, K, code = plan.km, plan.num_out, plan.cin, plan.cout, plan.K, plan.code
         L = _lib.lib()
         dev = y.device
         stream = _lib.stream_handle(dev)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dyc, sums = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw)
+        need_dres = ctx.has_res and ctx.needs_input_grad[5]
+        dyc, sums, dres = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw, z if ctx.has_res else None, need_dres)
         dx = dw = None
         if need_dx:
             if km._has_duplicates:  # (repeated coordinates: the general path's pair-list formulation)
@@ -179,7 +207,7 @@ class _ConvBnAct(Function):
                 dw = dw.to(w.dtype)
         dgamma, dbeta = _affine_grads(ctx, sums)
         ctx.plan = None
-        return dx, dw, dgamma, dbeta, None
+        return dx, dw, dgamma, dbeta, None, dres
 
 
 class _PointwiseBnAct(Function):
@@ -209,7 +237,7 @@ class _PointwiseBnAct(Function):
         x, w16, y, stats, gamma = ctx.saved_tensors
         plan = ctx.plan
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dyc, sums = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw)
+        dyc, sums, _ = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw)
         dx = dw = None
         if need_dx:
             from .pointwise import dense_rows
@@ -250,10 +278,13 @@ def _static_ok(conv, norm) -> int:
     return 1
 
 
-def conv_bn_act(x, conv, norm, relu: bool):
-    """``relu(norm(conv(x)))`` (``relu`` optional) through the fused node, or ``None`` when the layer needs the general path.
+def conv_bn_act(x, conv, norm, relu: bool, residual=None):
+    """``relu(norm(conv(x)) [+ residual])`` (``relu`` optional) through the fused node, or ``None`` when the layer needs the
+    general path.
 
-    ``x``: Voxels on the GPU; the compute dtype is the autocast dtype (bf16 / fp16) or a 16-bit feature dtype."""
+    ``x``: Voxels on the GPU; the compute dtype is the autocast dtype (bf16 / fp16) or a 16-bit feature dtype.
+    ``residual``: Voxels on the output coordinates (or their ``[M, Cout]`` feature tensor) - the identity branch of a residual
+    block (reference `models/mink_unet.py:160-172`), added between the normalisation and the activation in the same pass."""
     from warpconvnet_amd.geometry.types.voxels import Voxels
     from warpconvnet_amd.nn.functional.sparse_conv.helper import generate_output_coords_and_kernel_map, wrap_conv_output
 
@@ -278,6 +309,8 @@ def conv_bn_act(x, conv, norm, relu: bool):
     code = _lib.dtype_code(dtype)
     plan = _Plan()
     plan.cin, plan.cout, plan.K, plan.code, plan.relu = cin, cout, K, code, bool(relu)
+    if residual is not None and kind != 1:
+        return None  # (a residual tail behind a 1 x 1 x 1 convolution: the modules one by one)
     if kind == 2:
         feats = x.feature_tensor
         if feats.dtype != dtype:
@@ -304,5 +337,13 @@ def conv_bn_act(x, conv, norm, relu: bool):
     plan.km, plan.num_in, plan.num_out = km, feats.shape[0], M
     (plan.training, plan.momentum, plan.eps, plan.running_mean, plan.running_var, plan.counter,
      plan.fused_running) = bn_module_state(norm, feats)
-    out = _ConvBnAct.apply(feats, conv.weight, norm.weight, norm.bias, plan)
+    if residual is not None:
+        res = residual.feature_tensor if isinstance(residual, Voxels) else residual
+        if res.shape != (M, cout) or not res.is_cuda:
+            return None
+        if res.dtype != dtype:
+            res = res.to(dtype)
+        out = _ConvBnAct.apply(feats, conv.weight, norm.weight, norm.bias, plan, res.contiguous())
+    else:
+        out = _ConvBnAct.apply(feats, conv.weight, norm.weight, norm.bias, plan)
     return wrap_conv_output(x, bcoords_out, out_offsets, out, out_ts)
