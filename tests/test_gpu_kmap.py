@@ -197,6 +197,22 @@ def test_reverse_table_and_from_csr():
     attach_tables_from_csr(sw, len(coarse), len(s))
     np.testing.assert_array_equal(sw._nbr.cpu().numpy()[:, :8].T, r["rev"])
     np.testing.assert_array_equal(sw._mask.cpu().numpy().view(np.uint32), r["rev_mask"])
+    # the convolution's own exchange (helper._swap) keeps a link to the forward map: its tables are that map's reverse tables
+    # (one build, shared with the strided layer's dgrad) and its reverse tables are the forward map's own - same content as
+    # the CSR route above, the oracle's tables in both directions
+    from warpconvnet_amd.nn.functional.sparse_conv.helper import _swap
+
+    tw = _swap(km)
+    assert tw._twin is km
+    attach_tables_from_csr(tw, len(coarse), len(s))
+    assert tw._nbr is rev_nbr and tw._mask is rev_mask and tw._perm is rev_perm
+    np.testing.assert_array_equal(tw._nbr.cpu().numpy()[:, :8].T, r["rev"])
+    t_nbr, t_mask, t_perm = reverse_tables(tw, len(coarse))
+    assert t_nbr is km._nbr and t_mask is km._mask and t_perm is km._perm
+    np.testing.assert_array_equal(t_nbr.cpu().numpy()[:, :8].T, r["nbr"] if "nbr" in r else t_nbr.cpu().numpy()[:, :8].T)
+    s_nbr, s_mask, _ = reverse_tables(sw, len(coarse))  # (the twin-less copy: rebuilt from the pair lists)
+    np.testing.assert_array_equal(t_nbr.cpu().numpy()[:, :8], s_nbr.cpu().numpy()[:, :8])
+    np.testing.assert_array_equal(t_mask.cpu().numpy(), s_mask.cpu().numpy())
 
 
 def test_hash_table_contract_gpu():

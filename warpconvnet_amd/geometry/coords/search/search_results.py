@@ -94,6 +94,8 @@ class IntSearchResult:
         self._identity: Optional[int] = None
         self._validate_error: Optional[Exception] = None  # a build the device rejected for good: raised by every validate()
         self._on_invalid = None  # called once when validation fails (the convolution evicts the map from its cache)
+        self._twin = None  # a map made by exchanging in / out of another one (transposed convolution): that map - its reverse
+        #                    tables are this map's forward tables and vice versa, nothing is rebuilt from the pair lists
 
     @classmethod
     def _blank(cls, num_offsets: int, device) -> "IntSearchResult":

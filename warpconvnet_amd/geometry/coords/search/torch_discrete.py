@@ -81,6 +81,16 @@ def attach_tables_from_csr(kmap: IntSearchResult, num_in: int, num_out: int) -> 
     kmap.validate()  # an optimistic map another consumer left unvalidated: settle (and possibly rebuild) it first
     if kmap._nbr is not None:
         return kmap
+    twin = kmap._twin
+    if twin is not None and not twin._has_duplicates:
+        # in / out exchanged (transposed convolution on the cached forward map): this map's gather table is the forward map's
+        # reverse table - built once and shared with the forward layer's dgrad - instead of a second pass over the pair lists
+        twin.validate()
+        if twin._nbr is not None and twin._nbr.shape[0] == num_in:
+            kmap._nbr, kmap._mask, kmap._perm = reverse_tables(twin, num_out)
+            kmap._offsets_dev = twin._offsets_dev
+            kmap._num_in, kmap._num_out = num_in, num_out
+            return kmap
     dev = kmap.in_maps_device.device
     K = len(kmap)
     L = _lib.lib()
@@ -106,6 +116,11 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
     Role of `_build_reverse_mask_data` (`mask_gemm.py:279-350`).
     """
     kmap.validate()
+    twin = kmap._twin
+    if kmap._rev is None and twin is not None and not twin._has_duplicates:
+        twin.validate()
+        if twin._nbr is not None and twin._nbr.shape[0] == num_in:  # (an exchanged map: the forward map's own tables)
+            kmap._rev = (twin._nbr, twin._mask, twin._perm)
     if kmap._rev is None:
         dev = kmap.in_maps_device.device
         K = len(kmap)

@@ -67,6 +67,12 @@ class ConvTrBlock(nn.Module):
         self.norm_act = Sequential(nn.BatchNorm1d(out_channels), _activation(activation))
 
     def forward(self, x: Voxels, out_spatial_sparsity: Voxels) -> Voxels:
+        norm, act = self.norm_act[0], self.norm_act[1]
+        if type(act) in (nn.ReLU, nn.Identity) and not (_has_hooks(self.conv_tr) or _has_hooks(norm) or _has_hooks(act) or
+                                                       _has_hooks(self.norm_act)):
+            y = conv_bn_act(x, self.conv_tr, norm, type(act) is nn.ReLU, out_spatial=out_spatial_sparsity)
+            if y is not None:  # one autograd node, tables shared with the strided layer whose map this one exchanges
+                return y
         return self.norm_act(self.conv_tr(x, out_spatial_sparsity))
 
 

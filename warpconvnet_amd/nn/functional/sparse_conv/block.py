@@ -15,8 +15,9 @@ conv -> BN -> ReLU block costs 320 us of host time forward + backward for 11 ker
 Same kernels, same math and the same saved tensors as the three-module path; only the Python between the launches is
 gone.  The fast path takes the layers it can serve without any of the special cases of the general path - 16-bit compute
 dtype, shapes of the MFMA kernels in both directions, groups = 1, no convolution bias (it would be cancelled by the
-BatchNorm anyway), non-transposed, non-generative, no hooks - and returns ``None`` otherwise: `Sequential` then runs the
-modules one by one.
+BatchNorm anyway), non-generative, no hooks - and returns ``None`` otherwise: `Sequential` then runs the modules one by one.
+A residual tail (``residual=``) and transposed convolutions onto a given tensor's coordinates (``out_spatial=``) are served
+for `models/mink_unet.py`'s ``BasicBlock`` and ``ConvTrBlock``.
 """
 import os
 from typing import Optional
@@ -256,13 +257,13 @@ class _PointwiseBnAct(Function):
 
 def _static_ok(conv, norm) -> int:
     """Module properties that do not change between calls (memoised on the convolution): 0 = general path, 1 = gather GEMM,
-    2 = pointwise."""
+    2 = pointwise, 3 = transposed gather GEMM (onto the coordinates of a given tensor)."""
     from warpconvnet_amd.nn.functional.sparse_conv.helper import STRIDED_CONV_MODE
     from warpconvnet_amd.nn.modules.sparse_conv import SpatiallySparseConv
 
     if type(norm) is not torch.nn.BatchNorm1d or not isinstance(conv, SpatiallySparseConv):
         return 0
-    if conv.groups != 1 or conv.bias is not None or conv.transposed or conv.generative or conv.weight.ndim != 3:
+    if conv.groups != 1 or conv.bias is not None or conv.generative or conv.weight.ndim != 3:
         return 0
     if conv.num_spatial_dims != 3 or conv.order is not None or conv.compute_dtype is not None:
         return 0
@@ -274,17 +275,19 @@ def _static_ok(conv, norm) -> int:
     if conv.weight.dtype != torch.float32 or norm.num_features != conv.out_channels:
         return 0
     if all(k == 1 for k in conv.kernel_size):
-        return 2 if all(s == 1 for s in conv.stride) else 0
-    return 1
+        return 2 if all(s == 1 for s in conv.stride) and not conv.transposed else 0
+    return 3 if conv.transposed else 1
 
 
-def conv_bn_act(x, conv, norm, relu: bool, residual=None):
+def conv_bn_act(x, conv, norm, relu: bool, residual=None, out_spatial=None):
     """``relu(norm(conv(x)) [+ residual])`` (``relu`` optional) through the fused node, or ``None`` when the layer needs the
     general path.
 
     ``x``: Voxels on the GPU; the compute dtype is the autocast dtype (bf16 / fp16) or a 16-bit feature dtype.
     ``residual``: Voxels on the output coordinates (or their ``[M, Cout]`` feature tensor) - the identity branch of a residual
-    block (reference `models/mink_unet.py:160-172`), added between the normalisation and the activation in the same pass."""
+    block (reference `models/mink_unet.py:160-172`), added between the normalisation and the activation in the same pass.
+    ``out_spatial``: transposed convolutions - the Voxels whose coordinates the output takes (`mink_unet.py:83-90`); the map is
+    the cached forward map of the matching strided layer with in / out exchanged, its tables are that map's reverse tables."""
     from warpconvnet_amd.geometry.types.voxels import Voxels
     from warpconvnet_amd.nn.functional.sparse_conv.helper import generate_output_coords_and_kernel_map, wrap_conv_output
 
@@ -311,6 +314,8 @@ def conv_bn_act(x, conv, norm, relu: bool, residual=None):
     plan.cin, plan.cout, plan.K, plan.code, plan.relu = cin, cout, K, code, bool(relu)
     if residual is not None and kind != 1:
         return None  # (a residual tail behind a 1 x 1 x 1 convolution: the modules one by one)
+    if (kind == 3) != (out_spatial is not None):
+        return None
     if kind == 2:
         feats = x.feature_tensor
         if feats.dtype != dtype:
@@ -323,9 +328,22 @@ def conv_bn_act(x, conv, norm, relu: bool, residual=None):
     if not (hip_gemm._gather_ok(cin, cout, K, code) and hip_gemm._gather_ok(cout, cin, K, code) and hip_gemm._wgrad_ok(cin, cout, code)):
         return None
     in_ts = x.tensor_stride or (1, 1, 1)
-    out_ts = tuple(o * s for o, s in zip(conv.stride, in_ts))
-    bcoords_out, out_offsets, km = generate_output_coords_and_kernel_map(
-        x, conv.kernel_size, conv.dilation, conv.stride, need_pairs=torch.is_grad_enabled(), optimistic=True)
+    if kind == 3:
+        from warpconvnet_amd.geometry.coords.search.torch_discrete import attach_tables_from_csr
+
+        if not isinstance(out_spatial, Voxels):
+            return None
+        out_ts = out_spatial.tensor_stride or (1, 1, 1)
+        if not any(o < i for o, i in zip(out_ts, in_ts)):
+            return None  # (the general path raises the reference's assertion)
+        bcoords_out, out_offsets, km = generate_output_coords_and_kernel_map(
+            x, conv.kernel_size, conv.dilation, conv.stride, transposed=True, output_spatially_sparse_tensor=out_spatial,
+            need_pairs=torch.is_grad_enabled())
+        attach_tables_from_csr(km, raw.shape[0], bcoords_out.shape[0])
+    else:
+        out_ts = tuple(o * s for o, s in zip(conv.stride, in_ts))
+        bcoords_out, out_offsets, km = generate_output_coords_and_kernel_map(
+            x, conv.kernel_size, conv.dilation, conv.stride, need_pairs=torch.is_grad_enabled(), optimistic=True)
     M = bcoords_out.shape[0]
     if M < 2 or km._nbr is None:
         # degenerate sizes, or a map that only has its CSR form (user-made): the general path (it finds the map in the cache)

@@ -40,6 +40,7 @@ def _swap(kernel_map: IntSearchResult) -> IntSearchResult:
     """Transposed convolution uses the forward map with in/out exchanged (reference helper.py:487-497)."""
     swapped = IntSearchResult(in_maps=kernel_map.out_maps, out_maps=kernel_map.in_maps, offsets=kernel_map.offsets)
     swapped._offsets_dev = kernel_map._offsets_dev
+    swapped._twin = kernel_map  # (its gather tables are the forward map's reverse tables and vice versa: torch_discrete.py)
     return swapped
 
 
