@@ -22,8 +22,18 @@
 
 namespace wcn {
 
-constexpr int kNormBlocks = 1024;  // partial sums per channel (first reduction level)
-constexpr int kNormRowsInFlight = 4;
+// First reduction level: workgroups (= partial sums per channel) and rows in flight per thread.  Measured on [1 M, 96] /
+// [1 M, 32] / [290 k, 64] bf16, statistics and backward-reduce passes incl. the second level (tools/bench_bn.py, us):
+// 1024 x 4: 39 / 31 / 19 and 101 / 44 / 32;  512 x 8: 37 / 26 / 16 and 86 / 37 / 26;  256 x 8: 41 / 26 / 16 and 106 / 39 / 27;
+// 2048 x 4 and 512 x 16 are slower than 1024 x 4 (dev builds: -DWCN_NORM_BLOCKS / -DWCN_NORM_ROWS, tools/build_abl.sh).
+#ifndef WCN_NORM_BLOCKS
+#define WCN_NORM_BLOCKS 512
+#endif
+#ifndef WCN_NORM_ROWS
+#define WCN_NORM_ROWS 8
+#endif
+constexpr int kNormBlocks = WCN_NORM_BLOCKS;
+constexpr int kNormRowsInFlight = WCN_NORM_ROWS;
 
 template <typename T> struct NCvt;
 template <> struct NCvt<float> {
@@ -315,7 +325,7 @@ static int bn_reduce_t(int mode, const void* x, const void* dy, const float* rsc
                        const float* rstd, float* out0, float* out1, float* partial, hipStream_t s,
                        const BnFold& fold = BnFold(), const void* zmask = nullptr) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  // first-level workgroups: at least 128 rows each (small tensors: fewer partial sums for the second level), 1 024 at most
+  // first-level workgroups: at least 128 rows each (small tensors: fewer partial sums for the second level), kNormBlocks at most
   int64_t nb = ceil_div(n < 1 ? 1 : n, 128);
   const int nblocks = (int)(nb < kNormBlocks ? nb : kNormBlocks);
   const bool vec = c % VEC == 0;
