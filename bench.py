@@ -175,7 +175,7 @@ def secondary_configs(dev, args):
         rec = ConvLayerRecorder(net)
         unet_step()
         rec.close()
-        ms = time_events(unet_step, 5, warmup=3)
+        ms = time_events(unet_step, 10, warmup=3)
         out[f"minkunet14_{label}_ms"] = round(ms, 3)
         out[f"minkunet14_{label}_voxels"] = n
         layer_bytes = [conv_bytes(r) for r in rec.records]

@@ -62,6 +62,14 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_abi_version() >= 2
     assert L.wcn_pack_weight(_ct.addressof(buf), 27, 64, 128, _lib.WCN_BF16, 0, 0, _ct.addressof(buf), 64, None) == -5
     assert L.wcn_pack_weight_f32(_ct.addressof(buf), 27, 96, 96, _lib.WCN_BF16, 0, 0, _ct.addressof(buf), 27 * 96 * 96 * 2, None) == -5
+    # ABI 3 additions: identity-map dense products, residual-tail BatchNorm passes
+    assert L.wcn_abi_version() >= 3
+    assert L.wcn_conv_identity_supported(96, 128, _lib.WCN_BF16) == 1 and L.wcn_conv_identity_supported(128, 256, _lib.WCN_F16) == 1
+    assert L.wcn_conv_identity_supported(48, 64, _lib.WCN_BF16) == 0 and L.wcn_conv_identity_supported(96, 20, _lib.WCN_BF16) == 0
+    assert L.wcn_conv_identity_supported(64, 64, _lib.WCN_F32) == 0
+    assert L.wcn_bn_apply_residual(None, None, 4, 8, _lib.WCN_BF16, None, None, 1, None, None) == -5
+    assert L.wcn_bn_backward_reduce_masked(None, None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, None, 0, None) == -5
+    assert L.wcn_bn_backward_apply_masked(None, None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, None, None, None, None) == -5
     # parameter validation happens before any launch: bad arguments come back as status codes
     assert L.wcn_hash_prepare(None, 16, None) == -5
     assert L.wcn_hash_prepare(None, 17, None) == -5

@@ -228,7 +228,10 @@ using namespace wcn;
 
 extern "C" {
 
-int wcn_abi_version(void) { return 2; }  // 2: wcn_pack_weight[_f32] take the size of the destination buffer
+// 2: wcn_pack_weight[_f32] take the size of the destination buffer
+// 3 (additions only): identity map in wcn_conv_gather_gemm (nbr = mask = NULL, one offset) + wcn_conv_identity_supported,
+//    outputs wider than 128 channels on the channel-split kernels, wcn_bn_apply_residual / wcn_bn_backward_*_masked
+int wcn_abi_version(void) { return 3; }
 
 const char* wcn_status_string(int status) {
   switch (status) {
