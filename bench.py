@@ -12,6 +12,7 @@ gradients.  Inputs (coordinates, features, grad_out, fp32 master weights) are re
 timed region.  Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -71,6 +72,7 @@ def time_events(fn, iters, warmup=2):
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    gc.collect()  # (garbage of the warm-up and of earlier sections is collected here, not inside the timed window)
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for _ in range(iters):
@@ -539,6 +541,13 @@ def main():
 
     coords, feats, grad_out, offsets, conv, params = build_workload(args, dev, rank)
     N = coords.shape[0]
+    # Python's cyclic collector walks every tracked object of the process on a full collection - after `import torch` that is
+    # a 100-140 ms host stall whenever one happens to fall into a timed window (measured: the first timed step of the
+    # surface-scene section, 3.0 instead of 1.4 ms per step over its 50 steps, depending on nothing but how the script was
+    # started).  The collector stays ON; the objects that exist now (modules, the workload) move to the permanent generation,
+    # so later collections only walk what the steps themselves allocate.
+    gc.collect()
+    gc.freeze()
     # N > 1: persistent flat gradient bucket, the all-reduce is launched from the autograd hook of the last gradient
     step, _ = make_step(dev, world, coords, feats, grad_out, offsets, conv, params)
     elapsed, ms_half = timed_loop(step, args, dev, world)

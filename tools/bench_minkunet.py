@@ -5,6 +5,7 @@ time per iteration (the network is host-bound when they coincide).  GPU box only
     WARPCONVNET_AMD_HIP_BATCHNORM=0 python tools/bench_minkunet.py      # stock BatchNorm kernels for comparison
 """
 import argparse
+import gc
 import os
 import sys
 import time
@@ -39,6 +40,8 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.freeze()  # (a full collection over the import-time heap is a 100+ ms host stall if it lands in the window: bench.py)
     t = time.perf_counter()
     for _ in range(args.iters):
         step()
