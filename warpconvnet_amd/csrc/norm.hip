@@ -314,9 +314,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
   }
 }
 
-static inline unsigned norm_grid(int64_t items) {  // grid-stride: a few workgroups per CU, the LDS staging is amortised
+// grid-stride: a few workgroups per CU, the LDS staging is amortised.  Cap measured with tools/bench_bn.py on one box ([1 M, 96] /
+// [1 M, 32] / [290 k, 64] bf16, us): forward apply 2048: 70 / 21 / 13, 4096: 70 / 22 / 14; backward apply 2048: 128 / 33 / 21,
+// 4096: 114 / 31 / 20.  (Non-temporal loads / stores: 5 % faster on the tensor that exceeds the Infinity Cache, 10-15 % slower on
+// the ones a neighbouring kernel finds there - not used.)
+static inline unsigned norm_grid(int64_t items, int cap = 2048) {
   const int64_t g = ceil_div(items, 256 * 4);
-  return (unsigned)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
+  return (unsigned)(g < cap ? (g < 1 ? 1 : g) : cap);
 }
 
 template <typename T>
@@ -364,11 +368,11 @@ static int bn_bwd_apply_t(const void* dy, const void* x, const float* rscale, co
                           hipStream_t s, const void* zmask = nullptr, void* dres = nullptr) {
   constexpr int VEC = 16 / (int)sizeof(T);
   if (c % VEC == 0)
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC>), dim3(norm_grid(n * (c / VEC))), dim3(256), (size_t)5 * c * 4, s,
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC>), dim3(norm_grid(n * (c / VEC), 4096)), dim3(256), (size_t)5 * c * 4, s,
                        (const T*)dy, (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx,
                        (const T*)zmask, (T*)dres);
   else
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(norm_grid(n * c)), dim3(256), (size_t)5 * c * 4, s, (const T*)dy,
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(norm_grid(n * c, 4096)), dim3(256), (size_t)5 * c * 4, s, (const T*)dy,
                        (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx, (const T*)zmask,
                        (T*)dres);
   return launch_status();
