@@ -219,13 +219,11 @@ class _PointwiseBnAct(Function):
     def forward(ctx, x: Tensor, w: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], plan: _Plan) -> Tensor:
         from .pointwise import dense_rows
 
-        w16 = w[0] if w.dtype == x.dtype else w[0].to(x.dtype)
         y = dense_rows(x, w, False)
-        if y is None:
-            y = x @ w16
-        ctx.w3 = w
+        if y is None:  # (shapes outside the streaming kernel: the vendor GEMM on a cast copy of the weight)
+            y = x @ (w[0] if w.dtype == x.dtype else w[0].to(x.dtype))
         out, stats = _bn_forward(plan, y, gamma, beta)
-        ctx.save_for_backward(x, w16, y, stats, gamma)
+        ctx.save_for_backward(x, y, stats, gamma, w)  # (w: the parameter itself - no copy, and autograd's version check applies)
         ctx.plan, ctx.wdtype = plan, w.dtype
         ctx.gdtype = gamma.dtype if gamma is not None else None
         ctx.bdtype = beta.dtype if beta is not None else None
@@ -235,7 +233,7 @@ class _PointwiseBnAct(Function):
     def backward(ctx, grad_out: Tensor):
         from .pointwise import dense_wgrad
 
-        x, w16, y, stats, gamma = ctx.saved_tensors
+        x, y, stats, gamma, w3 = ctx.saved_tensors
         plan = ctx.plan
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dyc, sums, _ = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw)
@@ -243,9 +241,9 @@ class _PointwiseBnAct(Function):
         if need_dx:
             from .pointwise import dense_rows
 
-            dx = dense_rows(dyc, ctx.w3, True)
+            dx = dense_rows(dyc, w3, True)
             if dx is None:
-                dx = dyc @ w16.t()
+                dx = dyc @ (w3[0] if w3.dtype == dyc.dtype else w3[0].to(dyc.dtype)).t()
         if need_dw:
             dw = dense_wgrad(x, dyc).unsqueeze(0)
             if dw.dtype != ctx.wdtype:

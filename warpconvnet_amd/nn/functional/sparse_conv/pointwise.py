@@ -96,35 +96,34 @@ class _PointwiseConv(Function):
     def forward(ctx, feats: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
         """``weight``: ``[Cin, Cout]``, or the convolution's own ``[1, Cin, Cout]`` parameter (then the products take the
         streaming kernel of `dense_rows` where the shape allows)."""
-        w3 = weight if weight.ndim == 3 else None
-        w2 = weight[0] if w3 is not None else weight
-        w = w2 if w2.dtype == feats.dtype else w2.to(feats.dtype)
-        ctx.w3 = w3
-        ctx.save_for_backward(feats, w)
+        ctx.is3 = weight.ndim == 3
+        ctx.save_for_backward(feats, weight)  # (the parameter itself: no copy, autograd's version check applies)
         ctx.weight_dtype, ctx.has_bias = weight.dtype, bias is not None
         ctx.bias_dtype = bias.dtype if bias is not None else None
-        if w3 is not None:
-            out = dense_rows(feats, w3, False, bias)
+        if ctx.is3:
+            out = dense_rows(feats, weight, False, bias)
             if out is not None:
                 return out
-        out = feats @ w
+        w2 = weight[0] if ctx.is3 else weight
+        out = feats @ (w2 if w2.dtype == feats.dtype else w2.to(feats.dtype))  # (the cast copy only on the vendor-GEMM path)
         return out if bias is None else out + bias.to(out.dtype)
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
-        feats, w = ctx.saved_tensors
+        feats, weight = ctx.saved_tensors
         dy = grad_out.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = dense_rows(dy, ctx.w3, True) if ctx.w3 is not None else None
+            dx = dense_rows(dy, weight, True) if ctx.is3 else None
             if dx is None:
-                dx = dy @ w.t()
+                w2 = weight[0] if ctx.is3 else weight
+                dx = dy @ (w2 if w2.dtype == dy.dtype else w2.to(dy.dtype)).t()
         if ctx.needs_input_grad[1]:
             if (dy.is_cuda and dy.dtype in (torch.float16, torch.bfloat16) and feats.dtype == dy.dtype and feats.shape[0] > 0):
                 dw = dense_wgrad(feats.contiguous(), dy).to(ctx.weight_dtype)
             else:
                 dw = (feats.t() @ dy).to(ctx.weight_dtype)
-            if ctx.w3 is not None:
+            if ctx.is3:
                 dw = dw.unsqueeze(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if dy.is_cuda and dy.shape[0] > 0 and dy.dtype in (torch.float32, torch.float16, torch.bfloat16):
