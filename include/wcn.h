@@ -512,6 +512,20 @@ int wcn_bn_backward_apply_masked(const void* dy, const void* x, const void* z, i
                                  const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
                                  const float* sum_dy_xhat, void* dx, void* dres, wcn_stream_t stream);
 
+/* Layer entries: the BatchNorm of a training step in ONE call per direction (the host side of a network pays per call, not per
+ * launch: tools/host_attrib.py).  `stats` [5][channels] fp32 = mean | rstd | scale | shift | biased variance, written by the
+ * forward and read by the backward.  wcn_bn_train_forward = wcn_bn_stats_fold + wcn_bn_apply[_residual] (`residual` may be NULL);
+ * wcn_bn_train_backward = wcn_bn_backward_reduce[_masked] + wcn_bn_backward_apply[_masked]: `z` (stored output of a residual
+ * tail, its sign is the ReLU mask) or NULL (mask recomputed from x when `relu`), `sums` [2][channels] = sum_dy | sum_dy_xhat,
+ * `dx` NULL = sums only, `dres` (masked gradient, residual tails) may be NULL, `training` 0 = statistics were constants. */
+int wcn_bn_train_forward(const void* x, const void* residual, int64_t n, int32_t channels, int32_t dtype, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         int64_t* num_batches_tracked, int32_t relu, float* stats, void* y, void* workspace,
+                         size_t workspace_bytes, wcn_stream_t stream);
+int wcn_bn_train_backward(const void* dy, const void* x, const void* z, int32_t relu, int64_t n, int32_t channels, int32_t dtype,
+                          const float* stats, const float* gamma, int32_t training, float* sums, void* dx, void* dres,
+                          void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

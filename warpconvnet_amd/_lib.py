@@ -59,6 +59,11 @@ SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wcn_bn_backward_apply_masked": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wcn_bn_train_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     ctypes.c_float, ctypes.c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
+    "wcn_bn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wcn_pool_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     "wcn_pool_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

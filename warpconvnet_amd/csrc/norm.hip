@@ -529,4 +529,55 @@ int wcn_bn_backward_apply_masked(const void* dy, const void* x, const void* z, i
   }
 }
 
+// ---- layer entries: the BatchNorm of a training step in one call per direction ----
+// `stats`: [5][channels] fp32 = mean | rstd | scale | shift | biased variance, written by the forward and read by the backward.
+
+int wcn_bn_train_forward(const void* x, const void* residual, int64_t n, int32_t channels, int32_t dtype, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         int64_t* num_batches_tracked, int32_t relu, float* stats, void* y, void* workspace,
+                         size_t workspace_bytes, wcn_stream_t stream) {
+  if (!stats) return WCN_ERROR_INVALID_PARAMETERS;
+  float* mean = stats;
+  float* rstd = stats + channels;
+  float* scale = stats + 2 * (int64_t)channels;
+  float* shift = stats + 3 * (int64_t)channels;
+  float* var = stats + 4 * (int64_t)channels;
+  const int rc = wcn_bn_stats_fold(x, n, channels, dtype, gamma, beta, running_mean, running_var, momentum, eps, mean, var, rstd,
+                                   scale, shift, num_batches_tracked, workspace, workspace_bytes, stream);
+  if (rc != WCN_SUCCESS) return rc;
+  return residual ? wcn_bn_apply_residual(x, residual, n, channels, dtype, scale, shift, relu, y, stream)
+                  : wcn_bn_apply(x, n, channels, dtype, scale, shift, relu, y, stream);
+}
+
+// `z`: the stored output of a residual tail (mask = its sign), or NULL (`relu`: the mask is recomputed from x and the forward's
+// scale / shift).  `sums`: [2][channels] = sum_dy (bias gradient) | sum_dy_xhat (weight gradient).  `dx` NULL: sums only.
+// `training` 0: the statistics were constants (eval mode) - dx without the mean terms.
+int wcn_bn_train_backward(const void* dy, const void* x, const void* z, int32_t relu, int64_t n, int32_t channels, int32_t dtype,
+                          const float* stats, const float* gamma, int32_t training, float* sums, void* dx, void* dres,
+                          void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
+  if (!stats || !sums || channels < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  const float* mean = stats;
+  const float* rstd = stats + channels;
+  const float* rsc = (relu && !z) ? stats + 2 * (int64_t)channels : nullptr;
+  const float* rsh = (relu && !z) ? stats + 3 * (int64_t)channels : nullptr;
+  float* sum_dy = sums;
+  float* sum_dy_xhat = sums + channels;
+  const bool masked = z && relu;
+  int rc = masked ? wcn_bn_backward_reduce_masked(dy, x, z, n, channels, dtype, mean, rstd, sum_dy, sum_dy_xhat, workspace,
+                                                  workspace_bytes, stream)
+                  : wcn_bn_backward_reduce(dy, x, rsc, rsh, n, channels, dtype, mean, rstd, sum_dy, sum_dy_xhat, workspace,
+                                           workspace_bytes, stream);
+  if (rc != WCN_SUCCESS || !dx) return rc;
+  const float* a0 = sum_dy;
+  const float* a1 = sum_dy_xhat;
+  if (!training) {  // constants: the second half of the workspace is zeroed and stands in for the sums
+    float* zeros = reinterpret_cast<float*>(workspace);
+    if (hipMemsetAsync(zeros, 0, (size_t)channels * sizeof(float), (hipStream_t)stream) != hipSuccess)
+      return WCN_ERROR_KERNEL_EXECUTION;
+    a0 = a1 = zeros;
+  }
+  return masked ? wcn_bn_backward_apply_masked(dy, x, z, n, channels, dtype, mean, rstd, gamma, a0, a1, dx, dres, stream)
+                : wcn_bn_backward_apply(dy, x, rsc, rsh, n, channels, dtype, mean, rstd, gamma, a0, a1, dx, stream);
+}
+
 }  // extern "C"

@@ -43,30 +43,31 @@ class _Plan:
 
 def _bn_forward(plan: _Plan, y: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], residual: Optional[Tensor] = None):
     """BatchNorm (+ residual) (+ ReLU) of the convolution's output ``y``: statistics + fold (training) or fold of the running
-    statistics (eval), then apply.  -> (out, stats [5, C] = mean, rstd, scale, shift, var)"""
+    statistics (eval), then apply - one C call in training (`wcn_bn_train_forward`).
+    -> (out, stats [5, C] = mean, rstd, scale, shift, var)"""
     L = _lib.lib()
     dev = y.device
     stream = _lib.stream_handle(dev)
     M, cout, code = plan.num_out, plan.cout, plan.code
     stats = torch.empty((5, cout), dtype=torch.float32, device=dev)
+    out = torch.empty_like(y)
     gp, bp, yp = _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y)
     s0 = stats.data_ptr()
-    mean, rstd, scale, shift, var = (s0 + 4 * cout * i for i in range(5))
     if plan.training:
         ws = _bn_workspace(cout, dev)
         fr = plan.fused_running
-        _lib.check(L.wcn_bn_stats_fold(yp, M, cout, code, gp, bp, _lib.ptr(plan.running_mean) if fr else None,
-                                       _lib.ptr(plan.running_var) if fr else None, plan.momentum, plan.eps, mean, var, rstd,
-                                       scale, shift, _lib.ptr(plan.counter), _lib.ptr(ws), ws.numel(), stream),
-                   "wcn_bn_stats_fold")
+        _lib.check(L.wcn_bn_train_forward(yp, _lib.ptr(residual), M, cout, code, gp, bp, _lib.ptr(plan.running_mean) if fr else None,
+                                          _lib.ptr(plan.running_var) if fr else None, plan.momentum, plan.eps,
+                                          _lib.ptr(plan.counter), int(plan.relu), s0, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                          stream), "wcn_bn_train_forward")
         if plan.running_mean is not None and not fr:  # (non-fp32 running statistics: the module's own arithmetic)
             unbias = float(M) / float(max(M - 1, 1))
             plan.running_mean.mul_(1.0 - plan.momentum).add_(stats[0].to(plan.running_mean.dtype), alpha=plan.momentum)
             plan.running_var.mul_(1.0 - plan.momentum).add_(stats[4].to(plan.running_var.dtype), alpha=plan.momentum * unbias)
-    else:
-        _lib.check(L.wcn_bn_fold(_lib.ptr(plan.running_mean), _lib.ptr(plan.running_var), gp, bp, plan.eps, cout, mean, rstd,
-                                 scale, shift, stream), "wcn_bn_fold")
-    out = torch.empty_like(y)
+        return out, stats
+    mean, rstd, scale, shift = (s0 + 4 * cout * i for i in range(4))
+    _lib.check(L.wcn_bn_fold(_lib.ptr(plan.running_mean), _lib.ptr(plan.running_var), gp, bp, plan.eps, cout, mean, rstd,
+                             scale, shift, stream), "wcn_bn_fold")
     if residual is not None:
         _lib.check(L.wcn_bn_apply_residual(yp, _lib.ptr(residual), M, cout, code, scale, shift, int(plan.relu), _lib.ptr(out),
                                            stream), "wcn_bn_apply_residual")
@@ -77,50 +78,28 @@ def _bn_forward(plan: _Plan, y: Tensor, gamma: Optional[Tensor], beta: Optional[
 
 def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, stats: Tensor, gamma: Optional[Tensor], need_dy: bool,
                  z: Optional[Tensor] = None, need_dres: bool = False):
-    """-> (gradient of the convolution's output or None, sums [2, C] = sum_dy (bias gradient), sum_dy_xhat (weight gradient),
-    gradient of the residual or None).  ``z``: the stored output of a residual tail ReLU(BN(y) + r) - the ReLU mask is its sign."""
+    """One C call (`wcn_bn_train_backward`: reduce + apply).  -> (gradient of the convolution's output or None, sums [2, C] =
+    sum_dy (bias gradient), sum_dy_xhat (weight gradient), gradient of the residual or None).  ``z``: the stored output of a
+    residual tail ReLU(BN(y) + r) - the ReLU mask is its sign."""
     L = _lib.lib()
     dev = y.device
-    stream = _lib.stream_handle(dev)
     M, cout, code = plan.num_out, plan.cout, plan.code
     g = grad_out.contiguous()
     if g.dtype != y.dtype:
         g = g.to(y.dtype)
     sums = torch.empty((2, cout), dtype=torch.float32, device=dev)
-    s0 = stats.data_ptr()
-    mean, rstd = s0, s0 + 4 * cout
-    # fused ReLU: the mask comes from y (the convolution's output) and the scale / shift the forward applied to it
-    rsc, rsh = (s0 + 8 * cout, s0 + 12 * cout) if plan.relu else (None, None)
-    sum_dy, sum_dy_xhat = sums.data_ptr(), sums.data_ptr() + 4 * cout
     ws = _bn_workspace(cout, dev)
-    gp, yp = _lib.ptr(g), _lib.ptr(y)
     masked = z is not None and plan.relu  # (BN(y) + r without activation: the gradient reaches both branches unmasked)
-    if masked:
-        zp = _lib.ptr(z)
-        _lib.check(L.wcn_bn_backward_reduce_masked(gp, yp, zp, M, cout, code, mean, rstd, sum_dy, sum_dy_xhat, _lib.ptr(ws),
-                                                   ws.numel(), stream), "wcn_bn_backward_reduce_masked")
-    else:
-        _lib.check(L.wcn_bn_backward_reduce(gp, yp, rsc, rsh, M, cout, code, mean, rstd, sum_dy, sum_dy_xhat, _lib.ptr(ws),
-                                            ws.numel(), stream), "wcn_bn_backward_reduce")
-    if not need_dy and not (masked and need_dres):
-        return None, sums, (g if need_dres else None)
-    dyc = torch.empty_like(y)
-    if plan.training:
-        a0, a1 = sum_dy, sum_dy_xhat
-    else:  # eval: the statistics are constants
-        zeros = torch.zeros(cout, dtype=torch.float32, device=dev)
-        a0 = a1 = zeros.data_ptr()
-    dres = None
-    if masked:
-        dres = torch.empty_like(y) if need_dres else None
-        _lib.check(L.wcn_bn_backward_apply_masked(gp, yp, zp, M, cout, code, mean, rstd, _lib.ptr(gamma), a0, a1, _lib.ptr(dyc),
-                                                  _lib.ptr(dres), stream), "wcn_bn_backward_apply_masked")
-    else:
-        _lib.check(L.wcn_bn_backward_apply(gp, yp, rsc, rsh, M, cout, code, mean, rstd, _lib.ptr(gamma), a0, a1, _lib.ptr(dyc),
-                                           stream), "wcn_bn_backward_apply")
-        if need_dres:
-            dres = g
-    return dyc, sums, dres
+    want_dx = need_dy or (masked and need_dres)
+    dyc = torch.empty_like(y) if want_dx else None
+    dres = torch.empty_like(y) if (masked and need_dres) else None
+    _lib.check(L.wcn_bn_train_backward(_lib.ptr(g), _lib.ptr(y), _lib.ptr(z) if masked else None, int(plan.relu), M, cout, code,
+                                       stats.data_ptr(), _lib.ptr(gamma), int(plan.training), sums.data_ptr(), _lib.ptr(dyc),
+                                       _lib.ptr(dres), _lib.ptr(ws), ws.numel(), _lib.stream_handle(dev)),
+               "wcn_bn_train_backward")
+    if need_dres and not masked:
+        dres = g
+    return (dyc if need_dy else None), sums, dres
 
 
 def _affine_grads(ctx, sums: Tensor):
