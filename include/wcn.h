@@ -526,6 +526,17 @@ int wcn_bn_train_backward(const void* dy, const void* x, const void* z, int32_t 
                           const float* stats, const float* gamma, int32_t training, float* sums, void* dx, void* dres,
                           void* workspace, size_t workspace_bytes, wcn_stream_t stream);
 
+/* Layer entry: backward of SparseConv3d -> BatchNorm (-> ReLU | residual tail) (reference models/mink_unet.py:31-53, 160-172 run
+ * as three autograd nodes) in one call: wcn_bn_train_backward into `dy_conv` ([n_out][cout], caller's buffer), then
+ * wcn_conv_gather_gemm on the reverse tables with the transposed packed weight (`dx` NULL: skipped), then wcn_conv_wgrad (`dw`
+ * NULL: skipped).  16-bit dtypes, MFMA shapes (wcn_mfma_gather_supported in both directions, wcn_mfma_wgrad_supported). */
+int wcn_conv_bn_backward(const void* grad_out, const void* x, const void* y, const void* z, int32_t relu, const float* stats,
+                         const float* gamma, int32_t training, float* sums, void* dy_conv, void* dres, const void* w_packed_dgrad,
+                         const int32_t* rev_nbr, const uint32_t* rev_mask, const int32_t* rev_perm, int32_t flip, void* dx,
+                         const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets, float* dw, void* wgrad_workspace,
+                         size_t wgrad_workspace_bytes, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets,
+                         int32_t dtype, void* bn_workspace, size_t bn_workspace_bytes, wcn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_bn_backward_apply_masked(None, None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, None, None, None, None) == -5
     assert L.wcn_bn_train_forward(None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, 0.1, 1e-5, None, 1, None, None, None, 0, None) == -5
     assert L.wcn_bn_train_backward(None, None, None, 1, 4, 8, _lib.WCN_BF16, None, None, 1, None, None, None, None, 0, None) == -5
+    assert L.wcn_conv_bn_backward(*([None] * 4), 1, None, None, 1, *([None] * 7), 0, *([None] * 6), 0, 4, 4, 64, 64, 27, _lib.WCN_BF16,
+                                  None, 0, None) == -5
     # parameter validation happens before any launch: bad arguments come back as status codes
     assert L.wcn_hash_prepare(None, 16, None) == -5
     assert L.wcn_hash_prepare(None, 17, None) == -5

@@ -64,6 +64,10 @@ SIGNATURES = {
                                      c_void_p]),
     "wcn_bn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                       c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_conv_bn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                     c_size_t, c_void_p]),
     "wcn_pool_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     "wcn_pool_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

@@ -200,6 +200,30 @@ int wcn_conv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_m
   }
 }
 
+// Layer entry: the backward of SparseConv3d -> BatchNorm (-> ReLU / residual tail) in one call - BatchNorm reduce + apply
+// (wcn_bn_train_backward), ABt dgrad on the reverse tables, AtB wgrad.  The host side of a network pays per call.
+int wcn_conv_bn_backward(const void* grad_out, const void* x, const void* y, const void* z, int32_t relu, const float* stats,
+                         const float* gamma, int32_t training, float* sums, void* dy_conv, void* dres, const void* w_packed_dgrad,
+                         const int32_t* rev_nbr, const uint32_t* rev_mask, const int32_t* rev_perm, int32_t flip, void* dx,
+                         const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets, float* dw, void* wgrad_workspace,
+                         size_t wgrad_workspace_bytes, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets,
+                         int32_t dtype, void* bn_workspace, size_t bn_workspace_bytes, wcn_stream_t stream) {
+  if (!dy_conv || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_INVALID_PARAMETERS;
+  int rc = wcn_bn_train_backward(grad_out, y, z, relu, n_out, cout, dtype, stats, gamma, training, sums, dy_conv, dres, bn_workspace,
+                                 bn_workspace_bytes, stream);
+  if (rc != WCN_SUCCESS) return rc;
+  if (dx) {
+    if (!w_packed_dgrad || !rev_nbr || !rev_mask) return WCN_ERROR_INVALID_PARAMETERS;
+    rc = wcn_conv_gather_gemm(dy_conv, w_packed_dgrad, dx, rev_nbr, rev_mask, rev_perm, nullptr, n_out, n_in, cout, cin, num_offsets,
+                              dtype, WCN_ALGO_MFMA, 1, flip, stream);
+    if (rc != WCN_SUCCESS) return rc;
+  }
+  if (dw)
+    rc = wcn_conv_wgrad(x, dy_conv, dw, in_maps, out_maps, offsets, n_in, n_out, cin, cout, num_offsets, dtype, WCN_ALGO_MFMA,
+                        wgrad_workspace, wgrad_workspace_bytes, stream);
+  return rc;
+}
+
 int wcn_mfma_wgrad_bias_supported(int32_t cin, int32_t cout, int32_t dtype) {
   return mfma_wgrad_bias_supported(cin, cout, dtype) ? 1 : 0;
 }

@@ -148,7 +148,7 @@ class _ConvBnAct(Function):
     def backward(ctx, grad_out: Tensor):
         saved = ctx.saved_tensors
         x, w, y, stats, gamma = saved[:5]
-        z = saved[5] if len(saved) > 5 else (y if ctx.has_res else None)  # (no ReLU: only the flag matters)
+        z = saved[5] if len(saved) > 5 else None  # (stored output of a residual tail with ReLU: its sign is the mask)
         plan = ctx.plan
         km, M, cin, cout, K, code = plan.km, plan.num_out, plan.cin, plan.cout, plan.K, plan.code
         L = _lib.lib()
@@ -156,22 +156,33 @@ class _ConvBnAct(Function):
         stream = _lib.stream_handle(dev)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_dres = ctx.has_res and ctx.needs_input_grad[5]
-        dyc, sums, dres = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw, z if ctx.has_res else None, need_dres)
-        dx = dw = None
+        if km._has_duplicates or not (need_dx or need_dw):
+            # repeated coordinates (the general path's pair-list dgrad), or nothing behind the BatchNorm: the passes one by one
+            dyc, sums, dres = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw, z if ctx.has_res else None, need_dres)
+            dx = hip_gemm.hip_dgrad(dyc, w, km, plan.num_in, "auto") if need_dx else None
+            dw = hip_gemm.hip_wgrad(x, dyc, km, (K, cin, cout), "auto").to(w.dtype) if need_dw else None
+            dgamma, dbeta = _affine_grads(ctx, sums)
+            ctx.plan = None
+            return dx, dw, dgamma, dbeta, None, dres
+        # one C call: BatchNorm reduce + apply -> dgrad on the reverse tables -> wgrad (wcn_conv_bn_backward)
+        g = grad_out.contiguous()
+        if g.dtype != y.dtype:
+            g = g.to(y.dtype)
+        masked = z is not None and plan.relu
+        sums = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        dyc = torch.empty_like(y)
+        dres = torch.empty_like(y) if (masked and need_dres) else None
+        tbl = msk = perm = wpd = dx = None
+        flip = False
         if need_dx:
-            if km._has_duplicates:  # (repeated coordinates: the general path's pair-list formulation)
-                dx = hip_gemm.hip_dgrad(dyc, w, km, plan.num_in, "auto")
+            if km._symmetric:
+                tbl, msk, perm, flip = km._nbr, km._mask, km._perm, True
             else:
-                if km._symmetric:
-                    tbl, msk, perm, flip = km._nbr, km._mask, km._perm, True
-                else:
-                    tbl, msk, perm = reverse_tables(km, plan.num_in)
-                    flip = False
-                wpd = hip_gemm.pack_weight(w, True, flip, dtype=y.dtype)
-                dx = torch.empty((plan.num_in, cin), dtype=y.dtype, device=dev)
-                _lib.check(L.wcn_conv_gather_gemm(_lib.ptr(dyc), _lib.ptr(wpd), _lib.ptr(dx), _lib.ptr(tbl), _lib.ptr(msk),
-                                                  _lib.ptr(perm), None, M, plan.num_in, cout, cin, K, code, _lib.WCN_ALGO_MFMA, 1,
-                                                  int(flip), stream), "wcn_conv_gather_gemm")
+                tbl, msk, perm = reverse_tables(km, plan.num_in)
+            wpd = hip_gemm.pack_weight(w, True, flip, dtype=y.dtype)
+            dx = torch.empty((plan.num_in, cin), dtype=y.dtype, device=dev)
+        dw = wws = None
+        ws_bytes = 0
         if need_dw:
             slot = getattr(w, "_wcn_grad_slot", None)
             if slot is not None and w.grad is None and slot.dtype == torch.float32 and slot.shape == w.shape:
@@ -180,11 +191,17 @@ class _ConvBnAct(Function):
                 dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
             ws_bytes = hip_gemm._wgrad_workspace(K, cin, cout, _lib.WCN_ALGO_MFMA)
             wws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.check(L.wcn_conv_wgrad(_lib.ptr(x), _lib.ptr(dyc), _lib.ptr(dw), _lib.ptr(km.in_maps_device),
-                                        _lib.ptr(km.out_maps_device), _lib.ptr(km._offsets_dev), plan.num_in, M, cin, cout, K,
-                                        code, _lib.WCN_ALGO_MFMA, _lib.ptr(wws), ws_bytes, stream), "wcn_conv_wgrad")
-            if dw.dtype != w.dtype:
-                dw = dw.to(w.dtype)
+        bws = _bn_workspace(cout, dev)
+        _lib.check(L.wcn_conv_bn_backward(
+            _lib.ptr(g), _lib.ptr(x), _lib.ptr(y), _lib.ptr(z) if masked else None, int(plan.relu), stats.data_ptr(), _lib.ptr(gamma),
+            int(plan.training), sums.data_ptr(), _lib.ptr(dyc), _lib.ptr(dres), _lib.ptr(wpd), _lib.ptr(tbl), _lib.ptr(msk),
+            _lib.ptr(perm), int(flip), _lib.ptr(dx), _lib.ptr(km.in_maps_device) if need_dw else None,
+            _lib.ptr(km.out_maps_device) if need_dw else None, _lib.ptr(km._offsets_dev) if need_dw else None, _lib.ptr(dw),
+            _lib.ptr(wws), ws_bytes, plan.num_in, M, cin, cout, K, code, _lib.ptr(bws), bws.numel(), stream), "wcn_conv_bn_backward")
+        if need_dres and not masked:
+            dres = g
+        if dw is not None and dw.dtype != w.dtype:
+            dw = dw.to(w.dtype)
         dgamma, dbeta = _affine_grads(ctx, sums)
         ctx.plan = None
         return dx, dw, dgamma, dbeta, None, dres
