@@ -18,7 +18,6 @@ What is different is how a block runs, not what it computes:
 * ``use_checkpoint``: activation checkpointing per block through ``torch.utils.checkpoint`` (non-reentrant) with the BatchNorm
   buffers of the block restored after the recomputation, as the reference's mixin does (`mink_unet.py:92-112`).
 """
-import os
 from contextlib import contextmanager, nullcontext
 from typing import Optional, Union
 
@@ -103,9 +102,8 @@ class _Checkpointed(nn.Module):
     def _residual_tail(self, out: Voxels, last: ConvBlock, identity: Voxels) -> Voxels:
         """``relu(last(out) + identity)``: through the fused node when ``last`` is conv -> BatchNorm without activation."""
         conv, norm, act = last[0], last[1], last[2]
-        # (WARPCONVNET_AMD_FUSED_BLOCK=noresidual: A/B switch - fused conv -> BatchNorm nodes, the tail as separate modules)
-        if (type(act) is nn.Identity and type(self.relu) is nn.ReLU and os.environ.get("WARPCONVNET_AMD_FUSED_BLOCK") != "noresidual"
-                and not (_has_hooks(conv) or _has_hooks(norm) or _has_hooks(self.relu) or _has_hooks(last))):
+        if type(act) is nn.Identity and type(self.relu) is nn.ReLU and not (_has_hooks(conv) or _has_hooks(norm) or
+                                                                          _has_hooks(self.relu) or _has_hooks(last)):
             y = conv_bn_act(out, conv, norm, True, residual=identity)
             if y is not None:
                 return y

@@ -9,7 +9,6 @@ ranges + ordered slab reduction, deterministic): ~15 us.  Channel counts outside
 next multiple of 32 for that one product.
 """
 import functools
-import os
 from typing import Optional
 
 import torch
@@ -58,9 +57,6 @@ def dense_wgrad(x: Tensor, dy: Tensor) -> Tensor:
 
 @functools.lru_cache(maxsize=None)
 def _identity_ok(cin: int, cout: int, code: int) -> bool:
-    # WARPCONVNET_AMD_POINTWISE_GATHER=0: keep the vendor GEMM for every 1 x 1 x 1 product (A/B switch, tools/ab_unet.sh)
-    if os.environ.get("WARPCONVNET_AMD_POINTWISE_GATHER", "1") == "0":
-        return False
     return bool(_lib.lib().wcn_conv_identity_supported(cin, cout, code))
 
 
