@@ -251,3 +251,42 @@ def test_minkunet14_module_matches_its_module_by_module_run():
     cgrads, cbuf = run(ck)
     for u, v in zip(a + abuf, cgrads + cbuf):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("freeze", ["weight", "input", "both"])
+def test_fused_node_with_frozen_weight_or_input(freeze):
+    """`wcn_conv_bn_backward` skips the products nobody asked for: a frozen convolution weight (no wgrad), an input that does not
+    require grad (no dgrad), both (BatchNorm sums only) - the gradients that remain equal the module chain's bit for bit."""
+    import copy
+
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sequential import Sequential
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = torch.device("cuda:0")
+    c = scene_u(6000, 74)[:, 1:]
+    torch.manual_seed(3)
+    fused = Sequential(SparseConv3d(64, 96, 3, bias=False), nn.BatchNorm1d(96), nn.ReLU()).to(dev)
+    chain = copy.deepcopy(fused)
+    chain[0].register_forward_hook(lambda m, i, o: None)
+    feats = torch.randn(len(c), 64, device=dev)
+    res = []
+    for net in (fused, chain):
+        net[0].weight.requires_grad_(freeze not in ("weight", "both"))
+        x = Voxels([torch.from_numpy(c)], [feats], device=dev)
+        x = x.replace(batched_features=x.feature_tensor.detach().clone().requires_grad_(freeze not in ("input", "both")))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(x)
+        g = torch.randn(y.feature_tensor.shape, device=dev, generator=torch.Generator(dev).manual_seed(7)).to(y.feature_tensor.dtype)
+        net.zero_grad(set_to_none=True)
+        y.feature_tensor.backward(g)
+        xg = x.batched_features.batched_tensor.grad
+        res.append((y.feature_tensor.detach().clone(), xg, net[0].weight.grad, net[1].weight.grad.clone(), net[1].bias.grad.clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert (a[1] is None) == (freeze in ("input", "both")) and (b[1] is None) == (a[1] is None)
+    assert (a[2] is None) == (freeze in ("weight", "both")) and (b[2] is None) == (a[2] is None)
+    if a[1] is not None:
+        assert torch.equal(a[1], b[1])
+    if a[2] is not None:
+        assert torch.equal(a[2], b[2])
