@@ -290,3 +290,39 @@ def test_fused_node_with_frozen_weight_or_input(freeze):
         assert torch.equal(a[1], b[1])
     if a[2] is not None:
         assert torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("name", ["MinkUNet18", "MinkUNet50"])
+def test_minkunet_family_runs_and_matches_the_module_chain(name):
+    """The deeper members of `models.mink_unet` (two BasicBlocks per stage; BottleneckBlocks with 1 x 1 x 1 convolutions and a
+    residual tail behind a pointwise layer): logits and every parameter gradient with the fused nodes equal the
+    WARPCONVNET_AMD_FUSED_BLOCK=0 run bit for bit, gradients finite and non-zero."""
+    import copy
+    import os
+
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.models import mink_unet
+
+    dev = torch.device("cuda:0")
+    c = scene_u(12000, 75)[:, 1:]
+    torch.manual_seed(4)
+    net = getattr(mink_unet, name)(3, 7).to(dev)
+    feats = torch.randn(len(c), 3, device=dev)
+
+    def run(model):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(Voxels([torch.from_numpy(c)], [feats], device=dev))
+        y.feature_tensor.float().square().mean().backward()
+        return [y.feature_tensor.detach().clone()] + [p.grad.clone() for p in model.parameters()]
+
+    a = run(copy.deepcopy(net))
+    os.environ["WARPCONVNET_AMD_FUSED_BLOCK"] = "0"
+    try:
+        b = run(copy.deepcopy(net))
+    finally:
+        del os.environ["WARPCONVNET_AMD_FUSED_BLOCK"]
+    assert a[0].shape == (len(c), 7)
+    for u, v in zip(a, b):
+        assert torch.isfinite(u).all() and torch.equal(u, v)
+    assert sum(float(g.abs().sum()) > 0 for g in a[1:]) > 0.9 * (len(a) - 1)
