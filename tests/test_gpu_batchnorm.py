@@ -162,12 +162,14 @@ def test_fused_conv_bn_relu_block_equals_the_module_chain(cin, cout, ksize, stri
         assert a[-1] == b[-1]
 
 
+@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,block", [(64, 64, "BasicBlock"), (96, 128, "BasicBlock"), (128, 128, "BottleneckBlock")])
-def test_residual_tail_equals_the_module_chain(cin, cout, block):
+def test_residual_tail_equals_the_module_chain(cin, cout, block, amp):
     """`models.mink_unet.BasicBlock`: conv2's BatchNorm, `out += identity` and the ReLU (reference `mink_unet.py:160-172`) ride
     on the fused node's two BatchNorm passes (`wcn_bn_apply_residual`, `wcn_bn_backward_*_masked`).  With hooks on conv2 the same
     block runs its modules one by one: outputs, every gradient (input - both branches meet there -, weights, BatchNorm
-    parameters) and the running statistics are bit-identical, in training and in eval mode.  (A bottleneck's last convolution is
+    parameters) and the running statistics are bit-identical, in training and in eval mode, under bf16 and fp16 autocast (fp16:
+    the fp32 affine result must be rounded in a separate step in EVERY kernel - `bn_affine`'s barrier against v_fma_mixlo_f16).  (A bottleneck's last convolution is
     1 x 1 x 1: it keeps the module chain, the test pins that it still computes the same.)"""
     import copy
 
@@ -193,7 +195,7 @@ def test_residual_tail_equals_the_module_chain(cin, cout, block):
                 net.train(mode == "train")
                 x = Voxels([torch.from_numpy(c)], [feats], device=dev)
                 x = x.replace(batched_features=x.feature_tensor.detach().clone().requires_grad_(True))
-                with torch.autocast("cuda", dtype=torch.bfloat16):
+                with torch.autocast("cuda", dtype=amp):
                     y = net(x)
                 g = torch.randn(y.feature_tensor.shape, device=dev, generator=torch.Generator(dev).manual_seed(5)).to(y.feature_tensor.dtype)
                 net.zero_grad(set_to_none=True)

@@ -54,7 +54,16 @@ template <typename T, int VEC> struct alignas(sizeof(T) * VEC) NVec { T v[VEC]; 
 // y = x * scale + shift as ONE fused multiply-add, in the forward pass and wherever the backward passes need to know whether
 // the ReLU behind it let a value through: the mask (stored y > 0) is recomputed from x with the very same operation instead
 // of reading the forward output again (a third of the backward passes' traffic).
-__device__ __forceinline__ float bn_affine(float xf, float sc, float sh) { return __builtin_fmaf(xf, sc, sh); }
+__device__ __forceinline__ float bn_affine(float xf, float sc, float sh) {
+  float f = __builtin_fmaf(xf, sc, sh);
+  // The fp32 result is materialised before anything rounds it to the storage type.  Without the barrier the compiler fuses the
+  // fma with a following fp16 conversion into v_fma_mixlo_f16 (ONE rounding of the exact result) in some kernels and not in
+  // others (fp32 fma, then v_cvt_f16_f32: two roundings) - 1 ulp apart in ~1 of 40 000 elements, i.e. the passes that must
+  // agree on "what the forward stored" (the residual tail vs the plain apply, the backward's recomputed ReLU mask) did not for
+  // fp16 (tools/soak_models.py).  bf16 has no such instruction and was never affected.
+  asm volatile("" : "+v"(f));
+  return f;
+}
 template <typename T>
 __device__ __forceinline__ bool bn_relu_passes(float xf, float sc, float sh) {
   return NCvt<T>::ld(NCvt<T>::st(fmaxf(bn_affine(xf, sc, sh), 0.f))) > 0.f;  // what the forward stored, compared with zero
@@ -260,6 +269,8 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       float f = bn_affine(NCvt<T>::ld(xv.v[v]), s_coef[ch0 + v], s_coef[c + ch0 + v]);
+      // round, then add in fp32 and round again: what the framework's elementwise add of two 16-bit tensors does (for fp16 the
+      // fp32 sum is exact enough that this equals one rounding of the exact sum - checked on 84 M pairs)
       if (res) f = NCvt<T>::ld(NCvt<T>::st(NCvt<T>::ld(NCvt<T>::st(f)) + NCvt<T>::ld(rv.v[v])));
       if (relu) f = fmaxf(f, 0.f);
       yv.v[v] = NCvt<T>::st(f);
