@@ -328,3 +328,35 @@ def test_minkunet_family_runs_and_matches_the_module_chain(name):
     for u, v in zip(a, b):
         assert torch.isfinite(u).all() and torch.equal(u, v)
     assert sum(float(g.abs().sum()) > 0 for g in a[1:]) > 0.9 * (len(a) - 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_recomputed_relu_mask_is_the_stored_outputs_sign(dtype):
+    """The backward passes never read the forward's output: the ReLU mask is recomputed from x and the scale / shift the forward
+    applied, with the same fma and the same rounding to the storage type.  Property: with dy = 1 the masked column sums equal the
+    count of positive stored outputs per channel EXACTLY, on values crowded around the threshold (a 1-ulp disagreement between
+    two kernels' roundings - the fp16 fma + convert fusion `bn_affine` guards against - shows up here)."""
+    from warpconvnet_amd import _lib
+
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    st = _lib.stream_handle(dev)
+    code = _lib.dtype_code(dtype)
+    n, c = 200_000, 64
+    for seed in range(3):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        x = (torch.randn(n, c, device=dev, generator=g) * 0.05).to(dtype)
+        scale = torch.rand(c, device=dev, generator=g) + 0.5
+        shift = torch.randn(c, device=dev, generator=g) * 0.01
+        y = torch.empty_like(x)
+        _lib.check(L.wcn_bn_apply(_lib.ptr(x), n, c, code, _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(y), st), "wcn_bn_apply")
+        dy = torch.ones_like(x)
+        mean, rstd = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        s0, s1 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        ws = torch.empty(L.wcn_bn_workspace(c), dtype=torch.uint8, device=dev)
+        _lib.check(L.wcn_bn_backward_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), n, c, code, _lib.ptr(mean),
+                                            _lib.ptr(rstd), _lib.ptr(s0), _lib.ptr(s1), _lib.ptr(ws), ws.numel(), st),
+                   "wcn_bn_backward_reduce")
+        want = (y > 0).sum(0).float()
+        assert 0.3 * n < float(want.min()) and float(want.max()) < 0.7 * n  # (the threshold runs through the data)
+        assert torch.equal(s0, want)
