@@ -65,6 +65,10 @@ def test_pure_host_entry_points(hip_lib):
     # ABI 3 additions: identity-map dense products, residual-tail BatchNorm passes
     assert L.wcn_abi_version() >= 3
     assert L.wcn_conv_identity_supported(96, 128, _lib.WCN_BF16) == 1 and L.wcn_conv_identity_supported(128, 256, _lib.WCN_F16) == 1
+    # every shape the identity-map / channel-split path announces is one wcn_conv_gather_gemm accepts (320 = 5 x 64 was not)
+    for cin, cout in ((64, 320), (128, 384), (96, 512), (256, 192)):
+        assert L.wcn_conv_identity_supported(cin, cout, _lib.WCN_BF16) == 1
+        assert L.wcn_mfma_gather_supported(cin, cout, 1, _lib.WCN_BF16) == 1 and L.wcn_mfma_gather_supported(cin, cout, 27, _lib.WCN_F16) == 1
     assert L.wcn_conv_identity_supported(48, 64, _lib.WCN_BF16) == 0 and L.wcn_conv_identity_supported(96, 20, _lib.WCN_BF16) == 0
     assert L.wcn_conv_identity_supported(64, 64, _lib.WCN_F32) == 0
     assert L.wcn_bn_apply_residual(None, None, 4, 8, _lib.WCN_BF16, None, None, 1, None, None) == -5

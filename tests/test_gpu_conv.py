@@ -611,7 +611,8 @@ def test_generative_convolution_module(transposed, ksize, stride):
 
 @pytest.mark.parametrize("n", [1, 127, 70001])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cin,cout", [(64, 64), (96, 128), (128, 96), (256, 128), (160, 64), (128, 256), (192, 192), (64, 80)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (96, 128), (128, 96), (256, 128), (160, 64), (128, 256), (192, 192), (64, 80),
+                                      (128, 320)])
 def test_dense_rows_through_the_identity_map(cin, cout, dtype, n):
     """wcn_conv_gather_gemm with nbr = mask = NULL and one offset (include/wcn.h: wcn_conv_identity_supported) is the dense
     product of a 1 x 1 x 1 convolution: x @ w and dy @ w.T vs fp64 on the same 16-bit values, within one rounding of the

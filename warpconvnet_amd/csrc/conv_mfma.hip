@@ -588,6 +588,7 @@ bool mfma32_shape(int cin, int cout) {
 }
 
 bool mfma_gather_supported(int cin, int cout, int K, int dtype) {
+  if (gather_gemm_cs_supported(cin, cout, K, dtype)) return true;  // (incl. outputs in column blocks: 320 = 5 x 64, 384, 512 ...)
   if (mfma16_supported(cin, cout, K, dtype)) return true;
   if (dtype != WCN_F16 && dtype != WCN_BF16) return false;
   if (K < 1 || K > kMaxK) return false;
