@@ -3,6 +3,7 @@ same inputs): forward, input / weight / bias gradients, running statistics, fuse
 fast path."""
 import copy
 
+import numpy as np
 import pytest
 import torch
 import torch.nn as nn
@@ -360,3 +361,47 @@ def test_recomputed_relu_mask_is_the_stored_outputs_sign(dtype):
         want = (y > 0).sum(0).float()
         assert 0.1 * n < float(want.min()) and float(want.max()) < 0.9 * n  # (the threshold runs through the data)
         assert torch.equal(s0, want)
+
+
+@pytest.mark.parametrize("case", ["duplicates", "table_full"])
+def test_fused_node_on_scenes_the_optimistic_build_rejects(case):
+    """The fused conv -> BatchNorm -> ReLU node queues its gather GEMM on the tables of an optimistic build: (i) duplicate
+    coordinates whose later copy comes first (rebuild with the strict insert, and the backward takes the pair-list dgrad of the
+    general path), (ii) a scene too sparse for the first block table (TABLE_FULL rebuild).  Hints reset so the branches are taken;
+    outputs, gradients and running statistics equal the module chain's bit for bit."""
+    import copy
+
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import default_hints
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sequential import Sequential
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(18)
+    if case == "table_full":
+        cells = rng.permutation(36 * 36 * 36)[:24000]
+        c = np.stack([cells // 1296 * 8 + 7 * (cells % 2), cells // 36 % 36 * 8, cells % 36 * 8], 1).astype(np.int32)
+    else:
+        base = scene_u(5000, 32)[:, 1:]
+        c = np.concatenate([base[:400][::-1], base], 0).astype(np.int32)
+    torch.manual_seed(5)
+    fused = Sequential(SparseConv3d(64, 128, 3, bias=False), nn.BatchNorm1d(128), nn.ReLU()).to(dev)
+    chain = copy.deepcopy(fused)
+    chain[0].register_forward_hook(lambda m, i, o: None)
+    feats = torch.randn(len(c), 64)
+    res = []
+    for net in (fused, chain):
+        default_hints().reset()
+        vox = Voxels([torch.from_numpy(c)], [feats], device=dev)
+        x = vox.replace(batched_features=vox.feature_tensor.detach().clone().requires_grad_(True))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(x)
+        g = torch.randn(y.feature_tensor.shape, device=dev, generator=torch.Generator(dev).manual_seed(9)).to(y.feature_tensor.dtype)
+        net.zero_grad(set_to_none=True)
+        y.feature_tensor.backward(g)
+        km = next(iter(x.cache.values()))
+        assert km._has_duplicates == (case == "duplicates")
+        res.append([y.feature_tensor.detach().clone(), x.batched_features.batched_tensor.grad.clone(), net[0].weight.grad.clone(),
+                    net[1].weight.grad.clone(), net[1].bias.grad.clone(), net[1].running_mean.clone(), net[1].running_var.clone()])
+    for u, v in zip(*res):
+        assert torch.isfinite(u.float()).all() and torch.equal(u, v)
