@@ -832,3 +832,44 @@ def test_weight_gradient_lands_in_the_gradient_bucket_slot():
     assert torch.allclose(conv.weight.grad, 2 * ref_w, rtol=1e-6, atol=0)
     buckets.remove()
     assert not hasattr(conv.weight, "_wcn_grad_slot")
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_a_weight_used_twice_in_one_graph_sums_its_gradients_under_gradient_buckets(fused, monkeypatch):
+    """One conv (plain module, and inside the fused conv -> BN -> ReLU node) applied TWICE in a graph, gradients None,
+    buckets attached: `.grad` is None when both weight-gradient nodes run, so only the first may write into the bucket
+    slot (`dist.claim_grad_slot`); the second writes a fresh tensor and the engine adds them.  Expected = the same graph
+    without buckets (advisor finding, round 4: N x the last gradient instead of the sum)."""
+    from warpconvnet_amd.dist import GradientBuckets
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sequential import Sequential
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    monkeypatch.setenv("WARPCONVNET_AMD_FUSED_BLOCK", "1" if fused else "0")
+    dev = _dev()
+    c = scene_u(3000, 77)[:, 1:]
+    torch.manual_seed(1)
+    conv = SparseConv3d(64, 64, 3, bias=False).to(dev)
+    net = Sequential(conv, torch.nn.BatchNorm1d(64), torch.nn.ReLU()).to(dev) if fused else conv
+    feats = torch.randn(len(c), 64, device=dev)
+    g = torch.randn(len(c), 64, device=dev).bfloat16()
+
+    def run():
+        x = Voxels([torch.from_numpy(c)], [feats], device=dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(net(x))  # the same weight feeds two nodes of this graph
+        y.feature_tensor.backward(g.to(y.feature_tensor.dtype))
+
+    run()
+    ref = conv.weight.grad.clone()
+    assert ref.abs().max() > 0
+    for p in net.parameters():
+        p.grad = None
+    buckets = GradientBuckets(net.parameters())
+    buckets.zero_grad()
+    buckets._buckets[0]["flat"].fill_(float("nan"))
+    run()
+    buckets.finish()
+    assert torch.allclose(conv.weight.grad, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
+    assert not getattr(conv.weight, "_wcn_grad_claimed", False)
+    buckets.remove()

@@ -119,6 +119,37 @@ def test_strided_layers_from_the_cell_table(ksize, stride, prebuild):
     assert km.identity_map_index is None and not km._symmetric
 
 
+def test_tables_cached_on_a_coordinate_tensor_do_not_survive_an_in_place_edit():
+    """A submanifold build leaves its cell table on the coordinate tensor and a down-sampling pass leaves the kernel map of
+    its stride window on the output tensor (`cell_handle.py`).  Both are keyed to the tensor's CONTENT: after ``coords.add_``
+    (an augmentation shift between two layers) the strided layer must answer for the shifted coordinates - the reference
+    keys its maps per call (helper.py:446-459) and never sees a stale table."""
+    from warpconvnet_amd.geometry.coords.ops.stride import stride_coords
+    from warpconvnet_amd.geometry.coords.search.cell_handle import cells_of, stride_map_of
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+    s = np.concatenate([scene_u(6000, 3, 0), scene_u(5000, 4, 1)], 0).astype(np.int32)
+    a = torch.from_numpy(s).to(_dev())
+    generate_kernel_map(a, a, (1, 1, 1), (3, 3, 3))
+    assert cells_of(a) is not None
+    a[:, 1:].add_(1)  # a shift by one cell changes every coarse cell's membership
+    assert cells_of(a) is None and getattr(a, "_wcn_cells", None) is None
+    shifted = s.copy()
+    shifted[:, 1:] += 1
+    want, _ = okmap.stride_coords(shifted, (2, 2, 2))
+    got, _ = stride_coords(a, (2, 2, 2), num_batches=2, with_map=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    km = generate_kernel_map(a, got, (2, 2, 2), (2, 2, 2))
+    _check_against_oracle(km, shifted, want, (2, 2, 2), (2, 2, 2))
+    # ... and the map written next to the output coordinates dies with an edit of either side
+    assert stride_map_of(got, a) is not None
+    a[:, 1:].add_(2)
+    assert stride_map_of(got, a) is None
+    shifted[:, 1:] += 2
+    km = generate_kernel_map(a, got, (2, 2, 2), (2, 2, 2))
+    _check_against_oracle(km, shifted, want, (2, 2, 2), (2, 2, 2))
+
+
 def test_strided_first_layer_table_grows_and_range_errors_surface():
     """Down-sampling that builds its own cell table: a scene with one voxel per 8^3 block overflows the first-try block bound
     (TABLE_FULL -> larger table, remembered in the hints) and still gives the oracle's coordinates; a coordinate outside

@@ -74,6 +74,21 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, averag
     return calls
 
 
+def claim_grad_slot(param) -> Optional[torch.Tensor]:
+    """The bucket slot of ``param`` for ONE producer per backward pass, else None.
+
+    A weight-gradient kernel may write into the slot instead of a fresh tensor only if it is the first producer for this
+    parameter in this backward pass: with the parameter used by several nodes of one graph (weight tying, a block applied
+    twice, siamese branches) ``param.grad`` is still None when every node runs - AccumulateGrad fires after ALL producers -
+    so a second writer would overwrite the first and the engine would sum two aliases of the same memory (N x the last
+    gradient instead of the sum).  The claim is released by the post-accumulate hook, ``finish()`` and ``zero_grad()``."""
+    slot = getattr(param, "_wcn_grad_slot", None)
+    if slot is None or param.grad is not None or getattr(param, "_wcn_grad_claimed", False):
+        return None
+    param._wcn_grad_claimed = True
+    return slot
+
+
 class GradientBuckets:
     """Persistent flat gradient buckets with the all-reduce overlapped with the rest of the backward pass.
 
@@ -83,6 +98,8 @@ class GradientBuckets:
     * the view is also published as ``param._wcn_grad_slot``: a producer that can write its result anywhere - the sparse
       convolution's weight-gradient kernels - writes STRAIGHT into the bucket when ``param.grad is None`` and hands autograd an
       alias of the slot, which the engine adopts as ``.grad`` (no ``grad += dw`` launch per parameter, no copy by the hook).
+      Only the FIRST producer of a parameter per backward pass gets the slot (``claim_grad_slot``); a parameter used twice
+      in one graph has its further gradients written to fresh tensors and summed by the engine as usual.
       ``zero_grad()`` therefore sets the gradients to None by default (``set_to_none=False`` zero-fills in place);
     * buckets are filled in REVERSE parameter order (the order the backward pass produces gradients) and a bucket's
       all-reduce is launched from the autograd hook of its last gradient, asynchronously, so RCCL works over xGMI while
@@ -159,6 +176,7 @@ class GradientBuckets:
 
     @torch.no_grad()
     def _hook(self, p):
+        p._wcn_grad_claimed = False  # every producer of this backward pass has run
         bi, vi = self._where[id(p)]
         b = self._buckets[bi]
         v = b["views"][vi]
@@ -202,11 +220,14 @@ class GradientBuckets:
         for p in self.params:
             if hasattr(p, "_wcn_grad_slot"):
                 del p._wcn_grad_slot
+            p._wcn_grad_claimed = False
 
     @torch.no_grad()
     def finish(self) -> int:
         """Launch what is left (zeros for parameters without a gradient this iteration), wait, average.  Returns the
         number of collectives of this iteration."""
+        for p in self.params:
+            p._wcn_grad_claimed = False
         for b in self._buckets:
             if not b["launched"]:
                 for p, v in zip(b["params"], b["views"]):
@@ -233,6 +254,8 @@ class GradientBuckets:
         the weight gradients of the sparse convolutions straight into their bucket slots, every other gradient is moved in by
         the hook, parameters without a gradient contribute zeros (``finish``).  False: zero the buckets in place and keep the
         views attached (gradient accumulation across ``no_sync()`` micro-steps needs neither)."""
+        for p in self.params:
+            p._wcn_grad_claimed = False
         if set_to_none:
             for p in self.params:
                 p.grad = None

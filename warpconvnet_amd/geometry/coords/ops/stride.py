@@ -23,6 +23,7 @@ def _stride_coords_from_cells(bcoords: Tensor, stride: Tuple[int, ...], num_batc
 
     from warpconvnet_amd import _lib
 
+    from warpconvnet_amd.geometry.coords.search.cell_handle import attach_cells, attach_stride_map, cells_of
     from warpconvnet_amd.geometry.coords.search.packed_hashmap import PackedHashTable
     from warpconvnet_amd.geometry.coords.search.torch_discrete import default_hints
 
@@ -34,7 +35,7 @@ def _stride_coords_from_cells(bcoords: Tensor, stride: Tuple[int, ...], num_batc
     flags = torch.empty(max(1, (n + 63) // 64), dtype=torch.int64, device=dev)
     counts = torch.empty(ntile + 1, dtype=torch.int32, device=dev)
     meta = torch.zeros(num_batches + 2, dtype=torch.int32, device=dev)  # [out_offsets (B + 1) | status of a table built here]
-    cells = getattr(bcoords, "_wcn_cells", None)
+    cells = cells_of(bcoords)  # None once the tensor has been edited in place since the build
     hints = default_hints()
     while True:
         built = cells is None
@@ -61,7 +62,7 @@ def _stride_coords_from_cells(bcoords: Tensor, stride: Tuple[int, ...], num_batc
         PackedHashTable.raise_for_flags(status, n, 2 * n)
         break
     if built:
-        bcoords._wcn_cells = cells  # complete and validated: later layers on this tensor reuse it
+        attach_cells(bcoords, *cells)  # complete and validated: later layers on this tensor reuse it
     offsets = host[: num_batches + 1].clone()
     m = int(offsets[-1])
     out = torch.empty((m, 4), dtype=torch.int32, device=dev)
@@ -74,7 +75,7 @@ def _stride_coords_from_cells(bcoords: Tensor, stride: Tuple[int, ...], num_batc
                                        _lib.ptr(out), None, _lib.ptr(nbr), _lib.ptr(mask), stream), "wcn_cells_stride_emit")
     if nbr is not None:
         # the kernel map of a convolution with kernel_size == stride is exactly these cells: generate_kernel_map picks it up
-        out._wcn_stride_map = (bcoords.data_ptr(), n, tuple(int(v) for v in stride), nbr, mask)
+        attach_stride_map(out, bcoords, stride, nbr, mask)
     return out, offsets
 
 
@@ -95,9 +96,7 @@ def stride_coords(batch_indexed_coords: Tensor, stride: Tuple[int, ...], order=N
     order = to_point_ordering(order)
     if (num_batches is not None and order == POINT_ORDERING.RANDOM and batch_indexed_coords.is_cuda
             and batch_indexed_coords.shape[1] == 4 and batch_indexed_coords.shape[0] > 0
-            and batch_indexed_coords.dtype == torch.int32 and batch_indexed_coords.is_contiguous()
-            and (getattr(batch_indexed_coords, "_wcn_cells", None) is None
-                 or batch_indexed_coords._wcn_cells[1] == batch_indexed_coords.shape[0])):
+            and batch_indexed_coords.dtype == torch.int32 and batch_indexed_coords.is_contiguous()):
         from warpconvnet_amd import _lib
 
         if _lib.lib().wcn_cells_stride_supported(_lib.i3(stride)):

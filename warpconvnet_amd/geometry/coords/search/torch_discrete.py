@@ -16,6 +16,7 @@ from warpconvnet_amd.utils.compile_guard import eager_unless_compiling
 from torch import Tensor
 
 from warpconvnet_amd import _lib
+from warpconvnet_amd.geometry.coords.search.cell_handle import attach_cells, cells_of, stride_map_of
 from warpconvnet_amd.geometry.coords.search.packed_hashmap import PackedHashTable, _next_power_of_2
 from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
 from warpconvnet_amd.utils.ntuple import ntuple
@@ -298,13 +299,11 @@ def generate_kernel_map(
     # table the down-sampling pass wrote next to the output coordinates
     cells = prebuilt = None
     if not use_binned and N > 0 and M > 0 and os.environ.get("WARPCONVNET_AMD_KMAP_METHOD", "auto").strip().lower() != "hash":
-        c = getattr(batch_indexed_in_coords, "_wcn_cells", None)
-        if c is not None and c[1] == N:
-            cells = c
-        pm = getattr(batch_indexed_out_coords, "_wcn_stride_map", None)
-        if (pm is not None and pm[0] == in_coords.data_ptr() and pm[1] == N and pm[2] == tuple(stride) == tuple(ksize)
-                and all(d == 1 for d in dilation) and pm[3].shape[0] == M):
-            prebuilt = (pm[3], pm[4])
+        cells = cells_of(batch_indexed_in_coords)  # ignored once the tensor has been edited in place (`cell_handle.py`)
+        pm = stride_map_of(batch_indexed_out_coords, batch_indexed_in_coords, in_coords)
+        if (pm is not None and pm[0] == tuple(stride) == tuple(ksize) and all(d == 1 for d in dilation)
+                and pm[1].shape[0] == M):
+            prebuilt = (pm[1], pm[2])
 
     def launch():
         """Queue one build (tables + tally + scans + mask sort) on the current stream; nothing waits."""
@@ -427,10 +426,9 @@ def generate_kernel_map(
         if use_binned and not (flags & (_lib.WCN_FLAG_TABLE_FULL | _lib.WCN_FLAG_NEED_STRICT)):
             # the cell table of this coordinate set is complete and keeps the smallest row of every coordinate: strided
             # layers on the same tensor reuse it (down-sampling and their kernel maps, coords/ops/stride.py)
-            handle = (b["keep"][0], N, b["max_blocks"])
-            in_coords._wcn_cells = handle
+            attach_cells(in_coords, b["keep"][0], N, b["max_blocks"])
             if batch_indexed_in_coords is not in_coords and batch_indexed_in_coords.data_ptr() == in_coords.data_ptr():
-                batch_indexed_in_coords._wcn_cells = handle
+                attach_cells(batch_indexed_in_coords, b["keep"][0], N, b["max_blocks"])
         attach_tables(result, b)
         result._offsets = offsets_host
         result.identity_map_index = identity

@@ -27,6 +27,7 @@ from torch import Tensor
 from torch.autograd import Function
 
 from warpconvnet_amd import _lib
+from warpconvnet_amd.dist import claim_grad_slot
 from warpconvnet_amd.geometry.coords.search.torch_discrete import reverse_tables
 from warpconvnet_amd.nn.functional.normalizations import _workspace as _bn_workspace
 from warpconvnet_amd.nn.functional.normalizations import bn_module_state
@@ -185,7 +186,11 @@ class _ConvBnAct(Function):
         ws_bytes = 0
         if need_dw:
             slot = getattr(w, "_wcn_grad_slot", None)
-            if slot is not None and w.grad is None and slot.dtype == torch.float32 and slot.shape == w.shape:
+            if slot is not None and slot.dtype == torch.float32 and slot.shape == w.shape:
+                slot = claim_grad_slot(w)  # first producer of this parameter in this backward pass only
+            else:
+                slot = None
+            if slot is not None:
                 dw = slot.detach()  # data parallelism: straight into the gradient bucket (dist.GradientBuckets)
             else:
                 dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
@@ -301,6 +306,12 @@ def conv_bn_act(x, conv, norm, relu: bool, residual=None, out_spatial=None):
         return None
     if not norm.training and (norm.running_mean is None or norm.running_var is None):
         return None
+    # the kernels read gamma / beta (and, in eval, the running statistics) as `const float*`: anything else - a module cast
+    # with `.half()`, a non-contiguous view after a checkpoint load - goes the general way, which converts (`_HipBatchNorm`)
+    raw_f32 = [norm.weight, norm.bias] + ([] if norm.training else [norm.running_mean, norm.running_var])
+    for t in raw_f32:
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != raw.device):
+            return None
     cin, cout = conv.in_channels, conv.out_channels
     K = conv.weight.shape[0]
     code = _lib.dtype_code(dtype)
@@ -347,14 +358,18 @@ def conv_bn_act(x, conv, norm, relu: bool, residual=None, out_spatial=None):
         feats = feats.to(dtype)
     feats = feats.contiguous()
     plan.km, plan.num_in, plan.num_out = km, feats.shape[0], M
-    (plan.training, plan.momentum, plan.eps, plan.running_mean, plan.running_var, plan.counter,
-     plan.fused_running) = bn_module_state(norm, feats)
+    res = None
     if residual is not None:
         res = residual.feature_tensor if isinstance(residual, Voxels) else residual
-        if res.shape != (M, cout) or not res.is_cuda:
+        if res.shape != (M, cout) or res.device != feats.device:
             return None
         if res.dtype != dtype:
             res = res.to(dtype)
+    # every `return None` is above this line: bn_module_state() bumps `num_batches_tracked` when the kernel cannot, and a
+    # bail-out after it would count the batch twice (the modules then run one by one)
+    (plan.training, plan.momentum, plan.eps, plan.running_mean, plan.running_var, plan.counter,
+     plan.fused_running) = bn_module_state(norm, feats)
+    if res is not None:
         out = _ConvBnAct.apply(feats, conv.weight, norm.weight, norm.bias, plan, res.contiguous())
     else:
         out = _ConvBnAct.apply(feats, conv.weight, norm.weight, norm.bias, plan)

@@ -14,6 +14,7 @@ import torch
 from torch import Tensor
 from torch.autograd import Function
 
+from warpconvnet_amd.dist import claim_grad_slot
 from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
 from warpconvnet_amd.utils.ntuple import _pad_values
 
@@ -117,6 +118,8 @@ class UnifiedSpatiallySparseConvFunction(Function):
             if slot is not None and (weight.grad is not None or not need_dw or ctx.groups != 1 or slot.dtype != torch.float32
                                      or ctx.weight_dtype != torch.float32 or slot.shape != weight.shape):
                 slot = None
+            if slot is not None:
+                slot = claim_grad_slot(weight)  # first producer of this parameter in this backward pass only
 
             def _ctx(needs, want_db=False):
                 b = BwdCtx(grad_output, in_features, weight, ctx.kernel_map, ctx.num_out_coords, ctx.compute_dtype,
