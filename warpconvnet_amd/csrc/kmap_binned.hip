@@ -32,7 +32,9 @@
 
 namespace wcn {
 
-constexpr int kInsertSample = 16;  // cell_insert<0>: 1 voxel in 16 goes first (see the kernel)
+constexpr int kInsertSample = 8;  // cell_insert<0>: 1 voxel in 8 goes first (see the kernel; 16 left 1.6 % of the blocks of a 64-voxel-per-block
+// scene to the second pass, whose creation path is the expensive one: uniform 1 M scene 58.5 -> 53.4 us for the three insert launches, surface
+// scene 92 -> 76 us; 4 costs the sampled pass more than it saves: 60 / 70 us)
 constexpr int kInsertThreads = 512;
 constexpr int kNbThreads = 256;    // cell_neighbors: up to 4 independent waves per workgroup (fewer when the LDS grid is large)
 
