@@ -106,6 +106,30 @@ def test_minkunet14_hip_vs_explicit(monkeypatch):
     ref_grad_norm = {n: float(p.grad.float().norm()) for n, p in net.named_parameters() if p.grad is not None}
     net.set_algo("auto")
     net.zero_grad()
+    # ... with the FUSED conv -> BatchNorm (-> ReLU / residual tail) nodes on, and every node's own convolution - its raw
+    # output, and in the backward the input / weight gradients it returns for the gradient that reached it - held against the
+    # fp64 oracle on the node's own inputs: the fused path is tied to the oracle directly, not only through bit-identity with
+    # the module chain (tests/test_gpu_batchnorm.py)
+    import warpconvnet_amd.nn.functional.sparse_conv.block as block
+
+    node_errs = []
+
+    def observe(phase, t):
+        km = t["km"]
+        i, o, off = km.in_maps.cpu().numpy(), km.out_maps.cpu().numpy(), km.offsets.numpy()
+        dt = t["x"].dtype
+        xd, wd = t["x"].double().cpu(), t["w"].to(dt).double().cpu()
+        if phase == "forward":
+            want = oconv.forward(xd, wd, i, o, off, t["num_out"])
+            node_errs.append(("fwd", rel_max_err(t["y"], want), tuple(t["w"].shape)))
+        else:
+            dxr, dwr = oconv.backward(t["dy"].double().cpu(), xd, wd, i, o, off)
+            if t["dx"] is not None:
+                node_errs.append(("dgrad", rel_max_err(t["dx"], dxr), tuple(t["w"].shape)))
+            if t["dw"] is not None:
+                node_errs.append(("wgrad", rel_max_err(t["dw"], dwr), tuple(t["w"].shape)))
+
+    monkeypatch.setattr(block, "_OBSERVER", observe)
     x2 = vox.replace(batched_features=vox.feature_tensor.detach().clone())
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y2 = net(x2)
@@ -116,6 +140,10 @@ def test_minkunet14_hip_vs_explicit(monkeypatch):
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
         if ref_grad_norm[n] > 0:
             assert 0.3 < float(p.grad.float().norm()) / ref_grad_norm[n] < 3.0, n
+    # the fused nodes that carry a gather GEMM (1 x 1 x 1 convolutions take the pointwise node): forward, dgrad and wgrad each
+    kinds = {k for k, _, _ in node_errs}
+    assert kinds == {"fwd", "dgrad", "wgrad"} and len(node_errs) >= 40, (len(node_errs), kinds)
+    assert max(e for _, e, _ in node_errs) < 2e-2, sorted(node_errs, key=lambda t: t[1])[-3:]
 
 
 def test_minkunet14_map_structure():

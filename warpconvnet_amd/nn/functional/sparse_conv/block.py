@@ -35,6 +35,12 @@ from warpconvnet_amd.nn.functional.normalizations import bn_module_state
 from .detail import hip_gemm
 
 
+# Test instrumentation: a callable ``(phase, tensors: dict)`` that sees the convolution INSIDE every fused node - its inputs and
+# its raw output in the forward, the gradient that reaches it and the gradients it returns in the backward - so that the tests can
+# hold each node's three GEMMs against the fp64 oracle on the node's own inputs (tests/test_gpu_minkunet.py).  None in production.
+_OBSERVER = None
+
+
 class _Plan:
     """Per-call constants of one fused block (plain attributes: cheaper than threading a dozen Function arguments)."""
 
@@ -134,6 +140,8 @@ class _ConvBnAct(Function):
         launch()
         if km.validate():  # an optimistic map whose build the device rejected: rebuilt - repeat on the new tables
             launch()
+        if _OBSERVER is not None:
+            _OBSERVER("forward", dict(x=x, w=w, km=km, y=y, num_in=plan.num_in, num_out=M))
         out, stats = _bn_forward(plan, y, gamma, beta, residual)
         ctx.has_res = residual is not None
         if ctx.has_res and plan.relu:
@@ -162,6 +170,8 @@ class _ConvBnAct(Function):
             dyc, sums, dres = _bn_backward(plan, grad_out, y, stats, gamma, need_dx or need_dw, z if ctx.has_res else None, need_dres)
             dx = hip_gemm.hip_dgrad(dyc, w, km, plan.num_in, "auto") if need_dx else None
             dw = hip_gemm.hip_wgrad(x, dyc, km, (K, cin, cout), "auto").to(w.dtype) if need_dw else None
+            if _OBSERVER is not None:
+                _OBSERVER("backward", dict(x=x, w=w, km=km, dy=dyc, dx=dx, dw=dw, num_in=plan.num_in, num_out=M))
             dgamma, dbeta = _affine_grads(ctx, sums)
             ctx.plan = None
             return dx, dw, dgamma, dbeta, None, dres
@@ -207,6 +217,8 @@ class _ConvBnAct(Function):
             dres = g
         if dw is not None and dw.dtype != w.dtype:
             dw = dw.to(w.dtype)
+        if _OBSERVER is not None:
+            _OBSERVER("backward", dict(x=x, w=w, km=km, dy=dyc, dx=dx, dw=dw, num_in=plan.num_in, num_out=M))
         dgamma, dbeta = _affine_grads(ctx, sums)
         ctx.plan = None
         return dx, dw, dgamma, dbeta, None, dres
