@@ -230,6 +230,14 @@ int wcn_kmap_from_csr(const int32_t* in_maps, const int32_t* out_maps, const int
 size_t wcn_mask_argsort_workspace(int64_t n);
 int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int32_t num_bits, int64_t n, int32_t* perm,
                      void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+/* The row order the gather GEMMs cut into tiles (and the `perm` wcn_kmap_tally_sort writes): a tile runs one step per offset ANY of
+ * its rows has, so rows are grouped to keep the UNION of a tile's masks small.  Odd kernel volumes K = 2c + 1 <= 31: stable sort
+ * by a key of the same width as the mask - mirror-image offsets (k, K-1-k) paired, "which pairs" in the high half, "which member"
+ * in the low half, ranked in reflected-Gray order (csrc/mask_sort.h) - 8.8 -> 7.2 steps per 128-row tile on the uniform 1 M scene,
+ * unchanged on surface-like scenes.  Any other volume: wcn_mask_argsort.  The GEMM results do not depend on the order.
+ * Role of the reference's mask_argsort inside its mask-GEMM path (mask_gemm.py:127-254).  workspace: wcn_mask_argsort_workspace. */
+int wcn_mask_tile_order(const uint32_t* mask, int32_t mask_words, int32_t num_offsets, int64_t n, int32_t* perm,
+                        void* workspace, size_t workspace_bytes, wcn_stream_t stream);
 
 /* ---- sparse convolution GEMMs ------------------------------------------------------------------
  * Forward  (AB gather-scatter):  y[m]  = sum_k x[nbr[m][k]] . w[k]            w: [K, Cin, Cout]

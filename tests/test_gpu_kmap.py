@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import kmap as okmap
-from tests.util import scene_surface, scene_u, sort_buckets
+from tests.util import scene_surface, scene_u, sort_buckets, tile_key
 
 pytestmark = pytest.mark.gpu
 
@@ -38,12 +38,39 @@ def _check_against_oracle(km, in_np, out_np, ksize, stride=(1, 1, 1), dilation=(
     np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
     np.testing.assert_array_equal(km.out_maps.cpu().numpy(), r["out_maps"])
     np.testing.assert_array_equal(km._mask.cpu().numpy().view(np.uint32), r["mask"])
-    # permutation: a permutation of all rows, masks non-increasing along it
+    # permutation: a permutation of all rows in the tile order of the gather GEMMs - the stable descending sort by `tile_key`
+    # (odd kernel volumes up to 31: pair / Gray key; else the mask word itself, i.e. the reference's mask_argsort order)
     perm = km._perm.cpu().numpy()
     assert sorted(perm.tolist()) == list(range(len(out_np)))
-    m0 = r["mask"][:, 0][perm].astype(np.int64)
-    assert (np.diff(m0) <= 0).all()
+    key = tile_key(r["mask"][:, 0], K) if r["mask"].shape[1] == 1 else r["mask"][:, 0].astype(np.int64)
+    np.testing.assert_array_equal(perm, np.argsort(-key, kind="stable"))
     return r
+
+
+@pytest.mark.parametrize("K", [27, 9, 25, 31, 3, 8, 32, 26])
+def test_row_orders_of_the_c_abi(K):
+    """wcn_mask_argsort keeps the reference's order (descending mask, stable: mask_data_kernels.cu:187-220); wcn_mask_tile_order
+    is the stable descending sort by `tile_key` (tests/util.py restates csrc/mask_sort.h) for odd volumes up to 31 and the
+    same as wcn_mask_argsort otherwise.  Ragged size: the last sort tile is partial."""
+    from warpconvnet_amd import _lib
+
+    rng = np.random.default_rng(K)
+    n = 70_001
+    dense = rng.random((n, K)) < rng.choice([0.1, 0.4], size=(n, 1))  # a sparse and a dense population
+    m = (dense * (1 << np.arange(K, dtype=np.int64))).sum(1).astype(np.uint32)
+    if K % 2 == 1:
+        m |= np.uint32(1 << (K // 2))
+    mask = torch.from_numpy(m.view(np.int32)).to(_dev()).view(n, 1)
+    L = _lib.lib()
+    ws = torch.empty(L.wcn_mask_argsort_workspace(n), dtype=torch.uint8, device=_dev())
+    perm = torch.empty(n, dtype=torch.int32, device=_dev())
+    stream = _lib.stream_handle(_dev())
+    _lib.check(L.wcn_mask_argsort(_lib.ptr(mask), 1, min(K, 32), n, _lib.ptr(perm), _lib.ptr(ws), ws.numel(), stream), "argsort")
+    np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(-m.astype(np.int64), kind="stable"))
+    _lib.check(L.wcn_mask_tile_order(_lib.ptr(mask), 1, K, n, _lib.ptr(perm), _lib.ptr(ws), ws.numel(), stream), "tile order")
+    np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(-tile_key(m, K), kind="stable"))
+    if K in (8, 32, 26):
+        np.testing.assert_array_equal(tile_key(m, K), m.astype(np.int64))
 
 
 @pytest.fixture(params=["binned", "hash"])

@@ -44,3 +44,25 @@ def sort_buckets(in_maps, out_maps, offsets):
         order = np.lexsort((in_maps[s:e], out_maps[s:e]))
         in_maps[s:e], out_maps[s:e] = in_maps[s:e][order], out_maps[s:e][order]
     return in_maps, out_maps
+
+
+def tile_key(mask: np.ndarray, num_offsets: int) -> np.ndarray:
+    """numpy restatement of `tile_key` (warpconvnet_amd/csrc/mask_sort.h): the key the builder's row order (`perm`) is sorted by -
+    descending, ties in ascending row order.  Odd kernel volumes K = 2c + 1 <= 31: mirror-image offsets (k, K-1-k) paired, touched
+    pairs in the high half, the low member of each pair in the low half, ranked in reflected-Gray order, centre offset last;
+    any other volume: the mask word itself (the reference's descending-mask order, mask_data_kernels.cu:187-220)."""
+    m = mask.astype(np.int64) & 0xFFFFFFFF
+    K = int(num_offsets)
+    if not (3 <= K <= 31 and K % 2 == 1):
+        return m
+    c = K // 2
+    half = (1 << c) - 1
+    lo = m & half
+    hi = (m >> (c + 1)) & half
+    rh = np.zeros_like(hi)
+    for i in range(c):
+        rh |= ((hi >> (c - 1 - i)) & 1) << i
+    k = ((lo | rh) << c) | lo
+    for s in (1, 2, 4, 8, 16):
+        k ^= k >> s
+    return (k << 1) | ((m >> c) & 1)

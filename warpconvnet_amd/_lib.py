@@ -112,6 +112,7 @@ SIGNATURES = {
     ),
     "wcn_mask_argsort_workspace": (c_size_t, [c_int64]),
     "wcn_mask_argsort": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_mask_tile_order": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wcn_mfma_gather_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
     "wcn_mfma_wgrad_supported": (c_int, [c_int32, c_int32, c_int32]),
     "wcn_conv_identity_supported": (c_int, [c_int32, c_int32, c_int32]),

@@ -31,7 +31,7 @@ size_t wgrad_mfma_workspace(int K, int cin, int cout);
 bool mfma_wgrad_bias_supported(int cin, int cout, int dtype);
 int conv_wgrad_mfma(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                     const int32_t* offsets, int cin, int cout, int K, int dtype, void* workspace, size_t workspace_bytes,
-                    int cs_k, float* bias_grad, hipStream_t s);
+                    int cs_k, float* bias_grad, int64_t pair_bound, hipStream_t s);
 // dwconv.hip
 int dwconv_gather(const void* in, const void* w, void* out, const int32_t* tbl, const float* bias, int64_t n_out, int C,
                   int K, int dtype, int k_flip, hipStream_t s);
@@ -194,7 +194,7 @@ int wcn_conv_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_m
       return conv_wgrad_ref(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, s);
     case WCN_ALGO_MFMA:
       return conv_wgrad_mfma(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, workspace,
-                             workspace_bytes, -1, nullptr, s);
+                             workspace_bytes, -1, nullptr, (int64_t)num_offsets * (n_in < n_out ? n_in : n_out), s);
     default:
       return WCN_ERROR_INVALID_PARAMETERS;
   }
@@ -236,7 +236,7 @@ int wcn_conv_wgrad_bias(const void* x, const void* dy, float* dw, const int32_t*
     return WCN_ERROR_INVALID_PARAMETERS;
   if (self_offset < 0 || self_offset >= num_offsets) return WCN_ERROR_INVALID_PARAMETERS;
   return conv_wgrad_mfma(x, dy, dw, in_maps, out_maps, offsets, cin, cout, num_offsets, dtype, workspace, workspace_bytes,
-                         self_offset, bias_grad, (hipStream_t)stream);
+                         self_offset, bias_grad, (int64_t)num_offsets * (n_in < n_out ? n_in : n_out), (hipStream_t)stream);
 }
 
 int wcn_dwconv_gather(const void* in, const void* w, void* out, const int32_t* nbr, const float* bias, int64_t n_in,

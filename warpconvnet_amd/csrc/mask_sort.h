@@ -14,6 +14,17 @@
 //            are ranked 64 at a time: lanes with equal digits find each other with 9 ballots ("match-any"),
 //            rank = popcount(peers & lower lanes); the running base lives in LDS.  Stable by construction.
 // Descending order = ascending order of the inverted key.
+//
+// TILE ORDER (round 5).  The gather GEMMs cut `perm` into tiles of 64 - 128 rows and run one step per offset that ANY row of
+// the tile has, so what a tile costs is the size of the UNION of its rows' masks.  Plain descending-mask order groups rows by
+// their high offsets and leaves the low ones random inside a tile: 8.8 steps per 128-row tile on the uniform 1 M scene for
+// 4.2 offsets per row.  For odd kernel volumes K = 2c + 1 <= 31 the builder therefore sorts by tile_key(mask) instead - same
+// key width, same passes: offsets are paired with their mirror image (k, K-1-k); the high half of the key says which PAIRS a
+// row touches, the low half which member, and the whole is ranked in reflected-Gray order so that neighbouring keys differ in
+// few bits.  Rows whose neighbours lie in the same few directions become adjacent: 7.2 steps per tile on the uniform scene
+// (-18 %; 64-row tiles 7.8 -> 6.8), 9.08 -> 9.11 on the surface scene, whose rows already share whole masks
+// (tools/sim_tile_order.py).  Results do not depend on the order (a row accumulates its offsets in ascending k either way).
+// wcn_mask_argsort keeps the reference's exact descending-mask semantics (mask_data_kernels.cu:187-220).
 #pragma once
 
 #include "wcn_common.h"
@@ -30,6 +41,23 @@ constexpr size_t kRsScatterLds = (size_t)(kRsWaves * kRsBins + kRsBins + kRsWave
 
 __device__ __forceinline__ uint32_t rs_digit(uint32_t key, int shift) { return ((~key) >> shift) & (kRsBins - 1); }
 
+// centre index c of a kernel volume the tile order applies to (K = 2c + 1 <= 31, one mask word), else 0 = plain mask order
+__host__ __device__ __forceinline__ int tile_key_centre(int num_offsets, int mask_words) {
+#ifdef WCN_TILE_KEY_OFF  // A/B build: the reference's descending-mask order everywhere
+  return 0;
+#endif
+  return (mask_words == 1 && num_offsets >= 3 && num_offsets <= 31 && (num_offsets & 1)) ? num_offsets / 2 : 0;
+}
+__device__ __forceinline__ uint32_t tile_key(uint32_t m, int kc) {
+  if (kc <= 0) return m;
+  const uint32_t half = (1u << kc) - 1u;
+  const uint32_t lo = m & half;                                       // offsets 0 .. c-1
+  const uint32_t rh = __brev((m >> (kc + 1)) & half) >> (32 - kc);    // offsets K-1 .. c+1: bit i = offset K-1-i, the mirror of i
+  uint32_t k = ((lo | rh) << kc) | lo;                                // touched pairs | which member (01 / 11 tie: same pair set)
+  k ^= k >> 1; k ^= k >> 2; k ^= k >> 4; k ^= k >> 8; k ^= k >> 16;   // rank of k in reflected-Gray order
+  return (k << 1) | ((m >> kc) & 1u);                                 // the centre offset last (set in every submanifold row)
+}
+
 enum RsRole { kRsHist = 0, kRsScan = 1, kRsScatter = 2 };
 
 // A pass reads either the mask tensor itself (first pass: keys at `kin[i * stride]`, row id = i) or the (key, row) PAIRS the
@@ -37,6 +65,7 @@ enum RsRole { kRsHist = 0, kRsScan = 1, kRsScatter = 2 };
 // the number of scattered stores (tools/cell_probe.hip: 16 us per million) - or, in the last pass, the row ids alone.
 struct RsArgs {
   const uint32_t* kin;  // first pass only
+  int kc;               // first pass: keys are tile_key(kin[..], kc) (0 = the mask word itself)
   int64_t stride;
   const uint2* pin;     // later passes: (key, row) pairs
   int64_t n;
@@ -67,7 +96,7 @@ SortPlan sort_plan(void* workspace, int64_t n, int num_bits);
 // every launch of the sort, in order (at most 3 per pass); `first_counted`: counts / totals already hold the scanned
 // histogram of the first digit, so the first pass is its scatter alone
 int sort_launches(const SortPlan& plan, const uint32_t* mask, int mask_words, int64_t n, int32_t* perm, bool first_counted,
-                  RsLaunch out[12]);
+                  int kc, RsLaunch out[12]);
 void sort_run_range(const RsLaunch* launches, int begin, int end, hipStream_t stream);
 
 // ---- kernel bodies: `blk` = tile / digit index, `smem` >= 2 KB (hist), 16 B (scan), kRsScatterLds (scatter) ----
@@ -84,7 +113,7 @@ __device__ __forceinline__ void rs_hist_body(const RsArgs& a, int blk, char* sme
   for (int j = 0; j < kPer; ++j) {
     const int64_t idx = base + threadIdx.x + j * kRsThreads;
     const int64_t at = idx < a.n ? idx : a.n - 1;
-    k[j] = a.pin ? a.pin[at].x : a.kin[at * a.stride];
+    k[j] = a.pin ? a.pin[at].x : tile_key(a.kin[at * a.stride], a.kc);
   }
 #pragma unroll
   for (int j = 0; j < kPer; ++j)
@@ -141,7 +170,7 @@ __device__ __forceinline__ void rs_scatter_body(const RsArgs& a, int blk, char* 
       kreg[j] = kv.x;
       vreg[j] = (int32_t)kv.y;
     } else {
-      kreg[j] = a.kin[at * a.stride];
+      kreg[j] = tile_key(a.kin[at * a.stride], a.kc);
       vreg[j] = (int32_t)at;
     }
   }

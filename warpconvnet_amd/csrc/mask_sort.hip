@@ -29,10 +29,11 @@ SortPlan sort_plan(void* workspace, int64_t n, int num_bits) {
 }
 
 int sort_launches(const SortPlan& p, const uint32_t* mask, int mask_words, int64_t n, int32_t* perm, bool first_counted,
-                  RsLaunch out[12]) {
+                  int kc, RsLaunch out[12]) {
   int count = 0;
   RsArgs a;
   a.kin = mask;
+  a.kc = kc;
   a.stride = mask_words;
   a.pin = nullptr;
   a.n = n;
@@ -78,7 +79,20 @@ int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int32_t num_bits,
   if (n >= (1ll << 31) || !mask || !perm || !workspace || workspace_bytes < wcn_mask_argsort_workspace(n))
     return WCN_ERROR_INVALID_PARAMETERS;
   RsLaunch l[12];
-  const int count = sort_launches(sort_plan(workspace, n, num_bits), mask, mask_words, n, perm, false, l);
+  const int count = sort_launches(sort_plan(workspace, n, num_bits), mask, mask_words, n, perm, false, 0, l);
+  sort_run_range(l, 0, count, (hipStream_t)stream);
+  return launch_status();
+}
+
+int wcn_mask_tile_order(const uint32_t* mask, int32_t mask_words, int32_t num_offsets, int64_t n, int32_t* perm,
+                        void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
+  if (n < 0 || mask_words < 1 || num_offsets < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  if (n == 0) return WCN_SUCCESS;
+  if (n >= (1ll << 31) || !mask || !perm || !workspace || workspace_bytes < wcn_mask_argsort_workspace(n))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  RsLaunch l[12];
+  const int count = sort_launches(sort_plan(workspace, n, num_offsets < 32 ? num_offsets : 32), mask, mask_words, n, perm, false,
+                                  tile_key_centre(num_offsets, mask_words), l);
   sort_run_range(l, 0, count, (hipStream_t)stream);
   return launch_status();
 }

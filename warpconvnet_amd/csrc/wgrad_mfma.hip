@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kWgradGrid = 512;   // G: pair ranges (2 workgroups per CU)
+constexpr int kWgradGrid = 512;   // G: pair ranges (2 workgroups per CU) - the upper bound, see wgrad_ranges()
 constexpr int kPairs = 64;        // pairs per pipeline step
 constexpr int kZeroPage = 1024;   // bytes reserved at the start of the workspace (kept for layout compatibility)
 __device__ uint4 g_wgrad_zero_page[64];  // 1 KiB of zeros: source rows of padded pairs (no per-call memset)
@@ -378,10 +378,27 @@ size_t wgrad_mfma_workspace(int K, int cin, int cout) {
   return (size_t)kZeroPage + (size_t)(kWgradGrid + K) * cin * cout * sizeof(float) + (size_t)kWgradGrid * cout * sizeof(float);
 }
 
+// Pair ranges of a launch.  Every range flushes one fp32 [CIT, COT] tile per bucket it touches, and the reduce kernel reads them
+// all back: G + K slabs of cin * cout * 4 B.  512 ranges cost nothing next to a million gathered rows, but at the coarse levels
+// of a U-Net (a few thousand rows, 128 - 256 channels: 141 MB of slabs for ~40 k pairs) the slabs ARE the launch.  So: about
+// 512 pairs per range, never fewer workgroups than two per CU (the (cin, cout) tiles on grid.y count), never more than 512.
+// `pair_bound`: an upper bound of the pair count known on the host (K * rows), 0 = unknown.
+static int wgrad_ranges(int64_t pair_bound, int tiles) {
+#ifdef WCN_WGRAD_FIXED_G  // A/B build: 512 ranges whatever the size
+  return kWgradGrid;
+#endif
+  if (pair_bound <= 0) return kWgradGrid;
+  int64_t g = (pair_bound + 511) / 512;
+  const int64_t g_min = (kWgradGrid + tiles - 1) / tiles;
+  if (g < g_min) g = g_min;
+  if (g > kWgradGrid) g = kWgradGrid;
+  return (int)g;
+}
+
 template <typename T, int CIT, int COT>
 static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                         const int32_t* offsets, int cin, int cout, int K, void* workspace, int cs_k, float* bias_grad,
-                        hipStream_t s) {
+                        int64_t pair_bound, hipStream_t s) {
   typedef Wgrad<T, CIT, COT> W;
   static unsigned long long attr_done = 0ull;  // per device (wcn_common.h)
   const int rc = once_per_device(attr_done, [] {
@@ -408,7 +425,8 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
   }
   float* slabs = (float*)((char*)workspace + kZeroPage);
   float* cs_slabs = slabs + (size_t)(kWgradGrid + K) * cin * cout;
-  const dim3 grid(kWgradGrid, (cin / CIT) * (cout / COT));
+  const int G = wgrad_ranges(pair_bound, (cin / CIT) * (cout / COT));
+  const dim3 grid(G, (cin / CIT) * (cout / COT));
   if (bias_grad) {
     if constexpr (W::GRID) {
       hipLaunchKernelGGL((wgrad_mfma_kernel<T, CIT, COT, true>), grid, dim3(256), W::LDS_BYTES, s, (const T*)x,
@@ -426,26 +444,26 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, const int32_t*
   const unsigned gx = (unsigned)ceil_div(ce, 64);
   if (bias_grad && (int64_t)gx * 4 < cout) return WCN_ERROR_UNSUPPORTED_CONFIG;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, bias_grad ? K + 1 : K), dim3(256), 0, s, (const float*)slabs, offsets, K, ce,
-                     kWgradGrid, dw, (const float*)cs_slabs, cs_k, cout, bias_grad);
+                     G, dw, (const float*)cs_slabs, cs_k, cout, bias_grad);
   return launch_status();
 }
 
 template <typename T, int CIT>
 static int dispatch_wgrad_co(int cot, const void* x, const void* dy, float* dw, const int32_t* in_maps,
                              const int32_t* out_maps, const int32_t* offsets, int cin, int cout, int K, void* workspace,
-                             int cs_k, float* bias_grad, hipStream_t s) {
+                             int cs_k, float* bias_grad, int64_t pair_bound, hipStream_t s) {
   switch (cot) {
-    case 32: return launch_wgrad<T, CIT, 32>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
-    case 64: return launch_wgrad<T, CIT, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
-    case 96: return launch_wgrad<T, CIT, 96>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
-    default: return launch_wgrad<T, CIT, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    case 32: return launch_wgrad<T, CIT, 32>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
+    case 64: return launch_wgrad<T, CIT, 64>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
+    case 96: return launch_wgrad<T, CIT, 96>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
+    default: return launch_wgrad<T, CIT, 128>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
   }
 }
 
 template <typename T>
 static int dispatch_wgrad(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                           const int32_t* offsets, int cin, int cout, int K, void* workspace, int cs_k, float* bias_grad,
-                             hipStream_t s) {
+                          int64_t pair_bound, hipStream_t s) {
   const int cot = wgrad_tile(cout);
   int cit = wgrad_tile(cin);
   // 128 input channels: two 64-wide tiles instead of one 128-wide.  dY is then streamed twice (+43 % algorithmic traffic at
@@ -454,22 +472,22 @@ static int dispatch_wgrad(const void* x, const void* dy, float* dw, const int32_
   // 128 -> 128: 50 -> 31 us.
   if (cit == 128) cit = 64;
   switch (cit) {
-    case 32: return dispatch_wgrad_co<T, 32>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
-    case 64: return dispatch_wgrad_co<T, 64>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
-    case 96: return dispatch_wgrad_co<T, 96>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
-    default: return dispatch_wgrad_co<T, 128>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    case 32: return dispatch_wgrad_co<T, 32>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
+    case 64: return dispatch_wgrad_co<T, 64>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
+    case 96: return dispatch_wgrad_co<T, 96>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
+    default: return dispatch_wgrad_co<T, 128>(cot, x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
   }
 }
 
 int conv_wgrad_mfma(const void* x, const void* dy, float* dw, const int32_t* in_maps, const int32_t* out_maps,
                     const int32_t* offsets, int cin, int cout, int K, int dtype, void* workspace, size_t workspace_bytes,
-                    int cs_k, float* bias_grad, hipStream_t s) {
+                    int cs_k, float* bias_grad, int64_t pair_bound, hipStream_t s) {
   if (!mfma_wgrad_supported(cin, cout, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   if (bias_grad && (!mfma_wgrad_bias_supported(cin, cout, dtype) || cs_k < 0 || cs_k >= K)) return WCN_ERROR_UNSUPPORTED_CONFIG;
   if (!workspace || workspace_bytes < wgrad_mfma_workspace(K, cin, cout)) return WCN_ERROR_INVALID_PARAMETERS;
   if (dtype == WCN_BF16)
-    return dispatch_wgrad<__bf16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
-  return dispatch_wgrad<_Float16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, s);
+    return dispatch_wgrad<__bf16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
+  return dispatch_wgrad<_Float16>(x, dy, dw, in_maps, out_maps, offsets, cin, cout, K, workspace, cs_k, bias_grad, pair_bound, s);
 }
 
 }  // namespace wcn

@@ -56,7 +56,8 @@ def nbr_to_pair_table(nbr: Tensor, num_offsets: int) -> Tensor:
 
 @torch.no_grad()
 def mask_argsort(mask: Tensor, num_offsets: int = 32) -> Tensor:
-    """Rows sorted by descending neighbour mask (word 0), stable."""
+    """Row order for the gather GEMMs' tiles (`wcn_mask_tile_order`): rows with similar neighbour sets adjacent - for odd
+    kernel volumes up to 31 a stable sort by the pair / Gray key of `csrc/mask_sort.h`, else by descending mask word 0."""
     n, mw = mask.shape
     perm = torch.empty(n, dtype=torch.int32, device=mask.device)
     if n == 0:
@@ -65,9 +66,9 @@ def mask_argsort(mask: Tensor, num_offsets: int = 32) -> Tensor:
     ws_bytes = L.wcn_mask_argsort_workspace(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mask.device)
     _lib.check(
-        L.wcn_mask_argsort(_lib.ptr(mask), mw, min(int(num_offsets), 32), n, _lib.ptr(perm), _lib.ptr(ws), ws_bytes,
-                           _lib.stream_handle(mask.device)),
-        "wcn_mask_argsort",
+        L.wcn_mask_tile_order(_lib.ptr(mask), mw, int(num_offsets), n, _lib.ptr(perm), _lib.ptr(ws), ws_bytes,
+                              _lib.stream_handle(mask.device)),
+        "wcn_mask_tile_order",
     )
     return perm
 
