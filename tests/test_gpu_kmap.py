@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import kmap as okmap
-from tests.util import scene_surface, scene_u, sort_buckets, tile_key
+from tests.util import scene_surface, scene_u, sort_buckets, tile_key, tile_order_key
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def _check_against_oracle(km, in_np, out_np, ksize, stride=(1, 1, 1), dilation=(
     # (odd kernel volumes up to 31: pair / Gray key; else the mask word itself, i.e. the reference's mask_argsort order)
     perm = km._perm.cpu().numpy()
     assert sorted(perm.tolist()) == list(range(len(out_np)))
-    key = tile_key(r["mask"][:, 0], K) if r["mask"].shape[1] == 1 else r["mask"][:, 0].astype(np.int64)
+    key = tile_order_key(r["mask"][:, 0], K) if r["mask"].shape[1] == 1 else r["mask"][:, 0].astype(np.int64)
     np.testing.assert_array_equal(perm, np.argsort(-key, kind="stable"))
     return r
 
@@ -50,8 +50,8 @@ def _check_against_oracle(km, in_np, out_np, ksize, stride=(1, 1, 1), dilation=(
 @pytest.mark.parametrize("K", [27, 9, 25, 31, 3, 8, 32, 26])
 def test_row_orders_of_the_c_abi(K):
     """wcn_mask_argsort keeps the reference's order (descending mask, stable: mask_data_kernels.cu:187-220); wcn_mask_tile_order
-    is the stable descending sort by `tile_key` (tests/util.py restates csrc/mask_sort.h) for odd volumes up to 31 and the
-    same as wcn_mask_argsort otherwise.  Ragged size: the last sort tile is partial."""
+    is the stable descending sort by `tile_order_key` (tests/util.py restates csrc/mask_sort.h: `tile_key` for odd volumes up to
+    31, its top 20 bits for volumes above 18) and the same as wcn_mask_argsort otherwise.  Ragged size: the last sort tile is partial."""
     from warpconvnet_amd import _lib
 
     rng = np.random.default_rng(K)
@@ -68,7 +68,7 @@ def test_row_orders_of_the_c_abi(K):
     _lib.check(L.wcn_mask_argsort(_lib.ptr(mask), 1, min(K, 32), n, _lib.ptr(perm), _lib.ptr(ws), ws.numel(), stream), "argsort")
     np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(-m.astype(np.int64), kind="stable"))
     _lib.check(L.wcn_mask_tile_order(_lib.ptr(mask), 1, K, n, _lib.ptr(perm), _lib.ptr(ws), ws.numel(), stream), "tile order")
-    np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(-tile_key(m, K), kind="stable"))
+    np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(-tile_order_key(m, K), kind="stable"))
     if K in (8, 32, 26):
         np.testing.assert_array_equal(tile_key(m, K), m.astype(np.int64))
 

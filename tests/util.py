@@ -66,3 +66,13 @@ def tile_key(mask: np.ndarray, num_offsets: int) -> np.ndarray:
     for s in (1, 2, 4, 8, 16):
         k ^= k >> s
     return (k << 1) | ((m >> c) & 1)
+
+
+def tile_order_key(mask: np.ndarray, num_offsets: int) -> np.ndarray:
+    """What `perm` (wcn_kmap_tally_sort / wcn_mask_tile_order) is sorted by, descending and stable: `tile_key`, and for keys above
+    18 bits its top 20 bits only (two 10-bit radix passes instead of three 9-bit ones: `sort_plan`, csrc/mask_sort.hip)."""
+    K = int(num_offsets)
+    k = tile_key(mask, K)
+    if 3 <= K <= 31 and K % 2 == 1 and K > 18:
+        k = k >> max(K - 20, 0)
+    return k

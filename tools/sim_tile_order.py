@@ -57,6 +57,9 @@ for name, gen in (("uniform", scene_u), ("surface", scene_surface)):
         "Gray rank of the mask": igray(m, 27),
         "Gray rank of (pairs | low member)  = tile_key": tile_key(m, 27),
         "Gray rank of (pairs | both | low member), 39 bits (5 passes)": igray((orr << 26) | ((lo & rh) << 13) | lo, 39),
+        "tile_key, top 22 bits": tile_key(m, 27) >> 5,
+        "tile_key, top 20 bits (2 x 10-bit passes) = the builder's order": tile_key(m, 27) >> 7,
+        "tile_key, top 18 bits (2 x 9-bit passes)": tile_key(m, 27) >> 9,
     }
     print(f"{name}: {len(m)} rows, {np.mean([bin(int(x)).count('1') for x in m[:50000]]):.2f} offsets per row")
     for label, key in cands.items():

@@ -56,11 +56,13 @@ __global__ __launch_bounds__(kTallyThreads) void kmap_tally_kernel(uint32_t* __r
                                                                 int32_t* __restrict__ counts, int32_t* __restrict__ ticket,
                                                                 int nblk_sort, int32_t* __restrict__ dcounts,
                                                                 const int4* __restrict__ coords, CellTable t,
-                                                                uint32_t cmask, int32_t* __restrict__ status, int kc) {
-  __shared__ int s_hist[kRsBins];
+                                                                uint32_t cmask, int32_t* __restrict__ status, int kc,
+                                                                int sort_shift, int sort_bits) {
+  __shared__ int s_hist[kRsMaxBins];
+  const int sort_bins = 1 << sort_bits;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (HIST) {
-    for (int i = tid; i < kRsBins; i += kTallyThreads) s_hist[i] = 0;
+    for (int i = tid; i < sort_bins; i += kTallyThreads) s_hist[i] = 0;
     __syncthreads();
   }
   if (blockIdx.x == 0 && tid == 0) *ticket = 0;  // consumed by the scan launch behind this one
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kTallyThreads) void kmap_tally_kernel(uint32_t* __r
       for (int sb = 0; sb < kTileRows / 64; ++sb) {
         const int64_t row = row0 + sb * 64 + lane;
         const uint32_t bits = (w == mw - 1) ? last[sb] : (row < m ? mask[row * mw + w] : 0u);
-        if (HIST && w == 0 && row < m) atomicAdd(&s_hist[rs_digit(tile_key(bits, kc), 0)], 1);
+        if (HIST && w == 0 && row < m) atomicAdd(&s_hist[rs_digit(tile_key(bits, kc), sort_shift, sort_bits)], 1);
         for (int b = 0; b < kend; ++b) {
           const int c = __popcll(__ballot((bits >> b) & 1u));
           if (lane == b) mine += c;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kTallyThreads) void kmap_tally_kernel(uint32_t* __r
   if (HIST) {
     __syncthreads();
     if ((int)blockIdx.x < nblk_sort)
-      for (int i = tid; i < kRsBins; i += kTallyThreads) dcounts[(int64_t)i * nblk_sort + blockIdx.x] = s_hist[i];
+      for (int i = tid; i < sort_bins; i += kTallyThreads) dcounts[(int64_t)i * nblk_sort + blockIdx.x] = s_hist[i];
   }
 }
 
@@ -405,7 +407,8 @@ size_t wcn_kmap_counts_bytes(int64_t m, int32_t num_offsets) {
 }
 
 static void launch_tally(uint32_t* mask, int32_t* nbr, int64_t m, int K, int32_t* counts, bool hist, int nblk_sort,
-                         int32_t* dcounts, const int32_t* coords, const CellTable* cells, int32_t* status, int kc, hipStream_t s) {
+                         int32_t* dcounts, const int32_t* coords, const CellTable* cells, int32_t* status, int kc, int sort_shift,
+                         int sort_bits, hipStream_t s) {
   const int kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
   const int64_t ntile = wcn_kmap_num_blocks(m);
   int32_t* ticket = counts + (int64_t)K * (ntile + 1);
@@ -415,7 +418,7 @@ static void launch_tally(uint32_t* mask, int32_t* nbr, int64_t m, int K, int32_t
   const uint32_t cmask = cells ? (uint32_t)(cells->capacity - 1) : 0u;
 #define WCN_TALLY(H, R)                                                                                                \
   hipLaunchKernelGGL((kmap_tally_kernel<H, R>), grid, block, 0, s, mask, nbr, m, K, kp, mw, ntile, counts, ticket,       \
-                     nblk_sort, dcounts, (const int4*)coords, t, cmask, status, kc)
+                     nblk_sort, dcounts, (const int4*)coords, t, cmask, status, kc, sort_shift, sort_bits)
   if (hist && cells) WCN_TALLY(true, true);
   else if (hist) WCN_TALLY(true, false);
   else if (cells) WCN_TALLY(false, true);
@@ -424,10 +427,10 @@ static void launch_tally(uint32_t* mask, int32_t* nbr, int64_t m, int K, int32_t
 }
 
 static void launch_scan(int32_t* counts, int64_t ntile, int K, int32_t* offsets, const int32_t* status, int32_t* mirror,
-                        int nblk_sort, int32_t* dcounts, int32_t* dtotals, hipStream_t s) {
+                        int nblk_sort, int32_t* dcounts, int32_t* dtotals, int sort_bins, hipStream_t s) {
   int32_t* totals = counts + (int64_t)K * ntile;
   int32_t* ticket = totals + K;
-  hipLaunchKernelGGL(kmap_scan_kernel, dim3((unsigned)(K + (nblk_sort > 0 ? kRsBins : 0))), dim3(kBkThreads), 0, s, counts,
+  hipLaunchKernelGGL(kmap_scan_kernel, dim3((unsigned)(K + (nblk_sort > 0 ? sort_bins : 0))), dim3(kBkThreads), 0, s, counts,
                      ntile, K, totals, ticket, offsets, status, mirror, dcounts, nblk_sort, dtotals);
 }
 
@@ -435,8 +438,8 @@ int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t
   if (m < 0 || !valid_k(num_offsets)) return WCN_ERROR_INVALID_PARAMETERS;
   if (m == 0) return WCN_SUCCESS;
   if (!mask || !counts) return WCN_ERROR_INVALID_PARAMETERS;
-  launch_tally(const_cast<uint32_t*>(mask), nullptr, m, num_offsets, counts, false, 0, nullptr, nullptr, nullptr, nullptr, 0,
-               (hipStream_t)stream);
+  launch_tally(const_cast<uint32_t*>(mask), nullptr, m, num_offsets, counts, false, 0, nullptr, nullptr, nullptr, nullptr, 0, 0,
+               kRsBits, (hipStream_t)stream);
   return launch_status();
 }
 
@@ -444,7 +447,7 @@ int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t
 static int scan_impl(int32_t* counts, int64_t num_blocks, int32_t K, int32_t* offsets, const int32_t* status,
                      int32_t* mirror, wcn_stream_t stream) {
   if (num_blocks < 0 || (num_blocks & 3) || !valid_k(K) || !offsets || !counts) return WCN_ERROR_INVALID_PARAMETERS;
-  launch_scan(counts, num_blocks, K, offsets, status, mirror, 0, nullptr, nullptr, (hipStream_t)stream);
+  launch_scan(counts, num_blocks, K, offsets, status, mirror, 0, nullptr, nullptr, 0, (hipStream_t)stream);
   return launch_status();
 }
 
@@ -479,15 +482,15 @@ int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_off
       sort_workspace_bytes < wcn_kmap_tally_sort_workspace(m))
     return WCN_ERROR_INVALID_PARAMETERS;
   if (binned_workspace && (!coords || binned_n != m || max_blocks < 1)) return WCN_ERROR_INVALID_PARAMETERS;
-  const SortPlan plan = sort_plan(sort_workspace, m, num_offsets < 32 ? num_offsets : 32);
-  CellTable cells{};
-  if (binned_workspace) cells = carve_cells(binned_workspace, binned_n, max_blocks);
   // rows ordered for the gather GEMMs' tiles: tile_key (mask_sort.h) for odd kernel volumes up to 31, else descending mask
   const int kc = tile_key_centre(num_offsets, wcn_kmap_mask_words(num_offsets));
+  const SortPlan plan = sort_plan(sort_workspace, m, num_offsets < 32 ? num_offsets : 32, kc > 0);
+  CellTable cells{};
+  if (binned_workspace) cells = carve_cells(binned_workspace, binned_n, max_blocks);
   launch_tally(mask, nbr, m, num_offsets, counts, true, plan.nblk, plan.counts, coords, binned_workspace ? &cells : nullptr,
-               status, kc, s);
+               status, kc, plan.shift0, plan.bits, s);
   launch_scan(counts, wcn_kmap_num_blocks(m), num_offsets, offsets, status, host_mirror, plan.nblk, plan.counts,
-              plan.totals, s);
+              plan.totals, 1 << plan.bits, s);
   RsLaunch l[12];
   const int count = sort_launches(plan, mask, wcn_kmap_mask_words(num_offsets), m, perm, true, kc, l);
   sort_run_range(l, 0, count, s);

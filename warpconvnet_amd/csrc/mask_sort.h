@@ -31,15 +31,22 @@
 
 namespace wcn {
 
-constexpr int kRsBits = 9;
+constexpr int kRsBits = 9;                      // digit width of the exact sorts
 constexpr int kRsBins = 1 << kRsBits;
+// Tile order of kernel volumes above 18 offsets (the 3x3x3 kernel: 27 key bits): TWO passes of 10-bit digits over the top 20
+// bits of tile_key instead of three 9-bit passes over all of it.  The Gray-ranked key degrades gently when its low bits are cut
+// (offsets per 128-row tile, uniform / surface 1 M scenes: 27 bits 7.19 / 9.11, 20 bits 7.39 / 9.42, 18 bits 7.47 / 9.98 -
+// tools/sim_tile_order.py) and the GEMMs' time moves by a quarter of the step count, while a pass of the sort (histogram + scan +
+// scatter launches) is 23 us per million rows.
+constexpr int kRsBitsWide = 10;
+constexpr int kRsMaxBins = 1 << kRsBitsWide;
 constexpr int kRsTile = 2048;
 constexpr int kRsThreads = 256;
 constexpr int kRsWaves = kRsThreads / 64;
 constexpr int kRsPerWave = kRsTile / kRsWaves;  // 512 keys, 8 batches of 64
-constexpr size_t kRsScatterLds = (size_t)(kRsWaves * kRsBins + kRsBins + kRsWaves) * 4;
+constexpr size_t rs_scatter_lds(int bits) { return (size_t)(kRsWaves * (1 << bits) + (1 << bits) + kRsWaves) * 4; }
 
-__device__ __forceinline__ uint32_t rs_digit(uint32_t key, int shift) { return ((~key) >> shift) & (kRsBins - 1); }
+__device__ __forceinline__ uint32_t rs_digit(uint32_t key, int shift, int bits) { return ((~key) >> shift) & ((1u << bits) - 1u); }
 
 // centre index c of a kernel volume the tile order applies to (K = 2c + 1 <= 31, one mask word), else 0 = plain mask order
 __host__ __device__ __forceinline__ int tile_key_centre(int num_offsets, int mask_words) {
@@ -69,10 +76,11 @@ struct RsArgs {
   int64_t stride;
   const uint2* pin;     // later passes: (key, row) pairs
   int64_t n;
-  int shift;
+  int shift;            // first key bit of this pass's digit
+  int bits;             // digit width (kRsBits or kRsBitsWide)
   int nblk;
-  int32_t* counts;      // [kRsBins][nblk]
-  int32_t* totals;      // [kRsBins]
+  int32_t* counts;      // [1 << bits][nblk]
+  int32_t* totals;      // [1 << bits]
   uint2* pout;          // all but the last pass
   int32_t* vout;        // last pass: the permutation
 };
@@ -86,23 +94,27 @@ struct RsLaunch {
 struct SortPlan {
   int nblk;           // tiles of kRsTile keys
   int passes;
+  int bits;           // digit width
+  int shift0;         // low key bits no pass looks at (wide plans sort the top passes * bits bits of the key)
   uint2* pbuf[2];     // ping-pong (key, row) pairs
-  int32_t* counts;    // [kRsBins][nblk] per-(digit, tile) counts, scanned in place
-  int32_t* totals;    // [kRsBins] digit totals
+  int32_t* counts;    // [1 << bits][nblk] per-(digit, tile) counts, scanned in place
+  int32_t* totals;    // [1 << bits] digit totals
   size_t bytes;
 };
 
-SortPlan sort_plan(void* workspace, int64_t n, int num_bits);
+// `tile_order`: the plan of a tile_key sort (wide digits over the top bits for keys above 18 bits); else the exact sort
+SortPlan sort_plan(void* workspace, int64_t n, int num_bits, bool tile_order);
 // every launch of the sort, in order (at most 3 per pass); `first_counted`: counts / totals already hold the scanned
 // histogram of the first digit, so the first pass is its scatter alone
 int sort_launches(const SortPlan& plan, const uint32_t* mask, int mask_words, int64_t n, int32_t* perm, bool first_counted,
                   int kc, RsLaunch out[12]);
 void sort_run_range(const RsLaunch* launches, int begin, int end, hipStream_t stream);
 
-// ---- kernel bodies: `blk` = tile / digit index, `smem` >= 2 KB (hist), 16 B (scan), kRsScatterLds (scatter) ----
+// ---- kernel bodies: `blk` = tile / digit index, `smem` >= 4 B << bits (hist), 16 B (scan), rs_scatter_lds(bits) (scatter) ----
 __device__ __forceinline__ void rs_hist_body(const RsArgs& a, int blk, char* smem) {
   int* s_hist = reinterpret_cast<int*>(smem);
-  for (int i = threadIdx.x; i < kRsBins; i += kRsThreads) s_hist[i] = 0;
+  const int bins = 1 << a.bits;
+  for (int i = threadIdx.x; i < bins; i += kRsThreads) s_hist[i] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blk * kRsTile;
   // all of a thread's keys are requested before the first one is used: predicated loads inside the loop are waited for
@@ -117,9 +129,9 @@ __device__ __forceinline__ void rs_hist_body(const RsArgs& a, int blk, char* sme
   }
 #pragma unroll
   for (int j = 0; j < kPer; ++j)
-    if (base + threadIdx.x + j * kRsThreads < a.n) atomicAdd(&s_hist[rs_digit(k[j], a.shift)], 1);
+    if (base + threadIdx.x + j * kRsThreads < a.n) atomicAdd(&s_hist[rs_digit(k[j], a.shift, a.bits)], 1);
   __syncthreads();
-  for (int i = threadIdx.x; i < kRsBins; i += kRsThreads) a.counts[(int64_t)i * a.nblk + blk] = s_hist[i];
+  for (int i = threadIdx.x; i < bins; i += kRsThreads) a.counts[(int64_t)i * a.nblk + blk] = s_hist[i];
 }
 
 // one workgroup per digit: exclusive scan of counts[d][0..nblk) in place, totals[d] = row sum
@@ -150,10 +162,13 @@ __device__ __forceinline__ void rs_scan_body(const RsArgs& a, int digit, char* s
   if (tid == kRsThreads - 1) a.totals[digit] = run;
 }
 
+template <int BITS>
 __device__ __forceinline__ void rs_scatter_body(const RsArgs& a, int blk, char* smem) {
-  int* s_base = reinterpret_cast<int*>(smem);  // [kRsWaves][kRsBins] per-wave digit counts, then running output positions
-  int* s_dstart = s_base + kRsWaves * kRsBins;  // first output position of every digit (scan of the digit totals)
-  int* s_wsum = s_dstart + kRsBins;
+  constexpr int BINS = 1 << BITS;
+  constexpr int kPerT = BINS / kRsThreads;  // digits per thread (2 or 4)
+  int* s_base = reinterpret_cast<int*>(smem);  // [kRsWaves][BINS] per-wave digit counts, then running output positions
+  int* s_dstart = s_base + kRsWaves * BINS;  // first output position of every digit (scan of the digit totals)
+  int* s_wsum = s_dstart + BINS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t wave_begin = (int64_t)blk * kRsTile + (int64_t)wave * kRsPerWave;
   // the wave's 8 x 64 keys (and carried values) are requested up front and kept in registers: the ranking loop below is a
@@ -176,12 +191,17 @@ __device__ __forceinline__ void rs_scatter_body(const RsArgs& a, int blk, char* 
   }
   // ... and so are the digit totals and this block's (digit, block) bases: everything the kernel reads from global memory
   // is in flight at once
-  const int t0 = a.totals[2 * tid], t1 = a.totals[2 * tid + 1];
-  int blk_base[kRsBins / kRsThreads];
+  int tt[kPerT];
 #pragma unroll
-  for (int j = 0; j < kRsBins / kRsThreads; ++j) blk_base[j] = a.counts[(int64_t)(tid + j * kRsThreads) * a.nblk + blk];
-  {  // exclusive scan of the 512 digit totals: 2 per thread, wave scan, 4 wave partials
-    int incl = t0 + t1;
+  for (int j = 0; j < kPerT; ++j) tt[j] = a.totals[kPerT * tid + j];
+  int blk_base[kPerT];
+#pragma unroll
+  for (int j = 0; j < kPerT; ++j) blk_base[j] = a.counts[(int64_t)(tid + j * kRsThreads) * a.nblk + blk];
+  {  // exclusive scan of the digit totals: kPerT consecutive digits per thread, wave scan, 4 wave partials
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPerT; ++j) mine += tt[j];
+    int incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int t = __shfl_up(incl, d);
@@ -189,43 +209,46 @@ __device__ __forceinline__ void rs_scatter_body(const RsArgs& a, int blk, char* 
     }
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
-    int base = incl - (t0 + t1);
+    int base = incl - mine;
     for (int w = 0; w < wave; ++w) base += s_wsum[w];
-    s_dstart[2 * tid] = base;
-    s_dstart[2 * tid + 1] = base + t0;
+#pragma unroll
+    for (int j = 0; j < kPerT; ++j) {
+      s_dstart[kPerT * tid + j] = base;
+      base += tt[j];
+    }
   }
-  for (int i = tid; i < kRsWaves * kRsBins; i += kRsThreads) s_base[i] = 0;
+  for (int i = tid; i < kRsWaves * BINS; i += kRsThreads) s_base[i] = 0;
   __syncthreads();
   // phase 1: digit counts of this wave's sub-tile
 #pragma unroll
   for (int j = 0; j < kBatches; ++j)
-    if (wave_begin + j * 64 + lane < a.n) atomicAdd(&s_base[wave * kRsBins + rs_digit(kreg[j], a.shift)], 1);
+    if (wave_begin + j * 64 + lane < a.n) atomicAdd(&s_base[wave * BINS + rs_digit(kreg[j], a.shift, BITS)], 1);
   __syncthreads();
   // phase 2: counts -> starting positions (global base of (digit, block) + waves before this one)
 #pragma unroll
-  for (int j = 0; j < kRsBins / kRsThreads; ++j) {
+  for (int j = 0; j < kPerT; ++j) {
     const int d = tid + j * kRsThreads;
     int run = s_dstart[d] + blk_base[j];
 #pragma unroll
     for (int w = 0; w < kRsWaves; ++w) {
-      const int c = s_base[w * kRsBins + d];
-      s_base[w * kRsBins + d] = run;
+      const int c = s_base[w * BINS + d];
+      s_base[w * BINS + d] = run;
       run += c;
     }
   }
   __syncthreads();
   // phase 3: rank 64 keys at a time, in order
-  volatile int* my_base = s_base + wave * kRsBins;
+  volatile int* my_base = s_base + wave * BINS;
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int j = 0; j < kBatches; ++j) {
     const int64_t idx = wave_begin + j * 64 + lane;
     const bool live = idx < a.n;
     const uint32_t key = kreg[j];
-    const uint32_t d = live ? rs_digit(key, a.shift) : 0u;
+    const uint32_t d = live ? rs_digit(key, a.shift, BITS) : 0u;
     unsigned long long peers = __ballot(live);
 #pragma unroll
-    for (int b = 0; b < kRsBits; ++b) {
+    for (int b = 0; b < BITS; ++b) {
       const bool bit = (d >> b) & 1u;
       const unsigned long long ball = __ballot(bit);
       peers &= bit ? ball : ~ball;
@@ -245,7 +268,8 @@ template <int ROLE>
 __device__ __forceinline__ void rs_body(const RsArgs& a, int blk, char* smem) {
   if (ROLE == kRsHist) rs_hist_body(a, blk, smem);
   else if (ROLE == kRsScan) rs_scan_body(a, blk, smem);
-  else rs_scatter_body(a, blk, smem);
+  else if (a.bits == kRsBitsWide) rs_scatter_body<kRsBitsWide>(a, blk, smem);
+  else rs_scatter_body<kRsBits>(a, blk, smem);
 }
 
 }  // namespace wcn

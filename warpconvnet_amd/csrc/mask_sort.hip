@@ -11,7 +11,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_kernel(RsArgs a) {
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-SortPlan sort_plan(void* workspace, int64_t n, int num_bits) {
+SortPlan sort_plan(void* workspace, int64_t n, int num_bits, bool tile_order) {
   SortPlan p;
   p.nblk = (int)ceil_div(n > 0 ? n : 1, kRsTile);
   char* ws = (char*)workspace;
@@ -19,12 +19,20 @@ SortPlan sort_plan(void* workspace, int64_t n, int num_bits) {
   p.pbuf[0] = (uint2*)ws;
   p.pbuf[1] = (uint2*)(ws ? ws + seg : nullptr);
   p.counts = (int32_t*)(ws ? ws + 2 * seg : nullptr);
-  p.totals = p.counts ? p.counts + (int64_t)kRsBins * p.nblk : nullptr;
-  // only the low `num_bits` bits of word 0 can be set (num_bits = min(K, 32)): 3 passes for a 3x3x3 kernel
+  p.totals = p.counts ? p.counts + (int64_t)kRsMaxBins * p.nblk : nullptr;
+  // only the low `num_bits` bits of word 0 can be set (num_bits = min(K, 32)): 3 passes of an exact sort for a 3x3x3 kernel
   if (num_bits > 32) num_bits = 32;
   if (num_bits < 1) num_bits = 1;
-  p.passes = (num_bits + kRsBits - 1) / kRsBits;
-  p.bytes = 2 * seg + al256((size_t)kRsBins * (p.nblk + 1) * 4) + 256;
+  if (tile_order && num_bits > 2 * kRsBits) {  // the tile order of the gather GEMMs: top 20 key bits, two wide passes (mask_sort.h)
+    p.bits = kRsBitsWide;
+    p.passes = 2;
+    p.shift0 = num_bits > 2 * kRsBitsWide ? num_bits - 2 * kRsBitsWide : 0;
+  } else {
+    p.bits = kRsBits;
+    p.passes = (num_bits + kRsBits - 1) / kRsBits;
+    p.shift0 = 0;
+  }
+  p.bytes = 2 * seg + al256((size_t)kRsMaxBins * (p.nblk + 1) * 4) + 256;
   return p;
 }
 
@@ -34,6 +42,7 @@ int sort_launches(const SortPlan& p, const uint32_t* mask, int mask_words, int64
   RsArgs a;
   a.kin = mask;
   a.kc = kc;
+  a.bits = p.bits;
   a.stride = mask_words;
   a.pin = nullptr;
   a.n = n;
@@ -41,13 +50,13 @@ int sort_launches(const SortPlan& p, const uint32_t* mask, int mask_words, int64
   a.counts = p.counts;
   a.totals = p.totals;
   for (int pass = 0; pass < p.passes; ++pass) {
-    a.shift = pass * kRsBits;
+    a.shift = p.shift0 + pass * p.bits;
     const bool last = pass == p.passes - 1;
     a.pout = last ? nullptr : p.pbuf[pass & 1];
     a.vout = last ? perm : nullptr;  // the last pass writes the permutation alone
     if (!(pass == 0 && first_counted)) {
       out[count++] = RsLaunch{kRsHist, p.nblk, a};
-      out[count++] = RsLaunch{kRsScan, kRsBins, a};
+      out[count++] = RsLaunch{kRsScan, 1 << p.bits, a};
     }
     out[count++] = RsLaunch{kRsScatter, p.nblk, a};
     a.pin = a.pout;
@@ -58,9 +67,9 @@ int sort_launches(const SortPlan& p, const uint32_t* mask, int mask_words, int64
 void sort_run_range(const RsLaunch* l, int begin, int end, hipStream_t s) {
   for (int i = begin; i < end; ++i) {
     const dim3 grid((unsigned)l[i].blocks), block(kRsThreads);
-    if (l[i].role == kRsHist) hipLaunchKernelGGL(rs_kernel<kRsHist>, grid, block, (size_t)kRsBins * 4, s, l[i].a);
+    if (l[i].role == kRsHist) hipLaunchKernelGGL(rs_kernel<kRsHist>, grid, block, (size_t)4 << l[i].a.bits, s, l[i].a);
     else if (l[i].role == kRsScan) hipLaunchKernelGGL(rs_kernel<kRsScan>, grid, block, 64, s, l[i].a);
-    else hipLaunchKernelGGL(rs_kernel<kRsScatter>, grid, block, kRsScatterLds, s, l[i].a);
+    else hipLaunchKernelGGL(rs_kernel<kRsScatter>, grid, block, rs_scatter_lds(l[i].a.bits), s, l[i].a);
   }
 }
 
@@ -70,7 +79,7 @@ using namespace wcn;
 
 extern "C" {
 
-size_t wcn_mask_argsort_workspace(int64_t n) { return sort_plan(nullptr, n, 32).bytes; }
+size_t wcn_mask_argsort_workspace(int64_t n) { return sort_plan(nullptr, n, 32, false).bytes; }
 
 int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int32_t num_bits, int64_t n, int32_t* perm,
                      void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
@@ -79,7 +88,7 @@ int wcn_mask_argsort(const uint32_t* mask, int32_t mask_words, int32_t num_bits,
   if (n >= (1ll << 31) || !mask || !perm || !workspace || workspace_bytes < wcn_mask_argsort_workspace(n))
     return WCN_ERROR_INVALID_PARAMETERS;
   RsLaunch l[12];
-  const int count = sort_launches(sort_plan(workspace, n, num_bits), mask, mask_words, n, perm, false, 0, l);
+  const int count = sort_launches(sort_plan(workspace, n, num_bits, false), mask, mask_words, n, perm, false, 0, l);
   sort_run_range(l, 0, count, (hipStream_t)stream);
   return launch_status();
 }
@@ -91,8 +100,9 @@ int wcn_mask_tile_order(const uint32_t* mask, int32_t mask_words, int32_t num_of
   if (n >= (1ll << 31) || !mask || !perm || !workspace || workspace_bytes < wcn_mask_argsort_workspace(n))
     return WCN_ERROR_INVALID_PARAMETERS;
   RsLaunch l[12];
-  const int count = sort_launches(sort_plan(workspace, n, num_offsets < 32 ? num_offsets : 32), mask, mask_words, n, perm, false,
-                                  tile_key_centre(num_offsets, mask_words), l);
+  const int kc = tile_key_centre(num_offsets, mask_words);
+  const int count = sort_launches(sort_plan(workspace, n, num_offsets < 32 ? num_offsets : 32, kc > 0), mask, mask_words, n, perm,
+                                  false, kc, l);
   sort_run_range(l, 0, count, (hipStream_t)stream);
   return launch_status();
 }
