@@ -18,20 +18,31 @@ from torch.autograd import Function
 from warpconvnet_amd import _lib
 from warpconvnet_amd.geometry.coords.search.search_results import IntSearchResult
 
-_IDENTITY_MAPS = {}
+_ARANGE = {}         # device -> int32 arange, grown geometrically: every identity map of a device is a VIEW of it
+_IDENTITY_MAPS = {}  # (n, device) -> map object over a view (a few hundred bytes each; the rows are shared)
+_MAX_CACHED_MAPS = 64
 
 
 def _identity_map(n: int, dev: torch.device) -> IntSearchResult:
-    """Pair list (r, r), r = 0..n-1, as a one-offset kernel map; cached per (n, device) (8 bytes per row)."""
+    """Pair list (r, r), r = 0..n-1, as a one-offset kernel map.  A training loop with a different row count every iteration
+    neither re-creates the rows nor pins one buffer per size: all maps of a device are views of one arange that only grows
+    (4 bytes per row of the largest tensor seen); the map OBJECTS are cached by size and dropped oldest-first."""
     key = (n, str(dev))
     km = _IDENTITY_MAPS.get(key)
-    if km is None:
-        if len(_IDENTITY_MAPS) > 16:
-            _IDENTITY_MAPS.clear()
-        rows = torch.arange(n, dtype=torch.int32, device=dev)
-        km = IntSearchResult(rows, rows, torch.tensor([0, n], dtype=torch.int32))
-        km._offsets_dev = torch.tensor([0, n], dtype=torch.int32, device=dev)
-        _IDENTITY_MAPS[key] = km
+    rows = _ARANGE.get(key[1])
+    if km is not None and rows is not None and km._in_maps.data_ptr() == rows.data_ptr():
+        return km
+    if rows is None or rows.shape[0] < n:
+        rows = torch.arange(max(n, 2 * (rows.shape[0] if rows is not None else 0)), dtype=torch.int32, device=dev)
+        _ARANGE[key[1]] = rows
+        for k in [k for k in _IDENTITY_MAPS if k[1] == key[1]]:  # (views of the old, smaller buffer)
+            del _IDENTITY_MAPS[k]
+    while len(_IDENTITY_MAPS) >= _MAX_CACHED_MAPS:
+        del _IDENTITY_MAPS[next(iter(_IDENTITY_MAPS))]
+    view = rows[:n]
+    km = IntSearchResult(view, view, torch.tensor([0, n], dtype=torch.int32))
+    km._offsets_dev = torch.tensor([0, n], dtype=torch.int32, device=dev)
+    _IDENTITY_MAPS[key] = km
     return km
 
 
