@@ -450,11 +450,12 @@ def make_step(dev, world, coords, feats, grad_out, offsets, conv, params, attach
             buckets.finish()
         # the parameter update of a training step (plain SGD, lr 1e-6): bumps the parameters' version counters, so the packed
         # bf16 weight images are rebuilt next step like in any real training loop (two pack launches per step)
-        # (one multi-tensor launch for weight + bias, the way torch.optim.SGD(foreach=True) - the default on GPU - does it)
+        # (two elementwise launches, 4.5 us each; the multi-tensor form torch.optim.SGD uses - `torch._foreach_add_` - is ONE
+        # launch of 18 us for these two small tensors on this stack: measured, profiles/r05_kernel_trace_stats.md history)
         with torch.no_grad():
-            upd = [p for p in params if p.grad is not None]
-            if upd:
-                torch._foreach_add_(upd, [p.grad for p in upd], alpha=-1e-6)
+            for p in params:
+                if p.grad is not None:
+                    p.add_(p.grad, alpha=-1e-6)
 
     return step, buckets
 
