@@ -275,6 +275,14 @@ int wcn_pack_weight(const void* w, int32_t num_offsets, int32_t cin, int32_t cou
  * framework's cast: one launch instead of cast + pack per convolution and direction. */
 int wcn_pack_weight_f32(const float* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t transpose,
                         int32_t flip, void* packed, size_t packed_bytes, wcn_stream_t stream);
+/* Both images a training step needs - forward (w [K, cin, cout] as is) and dgrad (kernel-side roles exchanged: transposed, and
+ * k-flipped when `flip_dgrad`, i.e. for a submanifold map whose dgrad reads the forward table) - of an fp32 master weight in ONE
+ * launch: an optimizer step invalidates both at once.  Shapes: wcn_pack_weight_pair_supported (both directions on the
+ * channel-split kernels); sizes: wcn_packed_weight_bytes(K, cin, cout, dtype, 0) and (K, cout, cin, dtype, 1). */
+int wcn_pack_weight_pair_supported(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype);
+int wcn_pack_weight_f32_pair(const float* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t flip_dgrad,
+                             void* packed_fwd, size_t packed_fwd_bytes, void* packed_dgrad, size_t packed_dgrad_bytes,
+                             wcn_stream_t stream);
 
 /* y = gather-GEMM over a neighbour table.  Serves forward (x, packed w) and dgrad (dy, packed w^T).
  *   in   [n_in, cin]   out [n_out, cout]   nbr [n_out, kp]   mask [n_out, mw]   perm [n_out] or NULL

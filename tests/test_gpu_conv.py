@@ -121,6 +121,34 @@ def test_wgrad_fused_bias_grad(dtype, cin, cout):
                                 want_bias_grad=True)
     assert dbd is None
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (96, 96), (64, 256), (96, 320)])
+@pytest.mark.parametrize("flip", [False, True])
+def test_forward_and_dgrad_weight_images_in_one_launch(dtype, cin, cout, flip):
+    """wcn_pack_weight_f32_pair: the two images of a training step equal the ones wcn_pack_weight_f32 writes one by one, and
+    `pack_weight(..., dgrad_flip=)` leaves both in the parameter's cache (the backward then packs nothing)."""
+    from warpconvnet_amd import _lib
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    dev = _dev()
+    torch.manual_seed(cin + cout)
+    w = torch.nn.Parameter(torch.randn(27, cin, cout, device=dev))
+    assert _lib.lib().wcn_pack_weight_pair_supported(27, cin, cout, _lib.dtype_code(dtype)) == 1
+    fwd = hip_gemm.pack_weight(w, False, False, dtype=dtype, dgrad_flip=flip)
+    cache = w._wcn_packed
+    assert (dtype, False, False) in cache and (dtype, True, flip) in cache
+    bwd = hip_gemm.pack_weight(w, True, flip, dtype=dtype)
+    assert bwd is cache[(dtype, True, flip)][1]  # served from the cache
+    w2 = torch.nn.Parameter(w.detach().clone())
+    assert torch.equal(fwd.view(torch.int16), hip_gemm.pack_weight(w2, False, False, dtype=dtype).view(torch.int16))
+    assert torch.equal(bwd.view(torch.int16), hip_gemm.pack_weight(w2, True, flip, dtype=dtype).view(torch.int16))
+    # a wrong prediction costs one ordinary pack, never a wrong image
+    other = hip_gemm.pack_weight(w, True, not flip, dtype=dtype)
+    assert torch.equal(other.view(torch.int16), hip_gemm.pack_weight(w2, True, not flip, dtype=dtype).view(torch.int16))
+    with torch.no_grad():
+        w.add_(1.0)  # an optimizer step: both cached images are stale
+    assert not torch.equal(hip_gemm.pack_weight(w, False, False, dtype=dtype, dgrad_flip=flip).view(torch.int16), fwd.view(torch.int16))
+
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("method", ["binned", "hash"])

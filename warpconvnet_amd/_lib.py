@@ -125,6 +125,9 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p],
     ),
+    "wcn_pack_weight_pair_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
+    "wcn_pack_weight_f32_pair": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_size_t,
+                                         c_void_p]),
     "wcn_conv_gather_gemm": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,

@@ -17,6 +17,8 @@ int conv_gather_gemm_mfma(const void* in, const void* wp, void* out, const int32
                           float* out32, hipStream_t s);
 int pack_weight_mfma(const void* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                      hipStream_t s);
+int pack_weight_cs_pair(const float* w, int K, int cin, int cout, int dtype, int flip_dgrad, void* packed_fwd, void* packed_dgrad,
+                        hipStream_t s);
 int pack_weight_mfma_f32(const float* w, int K, int cin, int cout, int dtype, int transpose, int flip, void* packed,
                          hipStream_t s);
 bool mfma_grouped_supported(int cin, int cout, int K, int dtype);
@@ -86,6 +88,21 @@ int wcn_pack_weight_f32(const float* w, int32_t num_offsets, int32_t cin, int32_
   if (!w || !packed || num_offsets < 1 || cin < 1 || cout < 1) return WCN_ERROR_INVALID_PARAMETERS;
   if (packed_bytes < wcn_packed_weight_bytes(num_offsets, cin, cout, dtype, transpose)) return WCN_ERROR_INVALID_PARAMETERS;
   return pack_weight_mfma_f32(w, num_offsets, cin, cout, dtype, transpose, flip, packed, (hipStream_t)stream);
+}
+
+int wcn_pack_weight_pair_supported(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype) {
+  return (gather_gemm_cs_supported(cin, cout, num_offsets, dtype) && gather_gemm_cs_supported(cout, cin, num_offsets, dtype)) ? 1 : 0;
+}
+
+int wcn_pack_weight_f32_pair(const float* w, int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype, int32_t flip_dgrad,
+                             void* packed_fwd, size_t packed_fwd_bytes, void* packed_dgrad, size_t packed_dgrad_bytes,
+                             wcn_stream_t stream) {
+  if (!w || !packed_fwd || !packed_dgrad || num_offsets < 1 || cin < 1 || cout < 1) return WCN_ERROR_INVALID_PARAMETERS;
+  if (!wcn_pack_weight_pair_supported(num_offsets, cin, cout, dtype)) return WCN_ERROR_UNSUPPORTED_CONFIG;
+  if (packed_fwd_bytes < wcn_packed_weight_bytes(num_offsets, cin, cout, dtype, 0) ||
+      packed_dgrad_bytes < wcn_packed_weight_bytes(num_offsets, cout, cin, dtype, 1))
+    return WCN_ERROR_INVALID_PARAMETERS;
+  return pack_weight_cs_pair(w, num_offsets, cin, cout, dtype, flip_dgrad, packed_fwd, packed_dgrad, (hipStream_t)stream);
 }
 
 int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t* nbr, const uint32_t* mask,

@@ -92,9 +92,8 @@ struct CsCfg {
 // Outputs wider than 128 channels: `cout / cob` images of `cob` channels behind each other (column block on grid.y of the
 // main kernel), each the image of w[:, :, cb * cob : (cb + 1) * cob].
 template <typename TS, typename TD>
-__global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__ packed, int K, int cin, int cout, int cob,
-                                      int transpose, int flip) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_weight_cs_element(const TS* __restrict__ w, TD* __restrict__ packed, int64_t e, int K, int cin,
+                                                       int cout, int cob, int transpose, int flip) {
   const int WC = cob / 32, nchunk = (cin + kCsCIC - 1) / kCsCIC;  // a last chunk of 32 channels is zero-padded to 64
   const int64_t image = (int64_t)K * nchunk * kCsCIC * cob;
   if (e >= image * (cout / cob)) return;
@@ -113,6 +112,23 @@ __global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__
   // not transposed: w[kw][ci][co] ([K, cin, cout]); transposed: w is the forward weight [K, cout, cin]
   const int64_t src = transpose ? (((int64_t)kw * cout + co) * cin + ci) : (((int64_t)kw * cin + ci) * cout + co);
   packed[e] = ci < cin ? (TD)w[src] : (TD)0;
+}
+
+template <typename TS, typename TD>
+__global__ void pack_weight_cs_kernel(const TS* __restrict__ w, TD* __restrict__ packed, int K, int cin, int cout, int cob,
+                                      int transpose, int flip) {
+  pack_weight_cs_element(w, packed, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, K, cin, cout, cob, transpose, flip);
+}
+
+// Both images of a training step in ONE launch: blockIdx.y = 0 the forward image of w [K, cin, cout], 1 the dgrad image
+// (kernel-side roles exchanged: reduce over cout, produce cin; transposed, k-flipped for a submanifold map).  An optimizer step
+// invalidates both at once, so every layer of a network saves a launch per iteration.
+template <typename TD>
+__global__ void pack_weight_cs_pair_kernel(const float* __restrict__ w, TD* __restrict__ packed_fwd, TD* __restrict__ packed_dgrad,
+                                           int K, int cin, int cout, int cob_fwd, int cob_dgrad, int flip_dgrad) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.y == 0) pack_weight_cs_element(w, packed_fwd, e, K, cin, cout, cob_fwd, 0, 0);
+  else pack_weight_cs_element(w, packed_dgrad, e, K, cout, cin, cob_dgrad, 1, flip_dgrad);
 }
 
 #ifdef WCN_PROF
@@ -529,6 +545,23 @@ int pack_weight_cs(const void* w, int w_is_f32, int K, int cin, int cout, int dt
     hipLaunchKernelGGL((pack_weight_cs_kernel<uint16_t, uint16_t>), grid, block, 0, s, (const uint16_t*)w, (uint16_t*)packed,
                        K, cin, cout, cob, transpose, flip);
   }
+  return launch_status();
+}
+
+// forward + dgrad images of an fp32 master weight in one launch; both directions must be this family's shapes
+int pack_weight_cs_pair(const float* w, int K, int cin, int cout, int dtype, int flip_dgrad, void* packed_fwd, void* packed_dgrad,
+                        hipStream_t s) {
+  if (!gather_gemm_cs_supported(cin, cout, K, dtype) || !gather_gemm_cs_supported(cout, cin, K, dtype))
+    return WCN_ERROR_UNSUPPORTED_CONFIG;
+  const int64_t tot_f = (int64_t)K * ((cin + kCsCIC - 1) / kCsCIC) * kCsCIC * cout;
+  const int64_t tot_d = (int64_t)K * ((cout + kCsCIC - 1) / kCsCIC) * kCsCIC * cin;
+  const dim3 grid((unsigned)ceil_div(tot_f > tot_d ? tot_f : tot_d, 256), 2), block(256);
+  if (dtype == WCN_BF16)
+    hipLaunchKernelGGL((pack_weight_cs_pair_kernel<__bf16>), grid, block, 0, s, w, (__bf16*)packed_fwd, (__bf16*)packed_dgrad, K, cin,
+                       cout, cs_col_block(cout), cs_col_block(cin), flip_dgrad);
+  else
+    hipLaunchKernelGGL((pack_weight_cs_pair_kernel<_Float16>), grid, block, 0, s, w, (_Float16*)packed_fwd, (_Float16*)packed_dgrad,
+                       K, cin, cout, cs_col_block(cout), cs_col_block(cin), flip_dgrad);
   return launch_status();
 }
 

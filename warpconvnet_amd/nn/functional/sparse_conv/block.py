@@ -128,7 +128,11 @@ class _ConvBnAct(Function):
         dev = x.device
         stream = _lib.stream_handle(dev)
         km, M, cin, cout, K, code = plan.km, plan.num_out, plan.cin, plan.cout, plan.K, plan.code
-        wp = hip_gemm.pack_weight(w, False, False, dtype=x.dtype)
+        # (forward and dgrad image in one launch when this step has a backward; k-flip of the latter predicted as in hip_forward)
+        ks = getattr(km, "_kernel_size", None)
+        guess = (bool(km._symmetric) if getattr(km, "_validate_fn", None) is None
+                 else bool(ks is not None and all(int(k) % 2 == 1 for k in ks) and km._num_in == km._num_out))
+        wp = hip_gemm.pack_weight(w, False, False, dtype=x.dtype, dgrad_flip=guess if ctx.needs_input_grad[0] else None)
         y = torch.empty((M, cout), dtype=x.dtype, device=dev)
         xp, wpp, yp = _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y)
 

@@ -96,7 +96,13 @@ def resolve_wgrad_algo(algo: str, cin: int, cout: int, dtype: torch.dtype) -> in
     return _lib.WCN_ALGO_MFMA if ok else _lib.WCN_ALGO_REF
 
 
-def pack_weight(weight: Tensor, transpose: bool, flip: bool, dtype: Optional[torch.dtype] = None) -> Tensor:
+@functools.lru_cache(maxsize=None)
+def _pair_ok(K: int, cin: int, cout: int, code: int) -> bool:
+    return bool(_lib.lib().wcn_pack_weight_pair_supported(K, cin, cout, code))
+
+
+def pack_weight(weight: Tensor, transpose: bool, flip: bool, dtype: Optional[torch.dtype] = None,
+                dgrad_flip: Optional[bool] = None) -> Tensor:
     """Fragment-ordered weight image for the MFMA gather-GEMM.  ``weight`` is the forward [K, Cin, Cout]; an fp32 master
     weight with a 16-bit ``dtype`` is rounded while it is packed (one launch instead of cast + pack).
 
@@ -118,6 +124,32 @@ def pack_weight(weight: Tensor, transpose: bool, flip: bool, dtype: Optional[tor
         hit = cache.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
+    cacheable = weight.requires_grad and weight.is_leaf
+    if (dgrad_flip is not None and not transpose and not flip and cacheable and torch.is_grad_enabled()
+            and weight.dtype == torch.float32 and dtype in (torch.float16, torch.bfloat16)
+            and _pair_ok(K, c_in, c_out, _lib.dtype_code(dtype))):
+        # the forward image of a parameter that will need its dgrad image in this step's backward (``dgrad_flip``: whether that
+        # one is k-flipped - the caller's prediction; a wrong one only costs the ordinary pack later): both in ONE launch
+        esz = 2
+        fwd = torch.empty(_lib.lib().wcn_packed_weight_bytes(K, c_in, c_out, _lib.dtype_code(dtype), 0) // esz, dtype=dtype,
+                          device=weight.device)
+        bwd = torch.empty(_lib.lib().wcn_packed_weight_bytes(K, c_out, c_in, _lib.dtype_code(dtype), 1) // esz, dtype=dtype,
+                          device=weight.device)
+        _lib.check(
+            _lib.lib().wcn_pack_weight_f32_pair(_lib.ptr(weight), K, c_in, c_out, _lib.dtype_code(dtype), int(bool(dgrad_flip)),
+                                                _lib.ptr(fwd), fwd.numel() * esz, _lib.ptr(bwd), bwd.numel() * esz,
+                                                _lib.stream_handle(weight.device)),
+            "wcn_pack_weight_f32_pair",
+        )
+        if cache is None:
+            cache = {}
+            try:
+                weight._wcn_packed = cache
+            except AttributeError:
+                return fwd
+        cache[key] = (stamp, fwd)
+        cache[(dtype, True, bool(dgrad_flip))] = (stamp, bwd)
+        return fwd
     packed = _pack_weight_uncached(weight, K, kin, kout, transpose, flip, dtype)
     if weight.requires_grad and weight.is_leaf:
         if cache is None:
@@ -206,12 +238,12 @@ def master_weight_ok(x_dtype: torch.dtype, weight: Tensor, algo: str, transposed
 
 def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: Optional[Tensor], n_out: int,
                  cin: int, cout: int, K: int, algo_code: int, transposed: bool, flip: bool,
-                 bias: Optional[Tensor] = None, f32_out: bool = False) -> Tensor:
+                 bias: Optional[Tensor] = None, f32_out: bool = False, dgrad_flip: Optional[bool] = None) -> Tensor:
     out = torch.empty((n_out, cout), dtype=torch.float32 if f32_out else inp.dtype, device=inp.device)
     if n_out == 0:
         return out
     if algo_code == _lib.WCN_ALGO_MFMA:
-        w_arg = pack_weight(weight, transposed, flip, dtype=inp.dtype)
+        w_arg = pack_weight(weight, transposed, flip, dtype=inp.dtype, dgrad_flip=dgrad_flip)
     else:
         w_arg = weight
     if f32_out:
@@ -263,8 +295,15 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
             y = y * (sx * sw)  # exact power-of-two multiply-back, no host sync
             return y if bias is None else y + bias
         code = resolve_gather_algo(algo, cin, cout, K, x.dtype)
+        # prediction of the dgrad image's k-flip (a submanifold map over distinct coordinates): exact once the map is validated,
+        # "same row count, odd kernel" before that - a wrong guess only costs the ordinary dgrad pack in the backward
+        if getattr(kernel_map, "_validate_fn", None) is None:
+            guess = bool(kernel_map._symmetric)
+        else:
+            ks = getattr(kernel_map, "_kernel_size", None)
+            guess = bool(ks is not None and all(int(k) % 2 == 1 for k in ks) and kernel_map._num_in == kernel_map._num_out)
         return _gather_gemm(x, w, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K, code,
-                            transposed=False, flip=False, bias=bias)
+                            transposed=False, flip=False, bias=bias, dgrad_flip=guess)
 
     # An optimistic map (built by the convolution itself this very call) has not had its status word read: the forward is
     # queued on its tables FIRST - so the GPU runs mask sort -> forward back to back while the host gets to the status -
