@@ -116,8 +116,12 @@ class GradientBuckets:
         buckets.finish()         # wait, average; p.grad is ready for the optimizer
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True, bucket_bytes: int = 32 << 20):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True, bucket_bytes: int = 32 << 20,
+                 collective_when_alone: bool = False):
+        # collective_when_alone: issue the all-reduce even in a group of ONE rank (a no-op sum that still goes through the
+        # backend's streams, events and work handles) - how the single-GPU test box exercises the RCCL path of this class
         self.group, self.average = group, average
+        self._alone_too = bool(collective_when_alone) and dist.is_available() and dist.is_initialized()
         self.params = [p for p in params if p.requires_grad]
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self._buckets: List[dict] = []
@@ -171,7 +175,7 @@ class GradientBuckets:
 
     def _launch(self, b):
         b["launched"] = True
-        if self.world > 1:
+        if self.world > 1 or self._alone_too:
             b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @torch.no_grad()
