@@ -271,7 +271,7 @@ struct KsArgs {
   int64_t pair_capacity;
   int32_t* status;
 };
-constexpr size_t kKsLds = (size_t)2 * kStageCap * 4 + 32 * 8 + (size_t)(kBkThreads / 64) * 32 * 12 + 36 * 4;
+constexpr size_t kKsLds = (size_t)2 * kStageCap * 4 + 32 * 8 + (size_t)(kBkThreads / 64) * 32 * 12 + 36 * 4 + kStageCap;
 
 __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_id, char* smem) {
   const int32_t* __restrict__ nbr = q.nbr;
@@ -288,6 +288,7 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
   unsigned long long(*s_ball)[32] = reinterpret_cast<unsigned long long(*)[32]>(s_gbase + 32);  // rows of the wave that have the offset
   int(*s_cnt)[32] = reinterpret_cast<int(*)[32]>(s_ball + kBkThreads / 64);  // pairs per (wave, offset), then exclusive over the waves
   int* s_seg = reinterpret_cast<int*>(s_cnt + kBkThreads / 64);               // [33] first staged position of every offset
+  unsigned char* s_bk = reinterpret_cast<unsigned char*>(s_seg + 36);         // [kStageCap] offset (inside the word) of a staged pair
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = tile_id * kTileRows + wave * 64;
   const int64_t row = row0 + lane;
@@ -339,27 +340,73 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
     __syncthreads();
     const int total = s_seg[32];
     const bool staged = total <= kStageCap;
+    if ((64 % cols4) == 0) {
+      // 1 / 2 / 4 / 8 pieces per row: a lane holds the SAME four table columns 4c .. 4c+3 in every piece (rows r0 + j * rstep), so
+      // everything that depends on the offset alone - the wave's pair count below it, its row bitmap, the staged and the global
+      // base - is read once per word instead of once per value (3 LDS reads of 4 per value were these)
+      const int c = lane % cols4, r0 = lane / cols4, rstep = 64 / cols4;
+      int cnt_q[4], seg_q[4];
+      unsigned long long ball_q[4];
+      int64_t gb_q[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j >= cols4) break;
-      const int e = lane + 64 * j;
-      const int r = e / cols4, c = e - r * cols4;
-      const int vals[4] = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+      for (int t = 0; t < 4; ++t) {
+        const int b = (c * 4 + t) & 31;
+        cnt_q[t] = s_cnt[wave][b];
+        ball_q[t] = s_ball[wave][b];
+        seg_q[t] = s_seg[b];
+        gb_q[t] = s_gbase[b];
+      }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int b = c * 4 + q;  // offset inside the word
-        if (vals[q] < 0 || b >= kend) continue;
-        const int local = s_cnt[wave][b] + __popcll(s_ball[wave][b] & ((1ull << r) - 1ull));
-        if (staged) {
-          s_in[s_seg[b] + local] = vals[q];
-          s_out[s_seg[b] + local] = (int32_t)(row0 + r);
-        } else {
-          const int64_t pos = s_gbase[b] + local;
-          if (pos < pair_capacity) {
-            in_maps[pos] = vals[q];
-            out_maps[pos] = (int32_t)(row0 + r);
+      for (int j = 0; j < 8; ++j) {
+        if (j >= cols4) break;
+        const int r = r0 + j * rstep;
+        const unsigned long long below = (1ull << r) - 1ull;
+        const int vals[4] = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int b = c * 4 + t;
+          if (vals[t] < 0 || b >= kend) continue;
+          const int local = cnt_q[t] + __popcll(ball_q[t] & below);
+          if (staged) {
+            const int at = seg_q[t] + local;
+            s_in[at] = vals[t];
+            s_out[at] = (int32_t)(row0 + r);
+            s_bk[at] = (unsigned char)b;
           } else {
-            overflow = true;
+            const int64_t pos = gb_q[t] + local;
+            if (pos < pair_capacity) {
+              in_maps[pos] = vals[t];
+              out_maps[pos] = (int32_t)(row0 + r);
+            } else {
+              overflow = true;
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j >= cols4) break;
+        const int e = lane + 64 * j;
+        const int r = e / cols4, c = e - r * cols4;
+        const int vals[4] = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int b = c * 4 + q;  // offset inside the word
+          if (vals[q] < 0 || b >= kend) continue;
+          const int local = s_cnt[wave][b] + __popcll(s_ball[wave][b] & ((1ull << r) - 1ull));
+          if (staged) {
+            s_in[s_seg[b] + local] = vals[q];
+            s_out[s_seg[b] + local] = (int32_t)(row0 + r);
+            s_bk[s_seg[b] + local] = (unsigned char)b;
+          } else {
+            const int64_t pos = s_gbase[b] + local;
+            if (pos < pair_capacity) {
+              in_maps[pos] = vals[q];
+              out_maps[pos] = (int32_t)(row0 + r);
+            } else {
+              overflow = true;
+            }
           }
         }
       }
@@ -367,10 +414,7 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
     __syncthreads();
     if (staged) {
       for (int e = tid; e < total; e += kBkThreads) {
-        int b = 0;  // offset of staged entry e: largest b with s_seg[b] <= e
-#pragma unroll
-        for (int step = 16; step >= 1; step >>= 1)
-          if (b + step < 32 && s_seg[b + step] <= e) b += step;
+        const int b = s_bk[e];  // (offset of staged entry e, written with it: no search over the segment starts)
         const int64_t pos = s_gbase[b] + (e - s_seg[b]);
         if (pos < pair_capacity) {
           in_maps[pos] = s_in[e];
