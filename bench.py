@@ -273,7 +273,7 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
                                _lib.ptr(m.out_maps_device), _lib.ptr(m._offsets_dev), N, N, CIN, COUT, KVOL, _lib.WCN_BF16,
                                KVOL // 2, _lib.ptr(db_buf), _lib.ptr(ws_buf), ws_bytes, stream)
 
-    # ---- unrolled step: map build -> forward -> dgrad -> wgrad back to back, one event between the phases ----
+    # ---- unrolled step: map build -> forward -> wgrad -> dgrad back to back, one event between the phases ----
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(it)]
     for rep in range(-2, it):
         e = ev[max(rep, 0)]
@@ -285,13 +285,13 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
         k_fwd(m)
         assert not m.validate()
         e[2].record()
-        k_dgrad(m)
+        k_wgrad(m)  # (the module's backward order since round 5: weight gradient first - `detail/backends.py`)
         e[3].record()
-        k_wgrad(m)
+        k_dgrad(m)
         e[4].record()
     torch.cuda.synchronize()
     in_step = [float(np.mean([ev[r][p].elapsed_time(ev[r][p + 1]) for r in range(it)])) for p in range(4)]
-    t_kmap, tk_fwd, tk_dgrad, tk_wgrad = in_step
+    t_kmap, tk_fwd, tk_wgrad, tk_dgrad = in_step
     # isolated figures (back-to-back launches of one kernel find part of their operands in the 256 MiB Infinity Cache):
     # reported next to the in-step ones, never used for the roofline
     iso = {"fwd": time_events(lambda: k_fwd(km), it), "dgrad": time_events(lambda: k_dgrad(km), it),
@@ -377,7 +377,7 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
             "frac": dom["frac"], "compulsory_frac": dom["compulsory_frac"], "traffic": traffic, "traffic_static": traffic is not None,
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
-            "timing": "HIP events on the launch stream between the phases of an unrolled step (map build -> fwd -> dgrad -> wgrad), "
+            "timing": "HIP events on the launch stream between the phases of an unrolled step (map build -> fwd -> wgrad -> dgrad), "
                       "i.e. in-step; the rocprofv3 trace of this command is the newest profiles/r*_kernel_trace_stats.md",
         },
         "step_includes": "kernel-map build, forward, dgrad, wgrad + bias gradient, SGD parameter update (so both packed bf16 "
