@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kTallyThreads) void kmap_tally_kernel(uint32_t* __r
   if (HIST) {
     __syncthreads();
     if ((int)blockIdx.x < nblk_sort)
-      for (int i = tid; i < sort_bins; i += kTallyThreads) dcounts[(int64_t)i * nblk_sort + blockIdx.x] = s_hist[i];
+      for (int i = tid; i < sort_bins; i += kTallyThreads) dcounts[(int64_t)blockIdx.x * sort_bins + i] = s_hist[i];  // [tile][digit]
   }
 }
 
@@ -159,7 +159,7 @@ __device__ __forceinline__ int scan_row_256(int32_t* __restrict__ c, int64_t n, 
   return carry;
 }
 
-// blocks [0, K): offset rows; blocks [K, K + kRsBins): sort digit rows (nblk_sort > 0).  `mirror` (may be null):
+// blocks [0, K): offset rows; blocks [K, K + bins / 16): 16 sort digits each (nblk_sort > 0).  `mirror` (may be null):
 // device-accessible pinned HOST buffer [K+2] that receives the offsets and the status word in the same kernel - the host
 // waits for an event behind this launch instead of queueing a separate D2H copy.
 __global__ __launch_bounds__(kBkThreads) void kmap_scan_kernel(int32_t* __restrict__ counts, int64_t ntile, int K,
@@ -167,35 +167,13 @@ __global__ __launch_bounds__(kBkThreads) void kmap_scan_kernel(int32_t* __restri
                                                                int32_t* __restrict__ offsets,
                                                                const int32_t* __restrict__ status,
                                                                int32_t* __restrict__ mirror, int32_t* __restrict__ dcounts,
-                                                               int nblk_sort, int32_t* __restrict__ dtotals) {
+                                                               int nblk_sort, int32_t* __restrict__ dtotals, int sort_bins) {
   __shared__ int s_wave[kBkThreads / 64];
   __shared__ int s_last;
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= K) {  // sort digit row: exclusive scan over the sort tiles, digit total
-    const int d = blockIdx.x - K;
-    int32_t* row = dcounts + (int64_t)d * nblk_sort;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int chunk = (nblk_sort + kBkThreads - 1) / kBkThreads;
-    const int b0 = tid * chunk;
-    const int b1 = (b0 + chunk < nblk_sort) ? (b0 + chunk) : nblk_sort;
-    int sum = 0;
-    for (int b = b0; b < b1; ++b) sum += row[b];
-    int incl = sum;
-#pragma unroll
-    for (int q = 1; q < 64; q <<= 1) {
-      const int up = __shfl_up(incl, q);
-      if (lane >= q) incl += up;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int run = incl - sum;
-    for (int w = 0; w < wave; ++w) run += s_wave[w];
-    for (int b = b0; b < b1; ++b) {
-      const int v = row[b];
-      row[b] = run;
-      run += v;
-    }
-    if (tid == kBkThreads - 1) dtotals[d] = run;
+  if ((int)blockIdx.x >= K) {  // 16 sort digits: exclusive scan over the sort tiles, digit totals (mask_sort.h)
+    __shared__ int s_cols[kBkThreads];
+    rs_scan_body(dcounts, dtotals, nblk_sort, sort_bins, (int)blockIdx.x - K, reinterpret_cast<char*>(s_cols));
     return;
   }
   const int total = scan_row_256(counts + (int64_t)blockIdx.x * ntile, ntile, s_wave);
@@ -474,8 +452,8 @@ static void launch_scan(int32_t* counts, int64_t ntile, int K, int32_t* offsets,
                         int nblk_sort, int32_t* dcounts, int32_t* dtotals, int sort_bins, hipStream_t s) {
   int32_t* totals = counts + (int64_t)K * ntile;
   int32_t* ticket = totals + K;
-  hipLaunchKernelGGL(kmap_scan_kernel, dim3((unsigned)(K + (nblk_sort > 0 ? sort_bins : 0))), dim3(kBkThreads), 0, s, counts,
-                     ntile, K, totals, ticket, offsets, status, mirror, dcounts, nblk_sort, dtotals);
+  hipLaunchKernelGGL(kmap_scan_kernel, dim3((unsigned)(K + (nblk_sort > 0 ? (sort_bins + kRsScanCols - 1) / kRsScanCols : 0))), dim3(kBkThreads), 0,
+                     s, counts, ntile, K, totals, ticket, offsets, status, mirror, dcounts, nblk_sort, dtotals, sort_bins);
 }
 
 int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream) {

@@ -8,7 +8,7 @@
 //
 // 9-bit digits (512 bins) => 3 passes for the 27-bit masks of a 3x3x3 kernel (4 for 32 bits).  Per pass:
 //   hist     block-local LDS histogram of its 2048-key tile              -> counts[digit][block]
-//   scan     one workgroup per digit: exclusive scan over blocks + digit total (digit bases are scanned in the
+//   scan     one workgroup per 64 digits: exclusive scan over blocks + digit totals (digit bases are scanned in the
 //            scatter prologue)                                           -> global base of every (digit, block)
 //   scatter  wave w owns a contiguous quarter of the tile; per-wave digit counts give each wave its base, then keys
 //            are ranked 64 at a time: lanes with equal digits find each other with 9 ballots ("match-any"),
@@ -79,7 +79,7 @@ struct RsArgs {
   int shift;            // first key bit of this pass's digit
   int bits;             // digit width (kRsBits or kRsBitsWide)
   int nblk;
-  int32_t* counts;      // [1 << bits][nblk]
+  int32_t* counts;      // [nblk][1 << bits]: a tile's digit counts are one contiguous row (coalesced by its writer and its reader)
   int32_t* totals;      // [1 << bits]
   uint2* pout;          // all but the last pass
   int32_t* vout;        // last pass: the permutation
@@ -97,7 +97,7 @@ struct SortPlan {
   int bits;           // digit width
   int shift0;         // low key bits no pass looks at (wide plans sort the top passes * bits bits of the key)
   uint2* pbuf[2];     // ping-pong (key, row) pairs
-  int32_t* counts;    // [1 << bits][nblk] per-(digit, tile) counts, scanned in place
+  int32_t* counts;    // [nblk][1 << bits] per-(tile, digit) counts, scanned in place along the tiles
   int32_t* totals;    // [1 << bits] digit totals
   size_t bytes;
 };
@@ -131,35 +131,65 @@ __device__ __forceinline__ void rs_hist_body(const RsArgs& a, int blk, char* sme
   for (int j = 0; j < kPer; ++j)
     if (base + threadIdx.x + j * kRsThreads < a.n) atomicAdd(&s_hist[rs_digit(k[j], a.shift, a.bits)], 1);
   __syncthreads();
-  for (int i = threadIdx.x; i < bins; i += kRsThreads) a.counts[(int64_t)i * a.nblk + blk] = s_hist[i];
+  for (int i = threadIdx.x; i < bins; i += kRsThreads) a.counts[(int64_t)blk * bins + i] = s_hist[i];
 }
 
-// one workgroup per digit: exclusive scan of counts[d][0..nblk) in place, totals[d] = row sum
-__device__ __forceinline__ void rs_scan_body(const RsArgs& a, int digit, char* smem) {
-  int* s_part = reinterpret_cast<int*>(smem);
-  int32_t* row = a.counts + (int64_t)digit * a.nblk;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int chunk = (a.nblk + kRsThreads - 1) / kRsThreads;
-  const int b0 = tid * chunk;
-  const int b1 = (b0 + chunk < a.nblk) ? (b0 + chunk) : a.nblk;
+// Exclusive scan over the TILES of every digit's counts, in place, and the digit totals.  counts is [nblk][bins]: workgroup g owns
+// the 16 digits [16 g, 16 g + 16) - a 64-B piece of every row - and its 16 row groups a sixteenth of the rows each (the
+// [digit][tile] layout of rounds 2-4 made the writers of the counts store 512 - 1 024 words to as many different lines per tile).
+// Up to 512 tiles (1 M rows) a thread keeps its <= 32 counts in registers: one round trip of loads, the group prefix through LDS,
+// stores.  `smem` >= 256 ints.
+constexpr int kRsScanCols = 16;
+constexpr int kRsScanTrip = 32;
+__device__ __forceinline__ void rs_scan_body(int32_t* __restrict__ counts, int32_t* __restrict__ totals, int nblk, int bins, int g,
+                                             char* smem) {
+  int* s_part = reinterpret_cast<int*>(smem);  // [16 row groups][16 digits]
+  const int tid = threadIdx.x, dl = tid & (kRsScanCols - 1), rgp = tid / kRsScanCols;
+  constexpr int kGroups = kRsThreads / kRsScanCols;
+  const int d = g * kRsScanCols + dl;
+  const bool live = d < bins;
+  const int chunk = (nblk + kGroups - 1) / kGroups;
+  const int b0 = rgp * chunk, b1 = (b0 + chunk < nblk) ? (b0 + chunk) : nblk;
+  int32_t* col = counts + (live ? d : 0);
   int sum = 0;
-  for (int b = b0; b < b1; ++b) sum += row[b];
-  int incl = sum;
+  int v[kRsScanTrip];
+  const bool in_regs = chunk <= kRsScanTrip;
+  if (in_regs) {
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
+    for (int j = 0; j < kRsScanTrip; ++j) v[j] = (live && b0 + j < b1) ? col[(int64_t)(b0 + j) * bins] : 0;
+#pragma unroll
+    for (int j = 0; j < kRsScanTrip; ++j) sum += v[j];
+  } else if (live) {
+    for (int b = b0; b < b1; ++b) sum += col[(int64_t)b * bins];
   }
-  if (lane == 63) s_part[wave] = incl;
+  s_part[rgp * kRsScanCols + dl] = sum;
   __syncthreads();
-  int run = incl - sum;
-  for (int w = 0; w < wave; ++w) run += s_part[w];
-  for (int b = b0; b < b1; ++b) {
-    const int v = row[b];
-    row[b] = run;
-    run += v;
+  int run = 0, total = 0;
+#pragma unroll
+  for (int r = 0; r < kGroups; ++r) {
+    const int q = s_part[r * kRsScanCols + dl];
+    if (r < rgp) run += q;
+    total += q;
   }
-  if (tid == kRsThreads - 1) a.totals[digit] = run;
+  if (!live) return;
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < kRsScanTrip; ++j)
+      if (b0 + j < b1) {
+        col[(int64_t)(b0 + j) * bins] = run;
+        run += v[j];
+      }
+  } else {
+    for (int b = b0; b < b1; ++b) {
+      const int c = col[(int64_t)b * bins];
+      col[(int64_t)b * bins] = run;
+      run += c;
+    }
+  }
+  if (rgp == 0) totals[d] = total;
+}
+__device__ __forceinline__ void rs_scan_body(const RsArgs& a, int g, char* smem) {
+  rs_scan_body(a.counts, a.totals, a.nblk, 1 << a.bits, g, smem);
 }
 
 template <int BITS>
@@ -196,7 +226,7 @@ __device__ __forceinline__ void rs_scatter_body(const RsArgs& a, int blk, char* 
   for (int j = 0; j < kPerT; ++j) tt[j] = a.totals[kPerT * tid + j];
   int blk_base[kPerT];
 #pragma unroll
-  for (int j = 0; j < kPerT; ++j) blk_base[j] = a.counts[(int64_t)(tid + j * kRsThreads) * a.nblk + blk];
+  for (int j = 0; j < kPerT; ++j) blk_base[j] = a.counts[(int64_t)blk * BINS + tid + j * kRsThreads];
   {  // exclusive scan of the digit totals: kPerT consecutive digits per thread, wave scan, 4 wave partials
     int mine = 0;
 #pragma unroll

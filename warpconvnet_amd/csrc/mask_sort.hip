@@ -56,7 +56,7 @@ int sort_launches(const SortPlan& p, const uint32_t* mask, int mask_words, int64
     a.vout = last ? perm : nullptr;  // the last pass writes the permutation alone
     if (!(pass == 0 && first_counted)) {
       out[count++] = RsLaunch{kRsHist, p.nblk, a};
-      out[count++] = RsLaunch{kRsScan, 1 << p.bits, a};
+      out[count++] = RsLaunch{kRsScan, ((1 << p.bits) + kRsScanCols - 1) / kRsScanCols, a};
     }
     out[count++] = RsLaunch{kRsScatter, p.nblk, a};
     a.pin = a.pout;
@@ -68,7 +68,7 @@ void sort_run_range(const RsLaunch* l, int begin, int end, hipStream_t s) {
   for (int i = begin; i < end; ++i) {
     const dim3 grid((unsigned)l[i].blocks), block(kRsThreads);
     if (l[i].role == kRsHist) hipLaunchKernelGGL(rs_kernel<kRsHist>, grid, block, (size_t)4 << l[i].a.bits, s, l[i].a);
-    else if (l[i].role == kRsScan) hipLaunchKernelGGL(rs_kernel<kRsScan>, grid, block, 64, s, l[i].a);
+    else if (l[i].role == kRsScan) hipLaunchKernelGGL(rs_kernel<kRsScan>, grid, block, kRsThreads * 4, s, l[i].a);
     else hipLaunchKernelGGL(rs_kernel<kRsScatter>, grid, block, rs_scatter_lds(l[i].a.bits), s, l[i].a);
   }
 }
