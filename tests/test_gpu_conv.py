@@ -150,6 +150,42 @@ def test_forward_and_dgrad_weight_images_in_one_launch(dtype, cin, cout, flip):
     assert not torch.equal(hip_gemm.pack_weight(w, False, False, dtype=dtype, dgrad_flip=flip).view(torch.int16), fwd.view(torch.int16))
 
 
+@pytest.mark.parametrize("fused_block", [False, True])
+def test_the_training_forward_packs_both_weight_images(fused_block):
+    """The module path (and the fused conv -> BatchNorm node) must reach the pair packer: grad mode is OFF inside
+    `Function.forward`, so the decision rides on `ctx.needs_input_grad`, not on `torch.is_grad_enabled()` - after the forward
+    of a step whose input needs a gradient the parameter's cache already holds the (transposed, k-flipped) dgrad image."""
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = _dev()
+    c = torch.from_numpy(scene_u(4000, 77)[:, 1:]).to(dev)
+    n = c.shape[0]
+    feats = torch.randn(n, 64, device=dev).requires_grad_(True)
+    torch.manual_seed(0)
+    conv = SparseConv3d(64, 128, 3, bias=not fused_block).to(dev)
+    x = Voxels(c, feats, offsets=torch.tensor([0, n], dtype=torch.int32))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        if fused_block:
+            from warpconvnet_amd.nn.functional.sparse_conv.block import conv_bn_act
+
+            y = conv_bn_act(x, conv, torch.nn.BatchNorm1d(128).to(dev), relu=True)
+            assert y is not None
+        else:
+            y = conv(x)
+    cache = conv.weight._wcn_packed
+    assert (torch.bfloat16, False, False) in cache and (torch.bfloat16, True, True) in cache, list(cache)
+    before = cache[(torch.bfloat16, True, True)][1]
+    y.feature_tensor.float().sum().backward()
+    assert conv.weight._wcn_packed[(torch.bfloat16, True, True)][1] is before  # the backward packed nothing
+    assert feats.grad is not None and conv.weight.grad is not None
+    # inference: no dgrad image
+    conv2 = SparseConv3d(64, 128, 3).to(dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        conv2(Voxels(c, feats.detach(), offsets=torch.tensor([0, n], dtype=torch.int32)))
+    assert list(conv2.weight._wcn_packed) == [(torch.bfloat16, False, False)]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("method", ["binned", "hash"])
 def test_duplicate_rows_all_three_gemms_vs_oracle(dtype, method, monkeypatch):

@@ -32,6 +32,7 @@ class FwdCtx:
     groups: int = 1
     use_fp16_accum: bool = False
     bias: Optional[Tensor] = None  # fused epilogue (build extension; the reference adds the bias outside)
+    needs_dgrad: bool = False      # a backward with an input gradient will follow: pack the dgrad weight image with the forward's
 
 
 @dataclass
@@ -73,7 +74,8 @@ def _make_hip_fwd(algo: str) -> FwdFn:
         dt = ctx.compute_dtype or ctx.in_features.dtype
         # (an fp32 master weight stays as it is when the MFMA kernel takes the shape: its packed image is rounded from it)
         w = ctx.weight if hip_gemm.master_weight_ok(dt, ctx.weight, algo, False) else ctx.weight.to(dt)
-        out = hip_gemm.hip_forward(ctx.in_features.to(dt), w, ctx.kernel_map, ctx.num_out_coords, algo, bias=ctx.bias)
+        out = hip_gemm.hip_forward(ctx.in_features.to(dt), w, ctx.kernel_map, ctx.num_out_coords, algo, bias=ctx.bias,
+                                   want_dgrad_image=ctx.needs_dgrad)
         return out.to(ctx.in_features.dtype) if ctx.compute_dtype is not None else out
 
     return fn

@@ -125,7 +125,7 @@ def pack_weight(weight: Tensor, transpose: bool, flip: bool, dtype: Optional[tor
         if hit is not None and hit[0] == stamp:
             return hit[1]
     cacheable = weight.requires_grad and weight.is_leaf
-    if (dgrad_flip is not None and not transpose and not flip and cacheable and torch.is_grad_enabled()
+    if (dgrad_flip is not None and not transpose and not flip and cacheable
             and weight.dtype == torch.float32 and dtype in (torch.float16, torch.bfloat16)
             and _pair_ok(K, c_in, c_out, _lib.dtype_code(dtype))):
         # the forward image of a parameter that will need its dgrad image in this step's backward (``dgrad_flip``: whether that
@@ -265,8 +265,9 @@ def _gather_gemm(inp: Tensor, weight: Tensor, nbr: Tensor, mask: Tensor, perm: O
 
 
 def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult, num_out_coords: int,
-                algo: str = "auto", bias: Optional[Tensor] = None) -> Tensor:
-    """y[m] = sum_k x[nbr[m][k]] @ w[k] (+ bias, fused into the epilogue in fp32)."""
+                algo: str = "auto", bias: Optional[Tensor] = None, want_dgrad_image: bool = False) -> Tensor:
+    """y[m] = sum_k x[nbr[m][k]] @ w[k] (+ bias, fused into the epilogue in fp32).  ``want_dgrad_image``: a backward with an input
+    gradient follows (the autograd Function says so) - the dgrad weight image is packed in the forward image's launch."""
     if bias is not None:
         bias = bias.detach()
         if bias.dtype != torch.float32:
@@ -297,7 +298,9 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
         code = resolve_gather_algo(algo, cin, cout, K, x.dtype)
         # prediction of the dgrad image's k-flip (a submanifold map over distinct coordinates): exact once the map is validated,
         # "same row count, odd kernel" before that - a wrong guess only costs the ordinary dgrad pack in the backward
-        if getattr(kernel_map, "_validate_fn", None) is None:
+        if not want_dgrad_image:
+            guess = None
+        elif getattr(kernel_map, "_validate_fn", None) is None:
             guess = bool(kernel_map._symmetric)
         else:
             ks = getattr(kernel_map, "_kernel_size", None)

@@ -94,7 +94,7 @@ class UnifiedSpatiallySparseConvFunction(Function):
             out = torch.zeros((num_out_coords, cout), dtype=in_features.dtype, device=in_features.device)
             return out if bias is None else out + bias.to(out.dtype)
         fctx = FwdCtx(in_features, weight, kernel_map, num_out_coords, compute_dtype, {}, fwd_block_size, groups,
-                      bool(use_fp16_accum), bias)
+                      bool(use_fp16_accum), bias, needs_dgrad=bool(ctx.needs_input_grad[0]))
         return run_forward(_algo_name(fwd_algo, on_gpu), fctx)
 
     @staticmethod
