@@ -290,6 +290,12 @@ int wcn_pack_weight_f32_pair(const float* w, int32_t num_offsets, int32_t cin, i
  *   w:   for WCN_ALGO_REF the plain [K, cin, cout] tensor (or [K, cout', cin'] with w_transposed=1),
  *        for WCN_ALGO_MFMA the image made by wcn_pack_weight.
  * reference: _C.mask_gemm.fwd / .dgrad (mask_gemm_bindings.cu:2074-2101). */
+/* Mask in the table (round 5).  A neighbour-table row of 32 columns for K <= 31 offsets has a free last column; wcn_kmap_build_binned
+ * stores the row's MASK there (same 128-B store as the row).  Where wcn_conv_mask_in_table_supported (channel-split kernel shapes,
+ * row pitch 32), wcn_conv_gather_gemm / wcn_conv_bn_backward accept `mask` = NULL with a table and read the mask with the index slab:
+ * gathering mask[perm[i]] is one 128-B line per row (128 MB of fabric requests per launch at 1 M rows for 4 MB of masks).  Tables
+ * from other builders (wcn_kmap_probe, wcn_kmap_from_csr, wcn_kmap_reverse, strided maps) do NOT carry it: pass their mask. */
+int wcn_conv_mask_in_table_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype);
 int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t* nbr,
                          const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_in,
                          int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,

@@ -149,6 +149,41 @@ def test_forward_and_dgrad_weight_images_in_one_launch(dtype, cin, cout, flip):
         w.add_(1.0)  # an optimizer step: both cached images are stale
     assert not torch.equal(hip_gemm.pack_weight(w, False, False, dtype=dtype, dgrad_flip=flip).view(torch.int16), fwd.view(torch.int16))
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (96, 96), (64, 256)])
+def test_mask_read_from_the_table_row_equals_the_mask_array(dtype, cin, cout):
+    """Round 5: the binned builder stores a row's mask in the free last column of its 32-column table row and the channel-split
+    kernels read it with the index slab (`mask` = NULL) instead of gathering mask[perm[i]].  Same tiles, same steps: forward and
+    dgrad bit-identical to the launches that are handed the mask array; duplicates and out-of-table rows included."""
+    from warpconvnet_amd import _lib
+    from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
+
+    s = np.concatenate([scene_u(3000, 51, 0), scene_u(1100, 52, 1)], 0)
+    s = np.concatenate([s, s[:40]], 0)  # 40 duplicated coordinates: repaired rows copy their winner's row, mask column included
+    km = _kmap(s, s, (3, 3, 3), same=True)
+    assert km._mask_in_table
+    np.testing.assert_array_equal(km._nbr[:, 31].cpu().numpy().view(np.uint32), km._mask[:, 0].cpu().numpy().view(np.uint32))
+    dev = _dev()
+    g = torch.Generator().manual_seed(cin + cout)
+    X = torch.randn(len(s), cin, generator=g).to(dev, dtype)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev, dtype)
+    assert hip_gemm.table_mask(km, km._nbr, km._mask, cin, cout, 27, dtype) is None
+    y_tbl = hip_gemm._gather_gemm(X, W, km._nbr, None, km._perm, len(s), cin, cout, 27, _lib.WCN_ALGO_MFMA, False, False)
+    y_arr = hip_gemm._gather_gemm(X, W, km._nbr, km._mask, km._perm, len(s), cin, cout, 27, _lib.WCN_ALGO_MFMA, False, False)
+    assert torch.equal(y_tbl, y_arr)
+    dY = torch.randn(len(s), cout, generator=g).to(dev, dtype)
+    d_tbl = hip_gemm._gather_gemm(dY, W, km._nbr, None, km._perm, len(s), cout, cin, 27, _lib.WCN_ALGO_MFMA, True, True)
+    d_arr = hip_gemm._gather_gemm(dY, W, km._nbr, km._mask, km._perm, len(s), cout, cin, 27, _lib.WCN_ALGO_MFMA, True, True)
+    assert torch.equal(d_tbl, d_arr)
+    # a table that does not carry masks (hash builder) keeps its mask argument
+    import os
+    os.environ["WARPCONVNET_AMD_KMAP_METHOD"] = "hash"
+    try:
+        kh = _kmap(s[:-40], s[:-40], (3, 3, 3), same=True)
+    finally:
+        del os.environ["WARPCONVNET_AMD_KMAP_METHOD"]
+    assert not kh._mask_in_table and hip_gemm.table_mask(kh, kh._nbr, kh._mask, cin, cout, 27, dtype) is kh._mask
+
 
 @pytest.mark.parametrize("fused_block", [False, True])
 def test_the_training_forward_packs_both_weight_images(fused_block):

@@ -31,7 +31,11 @@ def _check_against_oracle(km, in_np, out_np, ksize, stride=(1, 1, 1), dilation=(
     # row-major table: same content, pad columns are -1
     nbr = km._nbr.cpu().numpy()
     np.testing.assert_array_equal(nbr[:, :K].T, r["found"])
-    assert (nbr[:, K:] == -1).all()
+    if km._mask_in_table:  # binned builder, 32-column rows: the free last column carries the row's mask (the GEMMs read it there)
+        assert nbr.shape[1] == 32 and (nbr[:, K:31] == -1).all()
+        np.testing.assert_array_equal(nbr[:, 31].view(np.uint32), r["mask"][:, 0])
+    else:
+        assert (nbr[:, K:] == -1).all()
     np.testing.assert_array_equal(km.offsets.numpy(), r["offsets"])
     np.testing.assert_array_equal(km._offsets_dev.cpu().numpy(), r["offsets"])
     # buckets come out ordered by output row -> equal to the canonical oracle order without sorting

@@ -126,6 +126,7 @@ SIGNATURES = {
         [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p],
     ),
     "wcn_pack_weight_pair_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
+    "wcn_conv_mask_in_table_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
     "wcn_pack_weight_f32_pair": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_size_t,
                                          c_void_p]),
     "wcn_conv_gather_gemm": (

@@ -90,6 +90,15 @@ int wcn_pack_weight_f32(const float* w, int32_t num_offsets, int32_t cin, int32_
   return pack_weight_mfma_f32(w, num_offsets, cin, cout, dtype, transpose, flip, packed, (hipStream_t)stream);
 }
 
+// A table row of 32 columns for K <= 31 offsets may carry the row's mask in its last column (wcn_kmap_build_binned writes it there):
+// the channel-split gather kernels then take `mask` = NULL and read it with the index slab.
+static bool mask_in_table_ok(int cin, int cout, int K, int dtype) {
+  return wcn_kmap_row_pitch(K) == 32 && K <= 31 && gather_gemm_cs_supported(cin, cout, K, dtype);
+}
+int wcn_conv_mask_in_table_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype) {
+  return mask_in_table_ok(cin, cout, num_offsets, dtype) ? 1 : 0;
+}
+
 int wcn_pack_weight_pair_supported(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype) {
   return (gather_gemm_cs_supported(cin, cout, num_offsets, dtype) && gather_gemm_cs_supported(cout, cin, num_offsets, dtype)) ? 1 : 0;
 }
@@ -123,7 +132,7 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
       return conv_gather_gemm_ref(in, w, out, nbr, bias, n_out, cin, cout, num_offsets, dtype, w_transposed, k_flip, s);
     case WCN_ALGO_MFMA:
       // `w` must be the packed image (wcn_pack_weight already applied transpose / flip)
-      if (!mask && !identity) return WCN_ERROR_INVALID_PARAMETERS;
+      if (!mask && !identity && !(nbr && mask_in_table_ok(cin, cout, num_offsets, dtype))) return WCN_ERROR_INVALID_PARAMETERS;
       {
         ConvEpilogue epi;
         epi.bias = bias;
@@ -230,7 +239,7 @@ int wcn_conv_bn_backward(const void* grad_out, const void* x, const void* y, con
                                  bn_workspace_bytes, stream);
   if (rc != WCN_SUCCESS) return rc;
   if (dx) {
-    if (!w_packed_dgrad || !rev_nbr || !rev_mask) return WCN_ERROR_INVALID_PARAMETERS;
+    if (!w_packed_dgrad || !rev_nbr) return WCN_ERROR_INVALID_PARAMETERS;  // (rev_mask may ride in the table: wcn_conv_gather_gemm checks)
     rc = wcn_conv_gather_gemm(dy_conv, w_packed_dgrad, dx, rev_nbr, rev_mask, rev_perm, nullptr, n_out, n_in, cout, cin, num_offsets,
                               dtype, WCN_ALGO_MFMA, 1, flip, stream);
     if (rc != WCN_SUCCESS) return rc;

@@ -199,29 +199,37 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   }
   __syncthreads();
   {
-    uint32_t my_mask = 0;
-    if (tid < TILE) {
-      const int32_t r = s_rows[tid];
-      if (r >= 0) my_mask = mask ? mask[r] : 1u;  // (no table: the identity map of a 1 x 1 x 1 kernel, see below)
-      s_mask[tid] = my_mask;
-      if (my_mask) atomicOr(&s_wmask[tid >> 5], my_mask);
+    // `mask` null with a table: the row's mask rides in the LAST column of its 128-B table row (kp = 32, K <= 31: wcn_kmap_build_binned
+    // writes it there, round 5), i.e. in the line the index slab is loaded from anyway.  A gather of mask[r] over the mask-sorted rows
+    // is a 128-B line per row - 128 MB of fabric requests per launch at 1 M rows for 4 MB of masks.
+    const bool mit = mask == nullptr && nbr != nullptr;
+    if (!mit) {
+      uint32_t my_mask = 0;
+      if (tid < TILE) {
+        const int32_t r = s_rows[tid];
+        if (r >= 0) my_mask = mask ? mask[r] : 1u;  // (no table: the identity map of a 1 x 1 x 1 kernel, see below)
+        s_mask[tid] = my_mask;
+        if (my_mask) atomicOr(&s_wmask[tid >> 5], my_mask);
+      }
     }
     // all row ids first, then all table loads, then all LDS writes (one global round trip)
     constexpr int kVec = SP / 4;  // 16-B pieces per slab row
-    constexpr int kIter = (TILE * kVec + NT - 1) / NT;
+    constexpr int kVecL = kVec + 1;  // ... and the piece that carries the mask (mit)
+    constexpr int kIter = (TILE * kVecL + NT - 1) / NT;
+    const int kv = mit ? kVecL : kVec;
     int32_t rr[kIter];
     int4 vv[kIter];
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
       const int e = tid + t * NT;
-      rr[t] = (e < TILE * kVec) ? s_rows[e / kVec] : -1;
+      rr[t] = (e < TILE * kv) ? s_rows[e / kv] : -1;
     }
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
       const int e = tid + t * NT;
-      const int c = e % kVec;
+      const int c = e % kv;
       vv[t] = make_int4(-1, -1, -1, -1);
-      if (rr[t] >= 0 && c * 4 < kp) {  // read once: non-temporal
+      if (rr[t] >= 0 && (c * 4 < kp)) {  // read once: non-temporal
         typedef __attribute__((ext_vector_type(4))) int i32x4;
         if (nbr) {
           const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * kp) + c);
@@ -234,7 +242,15 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
       const int e = tid + t * NT;
-      if (e < TILE * kVec) reinterpret_cast<int4*>(s_nbr + (e / kVec) * SP)[e % kVec] = vv[t];
+      if (e >= TILE * kv) continue;
+      const int row = e / kv, c = e % kv;
+      if (c < kVec) {
+        reinterpret_cast<int4*>(s_nbr + row * SP)[c] = vv[t];
+      } else {  // (mit) columns 28 .. 31: the mask is the last one
+        const uint32_t m = rr[t] >= 0 ? (uint32_t)vv[t].w : 0u;
+        s_mask[row] = m;
+        if (m) atomicOr(&s_wmask[row >> 5], m);
+      }
     }
   }
   __syncthreads();

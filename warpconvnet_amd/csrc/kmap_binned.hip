@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kInsertThreads) void cell_insert_kernel(BSlot* __re
         // the voxel is in no block, so cell_neighbors never visits it: give its table row defined ("no neighbour")
         // content - consumers may already be queued behind this build when the host sees the flag
         for (int k = 0; k < kp; ++k) nbr[i * kp + k] = -1;
+        if (kp == 32 && mw == 1) nbr[i * kp + 31] = 0;  // (the mask column of the row, see cell_neighbors)
         for (int w = 0; w < mw; ++w) mask[i * mw + w] = 0u;
       }
     }
@@ -404,6 +405,12 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
         } else {
           bits_a = (uint32_t)(ball_a >> (vsel * LPR)) & ((1u << LPR) - 1u);
           bits_b = (uint32_t)(ball_b >> (vsel * LPR)) & ((1u << LPR) - 1u);
+        }
+        // kp == 32 with one mask word (K <= 31): the row's LAST column is free - it carries the row's mask, in the same 128-B store,
+        // so that a consumer that loads the row (the gather GEMMs' index slab) needs no second, line-sized gather for 4 bytes
+        if (LPR == 32 && kp == 32 && mw == 1 && sub == 31) {
+          found_a = (int)bits_a;
+          found_b = (int)bits_b;
         }
         if (FAST) {
           char* nbr_b = reinterpret_cast<char*>(nbr);

@@ -44,6 +44,7 @@ __device__ __noinline__ void repair_row(int64_t row, const int4* __restrict__ co
     for (int q = 0; q < mw; ++q) mask[row * mw + q] = mask[(int64_t)w * mw + q];
   } else {  // block table overflow (flagged by the builder): defined, empty content
     for (int k = 0; k < kp; ++k) nbr[row * kp + k] = -1;
+    if (kp == 32 && mw == 1) nbr[row * kp + 31] = 0;  // (the mask column of a 32-column row, kmap_binned.hip)
     for (int q = 0; q < mw; ++q) mask[row * mw + q] = 0u;
   }
 }

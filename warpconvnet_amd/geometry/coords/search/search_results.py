@@ -86,6 +86,7 @@ class IntSearchResult:
         self._has_duplicates: bool = False  # submanifold map over repeated coordinates: dgrad goes through the pair lists
         self._dup_symmetric: bool = False   # ... with an odd kernel at stride 1: dgrad on the gather kernels after all
         self._rev: Optional[Tuple[Tensor, Tensor, Tensor]] = None
+        self._mask_in_table: bool = False  # `_nbr[:, 31]` is the row's mask (binned builder, 32-column rows): GEMMs may skip `_mask`
         self._num_in: Optional[int] = None
         self._num_out: Optional[int] = None
         self._pair_table_cache: Optional[Tensor] = None

@@ -406,6 +406,8 @@ def generate_kernel_map(
 
     def attach_tables(result, b):
         result._nbr, result._mask, result._perm = b["nbr"], b["mask"], b["perm"]
+        # the binned builder stores a row's mask in the free last column of its 32-column table row (csrc/kmap_binned.hip)
+        result._mask_in_table = bool(use_binned and kp == 32 and mw == 1 and K <= 31)
         result._offsets_dev = b["meta"][: K + 1]
         result._hashtable = b["table"]
         result._keepalive = b  # (workspaces the queued kernels still read)

@@ -137,7 +137,8 @@ class _ConvBnAct(Function):
         xp, wpp, yp = _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y)
 
         def launch():
-            _lib.check(L.wcn_conv_gather_gemm(xp, wpp, yp, _lib.ptr(km._nbr), _lib.ptr(km._mask), _lib.ptr(km._perm), None,
+            mk = hip_gemm.table_mask(km, km._nbr, km._mask, cin, cout, K, x.dtype)  # (None: the rows of the table carry their masks)
+            _lib.check(L.wcn_conv_gather_gemm(xp, wpp, yp, _lib.ptr(km._nbr), _lib.ptr(mk), _lib.ptr(km._perm), None,
                                               plan.num_in, M, cin, cout, K, code, _lib.WCN_ALGO_MFMA, 0, 0, stream),
                        "wcn_conv_gather_gemm")
 
@@ -194,6 +195,7 @@ class _ConvBnAct(Function):
                 tbl, msk, perm, flip = km._nbr, km._mask, km._perm, True
             else:
                 tbl, msk, perm = reverse_tables(km, plan.num_in)
+            msk = hip_gemm.table_mask(km, tbl, msk, cout, cin, K, y.dtype)
             wpd = hip_gemm.pack_weight(w, True, flip, dtype=y.dtype)
             dx = torch.empty((plan.num_in, cin), dtype=y.dtype, device=dev)
         dw = wws = None

@@ -97,6 +97,21 @@ def resolve_wgrad_algo(algo: str, cin: int, cout: int, dtype: torch.dtype) -> in
 
 
 @functools.lru_cache(maxsize=None)
+def _mask_in_table_ok(cin: int, cout: int, K: int, code: int) -> bool:
+    return bool(_lib.lib().wcn_conv_mask_in_table_supported(cin, cout, K, code))
+
+
+def table_mask(kernel_map, tbl: Tensor, mask: Tensor, kin: int, kout: int, K: int, dtype: torch.dtype) -> Optional[Tensor]:
+    """The mask argument of a gather-GEMM launch on ``tbl``: None when the table is the map's own binned table (its rows carry
+    their masks in the last column) and the shape is one the channel-split kernels take - they then read it with the index slab
+    instead of gathering ``mask[perm[i]]``, a 128-B line per row."""
+    if (getattr(kernel_map, "_mask_in_table", False) and tbl is kernel_map._nbr and dtype in (torch.float16, torch.bfloat16)
+            and _mask_in_table_ok(kin, kout, K, _lib.dtype_code(dtype))):
+        return None
+    return mask
+
+
+@functools.lru_cache(maxsize=None)
 def _pair_ok(K: int, cin: int, cout: int, code: int) -> bool:
     return bool(_lib.lib().wcn_pack_weight_pair_supported(K, cin, cout, code))
 
@@ -305,7 +320,8 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
         else:
             ks = getattr(kernel_map, "_kernel_size", None)
             guess = bool(ks is not None and all(int(k) % 2 == 1 for k in ks) and kernel_map._num_in == kernel_map._num_out)
-        return _gather_gemm(x, w, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K, code,
+        mk = table_mask(kernel_map, kernel_map._nbr, kernel_map._mask, cin, cout, K, x.dtype) if code == _lib.WCN_ALGO_MFMA else kernel_map._mask
+        return _gather_gemm(x, w, kernel_map._nbr, mk, kernel_map._perm, num_out_coords, cin, cout, K, code,
                             transposed=False, flip=False, bias=bias, dgrad_flip=guess)
 
     # An optimistic map (built by the convolution itself this very call) has not had its status word read: the forward is
@@ -400,6 +416,8 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
                           flip=flip, f32_out=True)
         return dx * (sg * sw)
     code = resolve_gather_algo(algo, cout, cin, K, dy.dtype)
+    if code == _lib.WCN_ALGO_MFMA:
+        mask = table_mask(kernel_map, tbl, mask, cout, cin, K, dy.dtype)
     return _gather_gemm(dy, w, tbl, mask, perm, num_in_coords, cout, cin, K, code, transposed=True, flip=flip)
 
 
