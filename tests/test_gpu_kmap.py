@@ -51,6 +51,26 @@ def _check_against_oracle(km, in_np, out_np, ksize, stride=(1, 1, 1), dilation=(
     return r
 
 
+@pytest.mark.parametrize("n", [1, 63, 2049, 1_200_000])
+def test_row_orders_at_the_edges_of_the_sort_plan(n):
+    """One row, less than a wave, one key past a tile, and more than 512 sort tiles (the scan of the per-(tile, digit) counts then
+    leaves its register-resident path): exact and tile orders of a 27-offset mask."""
+    from warpconvnet_amd import _lib
+
+    rng = np.random.default_rng(n)
+    m = (rng.integers(0, 1 << 27, size=n, dtype=np.int64) & rng.integers(0, 1 << 27, size=n, dtype=np.int64)).astype(np.uint32)
+    m |= np.uint32(1 << 13)
+    mask = torch.from_numpy(m.view(np.int32)).to(_dev()).view(n, 1)
+    L = _lib.lib()
+    ws = torch.empty(L.wcn_mask_argsort_workspace(n), dtype=torch.uint8, device=_dev())
+    perm = torch.empty(n, dtype=torch.int32, device=_dev())
+    stream = _lib.stream_handle(_dev())
+    _lib.check(L.wcn_mask_argsort(_lib.ptr(mask), 1, 27, n, _lib.ptr(perm), _lib.ptr(ws), ws.numel(), stream), "argsort")
+    np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(-m.astype(np.int64), kind="stable"))
+    _lib.check(L.wcn_mask_tile_order(_lib.ptr(mask), 1, 27, n, _lib.ptr(perm), _lib.ptr(ws), ws.numel(), stream), "tile order")
+    np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(-tile_order_key(m, 27), kind="stable"))
+
+
 @pytest.mark.parametrize("K", [27, 9, 25, 31, 3, 8, 32, 26])
 def test_row_orders_of_the_c_abi(K):
     """wcn_mask_argsort keeps the reference's order (descending mask, stable: mask_data_kernels.cu:187-220); wcn_mask_tile_order
