@@ -24,6 +24,7 @@ constexpr int kTallyThreads = (kRsTile / kTileRows) * 64;  // one wave per tile,
 constexpr int kStageCap = 3072;  // pairs staged in LDS per (tile, mask word); denser tiles store directly
 
 static_assert(kRsTile % kTileRows == 0, "a sort tile is a whole number of bucket tiles");
+static_assert(kBkThreads == kRsThreads, "the scan launch runs rs_scan_body (mask_sort.h) in its digit workgroups");
 
 // rows of duplicate coordinates (binned path): copy the table row of the row the cell keeps
 __device__ __noinline__ void repair_row(int64_t row, const int4* __restrict__ coords, const CellTable& t, uint32_t cmask,

@@ -55,9 +55,15 @@ def build_cell_grid(ref32: Tensor, cell_size: float = None, min_cell_size: float
     for a in range(3):
         cell3[:, a].clamp_(0, dims[a] - 1)
     cell = (cell3[:, 2] * dims[1] + cell3[:, 1]) * dims[0] + cell3[:, 0]
-    order = torch.argsort(cell, stable=True)
-    sorted_cell = cell[order]
     ncells = dims[0] * dims[1] * dims[2]
+    if ref32.is_cuda:
+        # in-house radix argsort on the (< 2^24) cell ids instead of the framework's merge sort of int64 keys
+        from warpconvnet_amd.geometry.coords.search.torch_discrete import argsort_u32_ascending
+
+        order = argsort_u32_ascending(cell, max(1, (ncells - 1).bit_length())).long()
+    else:
+        order = torch.argsort(cell, stable=True)
+    sorted_cell = cell[order]
     cell_start = torch.searchsorted(sorted_cell, torch.arange(ncells + 1, device=dev, dtype=torch.int64)).to(torch.int32)
     return ref32[order].contiguous(), order.to(torch.int32).contiguous(), cell_start, lo, h, dims
 

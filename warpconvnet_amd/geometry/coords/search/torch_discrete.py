@@ -74,6 +74,27 @@ def mask_argsort(mask: Tensor, num_offsets: int = 32) -> Tensor:
 
 
 @torch.no_grad()
+def argsort_u32_ascending(keys: Tensor, num_bits: int) -> Tensor:
+    """Stable ascending argsort of non-negative int32 keys below ``2 ** num_bits`` (int32 permutation) with the in-house LSD
+    radix sort (`wcn_mask_argsort` orders DESCENDING, ties in ascending row order: the keys go in complemented) - 3 passes
+    for 27 bits where the framework's sort of int64 keys is a block sort + seven merge launches (0.3 ms for 200 k keys)."""
+    n = keys.shape[0]
+    perm = torch.empty(n, dtype=torch.int32, device=keys.device)
+    if n == 0:
+        return perm
+    num_bits = max(1, min(int(num_bits), 31))
+    flipped = (((1 << num_bits) - 1) - keys.to(torch.int32)).contiguous()
+    L = _lib.lib()
+    ws_bytes = L.wcn_mask_argsort_workspace(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=keys.device)
+    _lib.check(
+        L.wcn_mask_argsort(_lib.ptr(flipped), 1, num_bits, n, _lib.ptr(perm), _lib.ptr(ws), ws_bytes, _lib.stream_handle(keys.device)),
+        "wcn_mask_argsort",
+    )
+    return perm
+
+
+@torch.no_grad()
 def attach_tables_from_csr(kmap: IntSearchResult, num_in: int, num_out: int) -> IntSearchResult:
     """Build nbr / mask / perm for a map that only has its CSR form (swapped or user-made maps).
 
