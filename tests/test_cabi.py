@@ -72,6 +72,11 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_conv_identity_supported(48, 64, _lib.WCN_BF16) == 0 and L.wcn_conv_identity_supported(96, 20, _lib.WCN_BF16) == 0
     assert L.wcn_conv_identity_supported(64, 64, _lib.WCN_F32) == 0
     assert L.wcn_bn_apply_residual(None, None, 4, 8, _lib.WCN_BF16, None, None, 1, None, None) == -5
+    # ABI 4 additions: tile order as an entry point, both weight images in one launch, the row mask in the table's last column
+    assert L.wcn_abi_version() >= 4
+    assert L.wcn_conv_mask_in_table_supported(64, 128, 27, _lib.WCN_BF16) == 1
+    assert L.wcn_conv_mask_in_table_supported(64, 128, 32, _lib.WCN_BF16) == 0  # no spare column at K = 32
+    assert L.wcn_pack_weight_pair_supported(27, 64, 128, _lib.WCN_BF16) == 1
     assert L.wcn_bn_backward_reduce_masked(None, None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, None, 0, None) == -5
     assert L.wcn_bn_backward_apply_masked(None, None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, None, None, None, None) == -5
     assert L.wcn_bn_train_forward(None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, 0.1, 1e-5, None, 1, None, None, None, 0, None) == -5

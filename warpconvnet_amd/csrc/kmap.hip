@@ -231,7 +231,10 @@ extern "C" {
 // 2: wcn_pack_weight[_f32] take the size of the destination buffer
 // 3 (additions only): identity map in wcn_conv_gather_gemm (nbr = mask = NULL, one offset) + wcn_conv_identity_supported,
 //    outputs wider than 128 channels on the channel-split kernels, wcn_bn_apply_residual / wcn_bn_backward_*_masked
-int wcn_abi_version(void) { return 3; }
+// 4 (additions only): wcn_mask_tile_order (the binned builder's row order as an entry point), wcn_pack_weight_f32_pair,
+//    mask = NULL with a binned 32-column table in wcn_conv_gather_gemm / wcn_conv_bn_backward (mask in column 31) +
+//    wcn_conv_mask_in_table_supported
+int wcn_abi_version(void) { return 4; }
 
 const char* wcn_status_string(int status) {
   switch (status) {
