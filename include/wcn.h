@@ -261,6 +261,16 @@ int wcn_mfma_wgrad_supported(int32_t cin, int32_t cout, int32_t dtype);
  * through the gather kernel at its HBM rate (the vendor GEMM runs these skinny shapes at 0.15-0.33 of it,
  * profiles/r04_unet_1M_roofline.md).  Shapes: cin % 32 == 0, cin >= 64, cout in {64, 96, 128}, f16 / bf16. */
 int wcn_conv_identity_supported(int32_t cin, int32_t cout, int32_t dtype);
+/* The NARROW 1 x 1 x 1 layers (same reference line, helper.py:206-213): y[n, cout] = x[n, cin] * W (+ bias) for any
+ * cin <= 128, cout <= 96 - the 3 -> 32 stem and the 96 -> 20 head of a MinkUNet and their input gradients - as one streaming
+ * kernel (csrc/dense_rows.hip; the vendor GEMM serves a 20- or 3-column operand at 0.09-0.15 of the HBM rate).  `w` is the
+ * layer's matrix as stored, row-major: [cin, cout], or [cout, cin] with w_transposed = 1 (the input gradient dy * W^T reads the
+ * forward weight in place); its elements are fp32 (w_is_f32 = 1, master weights) or `dtype`, converted in the kernel - no
+ * packed image.  The rows `x` are `dtype`, or fp32 with x_is_f32 = 1 (rounded to `dtype` on the fly, as a cast in front of the
+ * product would).  `y`: [n, cout] in `dtype` (f16 / bf16), fp32 accumulation, optional fp32 bias[cout]. */
+int wcn_dense_rows_supported(int32_t cin, int32_t cout, int32_t dtype);
+int wcn_dense_rows(const void* x, int32_t x_is_f32, const void* w, int32_t w_is_f32, int32_t w_transposed, const float* bias,
+                   void* y, int64_t n, int32_t cin, int32_t cout, int32_t dtype, wcn_stream_t stream);
 
 /* Packed weight image consumed by the MFMA kernels (fragment order, zero padding).  `transpose`=1
  * packs w[k]^T (dgrad); `flip`=1 additionally reverses k (dgrad of a submanifold map reuses the

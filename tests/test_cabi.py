@@ -77,6 +77,11 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_conv_mask_in_table_supported(64, 128, 27, _lib.WCN_BF16) == 1
     assert L.wcn_conv_mask_in_table_supported(64, 128, 32, _lib.WCN_BF16) == 0  # no spare column at K = 32
     assert L.wcn_pack_weight_pair_supported(27, 64, 128, _lib.WCN_BF16) == 1
+    # narrow 1 x 1 x 1 layers (stem / head) as one streaming launch
+    assert L.wcn_dense_rows_supported(96, 20, _lib.WCN_BF16) == 1 and L.wcn_dense_rows_supported(3, 32, _lib.WCN_F16) == 1
+    assert L.wcn_dense_rows_supported(129, 20, _lib.WCN_BF16) == 0 and L.wcn_dense_rows_supported(96, 20, _lib.WCN_F32) == 0
+    assert L.wcn_dense_rows(None, 0, None, 1, 0, None, None, 4, 96, 20, _lib.WCN_BF16, None) == -5
+    assert L.wcn_dense_rows(None, 0, None, 1, 0, None, None, 4, 96, 200, _lib.WCN_BF16, None) != 0
     assert L.wcn_bn_backward_reduce_masked(None, None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, None, 0, None) == -5
     assert L.wcn_bn_backward_apply_masked(None, None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, None, None, None, None) == -5
     assert L.wcn_bn_train_forward(None, None, 4, 8, _lib.WCN_BF16, None, None, None, None, 0.1, 1e-5, None, 1, None, None, None, 0, None) == -5

@@ -729,21 +729,66 @@ def test_dense_rows_through_the_identity_map(cin, cout, dtype, n):
 
     code = _lib.dtype_code(dtype)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    L = _lib.lib()
     y = dense_rows(x, w, False, bias)
-    if _lib.lib().wcn_conv_identity_supported(cin, cout, code):  # cout: 64 / 96 / 128, or wider in blocks of those
-        assert cout != 80 and y is not None and y.dtype == dtype and y.shape == (n, cout)
+    if L.wcn_conv_identity_supported(cin, cout, code) or L.wcn_dense_rows_supported(cin, cout, code):
+        # cout: 64 / 96 / 128, or wider in blocks of those; up to 128 -> 96 through the narrow-layer kernel
+        assert y is not None and y.dtype == dtype and y.shape == (n, cout)
         want = x.double().cpu() @ wq + bias.double().cpu()
         assert float((y.double().cpu() - want).abs().max()) <= eps * float(want.abs().max()) + 1e-6
     else:
-        assert cout == 80 and y is None
+        assert y is None
     dx = dense_rows(dy, w, True)
-    if _lib.lib().wcn_conv_identity_supported(cout, cin, code):
+    if L.wcn_conv_identity_supported(cout, cin, code) or L.wcn_dense_rows_supported(cout, cin, code):
         want = dy.double().cpu() @ wq.t()
         assert dx is not None and float((dx.double().cpu() - want).abs().max()) <= eps * float(want.abs().max()) + 1e-6
     else:
         assert dx is None
-    assert dense_rows(x[:, :48].contiguous(), w[:, :48].contiguous(), False) is None  # cin < 64: not this kernel's
+    assert (cin, cout) != (160, 64) or dx is None  # 64 -> 160: neither kernel's shape, the caller keeps the vendor GEMM
     assert dense_rows(x.float(), w, False) is None
+
+
+@pytest.mark.parametrize("n", [1, 33, 70001])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(3, 32), (96, 20), (20, 96), (5, 7), (1, 1), (100, 36), (127, 93), (128, 96), (16, 64), (48, 64)])
+def test_narrow_layers_as_one_streaming_launch(cin, cout, dtype, n):
+    """wcn_dense_rows (include/wcn.h; reference shortcut helper.py:206-213 `feats @ weight[0]`): x @ W (+ bias) and dy @ W^T for
+    the stem / head shapes the gather kernels do not take - fp32 or 16-bit weights read in place in either orientation, 16-bit
+    or fp32 rows - vs fp64 on the same rounded values, within one rounding of the output type (fp32 accumulation)."""
+    from warpconvnet_amd import _lib
+    from warpconvnet_amd.nn.functional.sparse_conv.pointwise import narrow_rows
+
+    dev = _dev()
+    torch.manual_seed(n * 131 + cin * 7 + cout)
+    w = torch.randn(1, cin, cout, device=dev) / cin ** 0.5
+    x32 = torch.randn(n, cin, device=dev)
+    dy = torch.randn(n, cout, device=dev).to(dtype)
+    bias = torch.randn(cout, device=dev)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert _lib.lib().wcn_dense_rows_supported(cin, cout, _lib.dtype_code(dtype)) == 1
+    wq = w[0].to(dtype).double().cpu()
+    xq = x32.to(dtype).double().cpu()
+    want = xq @ wq + bias.double().cpu()
+    tol = eps * float(want.abs().max()) + 1e-6
+    for rows, weight in ((x32.to(dtype), w), (x32.to(dtype), w.to(dtype)), (x32, w), (x32, w.to(dtype))):
+        y = narrow_rows(rows, weight, False, bias, dtype=dtype)
+        assert y is not None and y.dtype == dtype and y.shape == (n, cout)
+        assert float((y.double().cpu() - want).abs().max()) <= tol
+    y0 = narrow_rows(x32.to(dtype), w, False)  # (no bias)
+    assert float((y0.double().cpu() - xq @ wq).abs().max()) <= tol
+    wantx = dy.double().cpu() @ wq.t()
+    for weight in (w, w.to(dtype)):
+        dx = narrow_rows(dy, weight, True)
+        if cin > 96:  # (the input gradient would have more than 96 columns)
+            assert dx is None
+            continue
+        assert dx is not None and dx.shape == (n, cin)
+        assert float((dx.double().cpu() - wantx).abs().max()) <= eps * float(wantx.abs().max()) + 1e-6
+    # outside the kernel: more than 128 input / 96 output channels, fp32 arithmetic, a weight of a third type
+    assert narrow_rows(x32.to(dtype), torch.randn(1, cin, 97, device=dev), False) is None
+    assert narrow_rows(x32, w, False) is None
+    other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
+    assert narrow_rows(x32.to(dtype), w.to(other), False) is None
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])

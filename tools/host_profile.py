@@ -2,7 +2,7 @@
 Prints forward / backward host-enqueue time and cProfile tables of the forward and of the backward (run with the autograd
 engine's worker threads off, so its nodes execute under the profiler); the .pstats files land in gpurun_out/.  GPU box only.
 
-    python tools/host_profile.py [voxels]
+    python tools/host_profile.py [voxels] [noprof]
 """
 import cProfile
 import os
@@ -50,6 +50,14 @@ for _ in range(10):
     tf += t1 - t0
     tb += t3 - t2
 print(f"{n} voxels: host enqueue forward {tf * 100:.2f} ms, backward {tb * 100:.2f} ms per iteration")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    fwd().backward()
+torch.cuda.synchronize()
+print(f"free-running: {(time.perf_counter() - t0) * 50:.3f} ms per iteration")
+if len(sys.argv) > 2 and sys.argv[2] == "noprof":  # (for a kernel trace: tools/gap_report.py)
+    sys.exit(0)
 
 pr = cProfile.Profile()
 pr.enable()

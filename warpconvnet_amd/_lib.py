@@ -116,6 +116,11 @@ SIGNATURES = {
     "wcn_mfma_gather_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
     "wcn_mfma_wgrad_supported": (c_int, [c_int32, c_int32, c_int32]),
     "wcn_conv_identity_supported": (c_int, [c_int32, c_int32, c_int32]),
+    "wcn_dense_rows_supported": (c_int, [c_int32, c_int32, c_int32]),
+    "wcn_dense_rows": (
+        c_int,
+        [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p],
+    ),
     "wcn_packed_weight_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "wcn_pack_weight": (
         c_int,
@@ -341,6 +346,10 @@ def dtype_code(dtype: torch.dtype) -> int:
     if dtype == torch.bfloat16:
         return WCN_BF16
     raise TypeError(f"unsupported feature dtype {dtype} (supported: float32, float16, bfloat16)")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return {WCN_F32: torch.float32, WCN_F16: torch.float16, WCN_BF16: torch.bfloat16}[code]
 
 
 def i3(v) -> "ctypes.Array":

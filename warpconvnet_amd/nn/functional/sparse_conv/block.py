@@ -236,10 +236,10 @@ class _PointwiseBnAct(Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], plan: _Plan) -> Tensor:
-        from .pointwise import dense_rows
+        from .pointwise import dense_rows, narrow_rows
 
-        y = dense_rows(x, w, False)
-        if y is None:  # (shapes outside the streaming kernel: the vendor GEMM on a cast copy of the weight)
+        y = narrow_rows(x, w, False, dtype=_lib.torch_dtype(plan.code)) if x.dtype == torch.float32 else dense_rows(x, w, False)
+        if y is None:  # (shapes outside the streaming kernels: the vendor GEMM on a cast copy of the weight)
             y = x @ (w[0] if w.dtype == x.dtype else w[0].to(x.dtype))
         out, stats = _bn_forward(plan, y, gamma, beta)
         ctx.save_for_backward(x, y, stats, gamma, w)  # (w: the parameter itself - no copy, and autograd's version check applies)
@@ -340,9 +340,14 @@ def conv_bn_act(x, conv, norm, relu: bool, residual=None, out_spatial=None):
     if (kind == 3) != (out_spatial is not None):
         return None
     if kind == 2:
-        feats = x.feature_tensor
-        if feats.dtype != dtype:
-            feats = feats.to(dtype)
+        from .pointwise import narrow_takes_fp32_rows
+
+        if raw.dtype == torch.float32 and narrow_takes_fp32_rows(cin, cout, code):
+            feats = raw  # (a narrow stem under autocast: the kernel rounds the fp32 rows itself, no cast launch)
+        else:
+            feats = x.feature_tensor
+            if feats.dtype != dtype:
+                feats = feats.to(dtype)
         feats = feats.contiguous()
         plan.km, plan.num_in, plan.num_out = None, feats.shape[0], feats.shape[0]
         (plan.training, plan.momentum, plan.eps, plan.running_mean, plan.running_var, plan.counter,

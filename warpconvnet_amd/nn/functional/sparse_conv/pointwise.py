@@ -9,6 +9,7 @@ ranges + ordered slab reduction, deterministic): ~15 us.  Channel counts outside
 next multiple of 32 for that one product.
 """
 import functools
+import os
 from typing import Optional
 
 import torch
@@ -46,22 +47,24 @@ def _identity_map(n: int, dev: torch.device) -> IntSearchResult:
     return km
 
 
-def _pad_channels(t: Tensor, mult: int = 32) -> Tensor:
+def _pad_channels(t: Tensor, mult: int = 32, dtype: Optional[torch.dtype] = None) -> Tensor:
     c = t.shape[1]
     cp = (c + mult - 1) // mult * mult
+    dtype = t.dtype if dtype is None else dtype
     if cp == c:
-        return t.contiguous()
-    out = torch.zeros((t.shape[0], cp), dtype=t.dtype, device=t.device)
-    out[:, :c] = t
+        return t.contiguous() if t.dtype == dtype else t.to(dtype).contiguous()
+    out = torch.zeros((t.shape[0], cp), dtype=dtype, device=t.device)
+    out[:, :c] = t  # (rounds fp32 rows to the compute type in the same copy)
     return out
 
 
 def dense_wgrad(x: Tensor, dy: Tensor) -> Tensor:
-    """fp32 ``x^T @ dy`` ([Cin, Cout]) of two 16-bit ``[N, C]`` GPU tensors through the sparse wgrad kernel."""
+    """fp32 ``x^T @ dy`` ([Cin, Cout]) of two ``[N, C]`` GPU tensors through the sparse wgrad kernel; ``dy`` is 16-bit, ``x`` is
+    of the same type or fp32 (the rows a narrow stem read unrounded: rounded like its forward did)."""
     from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
 
     n, cin, cout = x.shape[0], x.shape[1], dy.shape[1]
-    xp, gp = _pad_channels(x), _pad_channels(dy)
+    xp, gp = _pad_channels(x, dtype=dy.dtype), _pad_channels(dy)
     dw = hip_gemm.hip_wgrad(xp, gp, _identity_map(n, x.device), (1, xp.shape[1], gp.shape[1]), "hip_mfma")
     return dw[0, :cin, :cout]
 
@@ -71,18 +74,61 @@ def _identity_ok(cin: int, cout: int, code: int) -> bool:
     return bool(_lib.lib().wcn_conv_identity_supported(cin, cout, code))
 
 
+@functools.lru_cache(maxsize=None)
+def _narrow_ok(cin: int, cout: int, code: int) -> bool:
+    # (WARPCONVNET_AMD_NARROW=0: the vendor GEMM for these layers, for A/B timing)
+    return os.environ.get("WARPCONVNET_AMD_NARROW", "1") != "0" and bool(_lib.lib().wcn_dense_rows_supported(cin, cout, code))
+
+
+def narrow_takes_fp32_rows(cin: int, cout: int, code: int) -> bool:
+    """True where a 1 x 1 x 1 layer on fp32 rows under 16-bit autocast runs as `narrow_rows` on the fp32 rows themselves."""
+    return _narrow_ok(cin, cout, code) and not _identity_ok(cin, cout, code)
+
+
+def narrow_rows(x: Tensor, weight3: Tensor, transposed: bool, bias: Optional[Tensor] = None,
+                dtype: Optional[torch.dtype] = None) -> Optional[Tensor]:
+    """The same product for the NARROW layers (stem 3 -> 32, head 96 -> 20 and their input gradients; any cin <= 128, cout <= 96)
+    through `wcn_dense_rows`: one streaming launch that reads the weight where it is (fp32 master or 16-bit, either
+    orientation) - no packed image, no cast copy.  ``x``: 16-bit rows, or fp32 rows with ``dtype`` = the 16-bit compute type
+    (rounded in the kernel, as the cast under autocast would).  None when the kernel does not apply."""
+    _, cin, cout = weight3.shape
+    kin, kout = (cout, cin) if transposed else (cin, cout)
+    out_dtype = dtype if dtype is not None else x.dtype
+    if (not x.is_cuda or out_dtype not in (torch.float16, torch.bfloat16) or x.dtype not in (out_dtype, torch.float32)
+            or x.ndim != 2 or x.shape[0] == 0 or x.shape[1] != kin or weight3.dtype not in (out_dtype, torch.float32)
+            or weight3.device != x.device or not _narrow_ok(kin, kout, _lib.dtype_code(out_dtype))):
+        return None
+    x = x.contiguous()
+    w = weight3.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    n = x.shape[0]
+    out = torch.empty((n, kout), dtype=out_dtype, device=x.device)
+    if bias is not None:
+        bias = bias.detach().float().contiguous()
+    _lib.check(
+        _lib.lib().wcn_dense_rows(_lib.ptr(x), int(x.dtype == torch.float32), _lib.ptr(w), int(w.dtype == torch.float32),
+                                  int(transposed), _lib.ptr(bias), _lib.ptr(out), n, kin, kout, _lib.dtype_code(out_dtype),
+                                  _lib.stream_handle(x.device)),
+        "wcn_dense_rows",
+    )
+    return out
+
+
 def dense_rows(x: Tensor, weight3: Tensor, transposed: bool, bias: Optional[Tensor] = None) -> Optional[Tensor]:
     """``x @ weight3[0]`` (``transposed``: ``x @ weight3[0].T``) for 16-bit ``[N, C]`` GPU rows through the channel-split gather
     kernel with the identity map - a streaming kernel at its HBM rate where the vendor GEMM serves these skinny shapes at
     0.15-0.33 of it.  ``weight3`` is the convolution's ``[1, Cin, Cout]`` weight (its packed image is cached per parameter
-    version like every other layer's).  None when the shape is not one of the kernel's."""
+    version like every other layer's).  Shapes outside that kernel (narrow stems and heads) take `narrow_rows`; None when
+    neither applies."""
     from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
 
     _, cin, cout = weight3.shape
     kin, kout = (cout, cin) if transposed else (cin, cout)
-    if (not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16) or x.shape[0] == 0 or x.shape[1] != kin
-            or not _identity_ok(kin, kout, _lib.dtype_code(x.dtype))):
+    if not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16) or x.shape[0] == 0 or x.shape[1] != kin:
         return None
+    if not _identity_ok(kin, kout, _lib.dtype_code(x.dtype)):
+        return narrow_rows(x, weight3, transposed, bias)
     x = x.contiguous()
     wp = hip_gemm.pack_weight(weight3, transposed, False, dtype=x.dtype)
     n = x.shape[0]
