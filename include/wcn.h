@@ -557,6 +557,13 @@ int wcn_bn_train_forward(const void* x, const void* residual, int64_t n, int32_t
 int wcn_bn_train_backward(const void* dy, const void* x, const void* z, int32_t relu, int64_t n, int32_t channels, int32_t dtype,
                           const float* stats, const float* gamma, int32_t training, float* sums, void* dx, void* dres,
                           void* workspace, size_t workspace_bytes, wcn_stream_t stream);
+/* The same with a row pitch for `dy` (elements; >= channels, 0 = channels): the gradient a channel concatenation hands to one of
+ * its inputs is a column slice of a wider row-major tensor (reference models/mink_unet.py:392-404: `cat` of the up-sampled and
+ * the skip tensor) - read in place instead of through a contiguous copy.  16-B pieces need dy and dy_ld * sizeof(T) 16-B
+ * aligned; anything else takes the element path. */
+int wcn_bn_train_backward_ld(const void* dy, int64_t dy_ld, const void* x, const void* z, int32_t relu, int64_t n, int32_t channels,
+                             int32_t dtype, const float* stats, const float* gamma, int32_t training, float* sums, void* dx,
+                             void* dres, void* workspace, size_t workspace_bytes, wcn_stream_t stream);
 
 /* Layer entry: backward of SparseConv3d -> BatchNorm (-> ReLU | residual tail) (reference models/mink_unet.py:31-53, 160-172 run
  * as three autograd nodes) in one call: wcn_bn_train_backward into `dy_conv` ([n_out][cout], caller's buffer), then
@@ -568,6 +575,14 @@ int wcn_conv_bn_backward(const void* grad_out, const void* x, const void* y, con
                          const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets, float* dw, void* wgrad_workspace,
                          size_t wgrad_workspace_bytes, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets,
                          int32_t dtype, void* bn_workspace, size_t bn_workspace_bytes, wcn_stream_t stream);
+/* ... with a row pitch for `grad_out` (see wcn_bn_train_backward_ld). */
+int wcn_conv_bn_backward_ld(const void* grad_out, int64_t grad_out_ld, const void* x, const void* y, const void* z, int32_t relu,
+                            const float* stats, const float* gamma, int32_t training, float* sums, void* dy_conv, void* dres,
+                            const void* w_packed_dgrad, const int32_t* rev_nbr, const uint32_t* rev_mask, const int32_t* rev_perm,
+                            int32_t flip, void* dx, const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets,
+                            float* dw, void* wgrad_workspace, size_t wgrad_workspace_bytes, int64_t n_in, int64_t n_out,
+                            int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype, void* bn_workspace,
+                            size_t bn_workspace_bytes, wcn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -405,3 +405,92 @@ def test_fused_node_on_scenes_the_optimistic_build_rejects(case):
                     net[1].weight.grad.clone(), net[1].bias.grad.clone(), net[1].running_mean.clone(), net[1].running_var.clone()])
     for u, v in zip(*res):
         assert torch.isfinite(u.float()).all() and torch.equal(u, v)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("c,left,right", [(96, 32, 0), (32, 0, 96), (64, 3, 5), (20, 4, 0), (40, 8, 8)])
+@pytest.mark.parametrize("tail", [False, True])
+def test_backward_reads_a_column_slice_of_a_wider_gradient_in_place(dtype, c, left, right, tail):
+    """`wcn_bn_train_backward_ld` (include/wcn.h): the gradient `torch.cat` hands to one of its inputs (reference
+    models/mink_unet.py:392-404) is a column slice of a wider row-major tensor; the reduce and apply passes read it with its row
+    pitch.  Same sums, same gradients, bit for bit, as on a contiguous copy - 16-B pieces where pitch and offset allow, the
+    element path otherwise; `tail`: the masked passes of a residual tail."""
+    from warpconvnet_amd import _lib
+
+    dev = torch.device(DEV)
+    L = _lib.lib()
+    st = _lib.stream_handle(dev)
+    code = _lib.dtype_code(dtype)
+    n = 30_011
+    torch.manual_seed(c + left)
+    y = torch.randn(n, c, device=dev).to(dtype)
+    z = torch.randn(n, c, device=dev).to(dtype) if tail else None
+    wide = torch.randn(n, left + c + right, device=dev).to(dtype)
+    g = wide[:, left:left + c]
+    assert not g.is_contiguous() or left + right == 0
+    gamma = torch.rand(c, device=dev) + 0.5
+    stats = torch.empty(5, c, device=dev)
+    stats[0], stats[1] = y.float().mean(0), 1.0 / (y.float().var(0, unbiased=False) + 1e-5).sqrt()
+    stats[2], stats[3] = gamma * stats[1], -stats[0] * gamma * stats[1]
+    ws = torch.empty(L.wcn_bn_workspace(c), dtype=torch.uint8, device=dev)
+
+    def run(rows, ld):
+        sums = torch.empty(2, c, device=dev)
+        dx, dres = torch.empty_like(y), (torch.empty_like(y) if tail else None)
+        _lib.check(L.wcn_bn_train_backward_ld(_lib.ptr(rows), ld, _lib.ptr(y), _lib.ptr(z), 1, n, c, code, _lib.ptr(stats),
+                                              _lib.ptr(gamma), 1, _lib.ptr(sums), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(ws),
+                                              ws.numel(), st), "wcn_bn_train_backward_ld")
+        return sums, dx, dres
+
+    a = run(g, wide.shape[1])
+    b = run(g.contiguous(), 0)
+    vec = 16 // y.element_size()
+    if c % vec != 0 or (g.data_ptr() % 16 == 0 and (wide.shape[1] * y.element_size()) % 16 == 0):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and (not tail or torch.equal(a[2], b[2]))
+    else:
+        # a misaligned slice takes the element path: another reduction order than the 16-B path of the contiguous copy
+        # (`block._grad_rows` hands such slices over as copies, so a network never sees the difference)
+        assert rel_max_err(a[0], b[0]) < 1e-5 and rel_max_err(a[1].float(), b[1].float()) < 2e-2
+        assert not tail or torch.equal(a[2], b[2])  # (the masked gradient is elementwise)
+    assert L.wcn_bn_train_backward_ld(_lib.ptr(g), c - 1, _lib.ptr(y), None, 1, n, c, code, _lib.ptr(stats), _lib.ptr(gamma), 1,
+                                      _lib.ptr(a[0]), None, None, _lib.ptr(ws), ws.numel(), st) == -5  # pitch below the row length
+
+
+def test_fused_blocks_under_a_channel_concatenation_take_the_sliced_gradient():
+    """Two fused conv -> BN -> ReLU blocks whose outputs are concatenated and fed to a third (the decoder pattern of
+    `models/mink_unet.py`): gradients equal the module-by-module run bit for bit - the sliced gradients reach the BatchNorm
+    backward without a contiguous copy (`block._grad_rows`)."""
+    import os
+
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sequential import Sequential
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = torch.device(DEV)
+    coords = torch.from_numpy(scene_u(20000, 14)[:, 1:]).to(dev)
+    n = coords.shape[0]
+    torch.manual_seed(5)
+    a = Sequential(SparseConv3d(32, 96, 3, bias=False), nn.BatchNorm1d(96), nn.ReLU()).to(dev)
+    b = Sequential(SparseConv3d(32, 32, 3, bias=False), nn.BatchNorm1d(32), nn.ReLU()).to(dev)
+    c = Sequential(SparseConv3d(128, 64, 3, bias=False), nn.BatchNorm1d(64), nn.ReLU()).to(dev)
+    feats = torch.randn(n, 32, device=dev)
+    off = torch.tensor([0, n], dtype=torch.int32)
+
+    def run(fused):
+        os.environ["WARPCONVNET_AMD_FUSED_BLOCK"] = "1" if fused else "0"
+        try:
+            for m in (a, b, c):
+                m.zero_grad(set_to_none=True)
+            f = feats.clone().requires_grad_(True)
+            x = Voxels(coords, f, offsets=off)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                ya, yb = a(x), b(x)
+                cat = ya.replace(batched_features=torch.cat([ya.feature_tensor, yb.feature_tensor], dim=1))
+                out = c(cat)
+            out.feature_tensor.float().square().mean().backward()
+            return [p.grad.clone() for m in (a, b, c) for p in m.parameters()] + [f.grad.clone()]
+        finally:
+            os.environ.pop("WARPCONVNET_AMD_FUSED_BLOCK", None)
+
+    for u, v in zip(run(True), run(False)):
+        assert torch.equal(u, v)

@@ -64,6 +64,12 @@ SIGNATURES = {
                                      c_void_p]),
     "wcn_bn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                       c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_bn_train_backward_ld": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                         c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wcn_conv_bn_backward_ld": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                        c_void_p, c_size_t, c_void_p]),
     "wcn_conv_bn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,

@@ -234,9 +234,21 @@ int wcn_conv_bn_backward(const void* grad_out, const void* x, const void* y, con
                          const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets, float* dw, void* wgrad_workspace,
                          size_t wgrad_workspace_bytes, int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets,
                          int32_t dtype, void* bn_workspace, size_t bn_workspace_bytes, wcn_stream_t stream) {
+  return wcn_conv_bn_backward_ld(grad_out, 0, x, y, z, relu, stats, gamma, training, sums, dy_conv, dres, w_packed_dgrad, rev_nbr,
+                                 rev_mask, rev_perm, flip, dx, in_maps, out_maps, offsets, dw, wgrad_workspace, wgrad_workspace_bytes,
+                                 n_in, n_out, cin, cout, num_offsets, dtype, bn_workspace, bn_workspace_bytes, stream);
+}
+
+int wcn_conv_bn_backward_ld(const void* grad_out, int64_t grad_out_ld, const void* x, const void* y, const void* z, int32_t relu,
+                            const float* stats, const float* gamma, int32_t training, float* sums, void* dy_conv, void* dres,
+                            const void* w_packed_dgrad, const int32_t* rev_nbr, const uint32_t* rev_mask, const int32_t* rev_perm,
+                            int32_t flip, void* dx, const int32_t* in_maps, const int32_t* out_maps, const int32_t* offsets,
+                            float* dw, void* wgrad_workspace, size_t wgrad_workspace_bytes, int64_t n_in, int64_t n_out,
+                            int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype, void* bn_workspace,
+                            size_t bn_workspace_bytes, wcn_stream_t stream) {
   if (!dy_conv || (dtype != WCN_F16 && dtype != WCN_BF16)) return WCN_ERROR_INVALID_PARAMETERS;
-  int rc = wcn_bn_train_backward(grad_out, y, z, relu, n_out, cout, dtype, stats, gamma, training, sums, dy_conv, dres, bn_workspace,
-                                 bn_workspace_bytes, stream);
+  int rc = wcn_bn_train_backward_ld(grad_out, grad_out_ld, y, z, relu, n_out, cout, dtype, stats, gamma, training, sums, dy_conv, dres,
+                                    bn_workspace, bn_workspace_bytes, stream);
   if (rc != WCN_SUCCESS) return rc;
   if (dx) {
     if (!w_packed_dgrad || !rev_nbr) return WCN_ERROR_INVALID_PARAMETERS;  // (rev_mask may ride in the table: wcn_conv_gather_gemm checks)

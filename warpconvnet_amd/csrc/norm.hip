@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
                                                           const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                           int64_t n, int c,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          float* __restrict__ partial, const T* __restrict__ zmask) {
+                                                          float* __restrict__ partial, const T* __restrict__ zmask,
+                                                          int64_t dy_ld) {
   // zmask (MODE 1, instead of rscale / rshift): the stored output of ReLU(BN(x) + residual); g = dy where it is positive
+  // dy_ld: row pitch of dy in elements (a column slice of a wider tensor - the gradient of a channel concatenation - is read in place)
   __shared__ float s_red[2][256 * VEC];
   const int tid = threadIdx.x;
   const int cgroups = (c + VEC - 1) / VEC;
@@ -112,14 +114,15 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const T* __restrict__ 
 #pragma unroll
         for (int q = 0; q < kNormRowsInFlight; ++q) {
           const int64_t rq = r + (int64_t)q * rsteps;
-          const int64_t at = (rq < r1 ? rq : r1 - 1) * c + ch0;
+          const int64_t rc = rq < r1 ? rq : r1 - 1;
+          const int64_t at = rc * c + ch0;
           if (VEC > 1) {
             xv[q] = *reinterpret_cast<const NVec<T, VEC>*>(x + at);
-            if (MODE == 1) gv[q] = *reinterpret_cast<const NVec<T, VEC>*>(dy + at);
+            if (MODE == 1) gv[q] = *reinterpret_cast<const NVec<T, VEC>*>(dy + rc * dy_ld + ch0);
             if (MODE == 1 && zmask) zv[q] = *reinterpret_cast<const NVec<T, VEC>*>(zmask + at);
           } else {
             xv[q].v[0] = x[at];
-            if (MODE == 1) gv[q].v[0] = dy[at];
+            if (MODE == 1) gv[q].v[0] = dy[rc * dy_ld + ch0];
             if (MODE == 1 && zmask) zv[q].v[0] = zmask[at];
           }
         }
@@ -288,7 +291,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ sum_dy,
                                                              const float* __restrict__ sum_dy_xhat, T* __restrict__ dx,
-                                                             const T* __restrict__ zmask, T* __restrict__ dres) {
+                                                             const T* __restrict__ zmask, T* __restrict__ dres,
+                                                             int64_t dy_ld) {
   // zmask / dres: residual tail - the mask is the stored output's sign, the masked gradient is also the residual branch's
   extern __shared__ float s_coef[];  // [5][c]: A, B, C, and scale / shift of the forward pass (ReLU mask)
   const float inv_n = 1.0f / (float)n;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
   const int64_t total = n * cv;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int ch0 = (int)(e % cv) * VEC;
-    const NVec<T, VEC> gv = *reinterpret_cast<const NVec<T, VEC>*>(dy + e * VEC);
+    const NVec<T, VEC> gv = *reinterpret_cast<const NVec<T, VEC>*>(dy + (dy_ld == c ? e * VEC : (e / cv) * dy_ld + ch0));
     const NVec<T, VEC> xv = *reinterpret_cast<const NVec<T, VEC>*>(x + e * VEC);
     NVec<T, VEC> ov, zv, mv;
     if (zmask) zv = *reinterpret_cast<const NVec<T, VEC>*>(zmask + e * VEC);
@@ -338,15 +342,16 @@ template <typename T>
 static int bn_reduce_t(int mode, const void* x, const void* dy, const float* rscale, const float* rshift, int64_t n, int c,
                        const float* mean,
                        const float* rstd, float* out0, float* out1, float* partial, hipStream_t s,
-                       const BnFold& fold = BnFold(), const void* zmask = nullptr) {
+                       const BnFold& fold = BnFold(), const void* zmask = nullptr, int64_t dy_ld = 0) {
   constexpr int VEC = 16 / (int)sizeof(T);
+  if (dy_ld <= 0) dy_ld = c;
   // first-level workgroups: at least 128 rows each (small tensors: fewer partial sums for the second level), kNormBlocks at most
   int64_t nb = ceil_div(n < 1 ? 1 : n, 128);
   const int nblocks = (int)(nb < kNormBlocks ? nb : kNormBlocks);
-  const bool vec = c % VEC == 0;
+  const bool vec = c % VEC == 0 && dy_ld % VEC == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
 #define WCN_NR(V, M)                                                                                                  \
   hipLaunchKernelGGL((norm_reduce_kernel<T, V, M>), dim3(nblocks), dim3(256), 0, s, (const T*)x, (const T*)dy,          \
-                     rscale, rshift, n, c, mean, rstd, partial, (const T*)zmask)
+                     rscale, rshift, n, c, mean, rstd, partial, (const T*)zmask, dy_ld)
   if (mode == 0) { if (vec) WCN_NR(VEC, 0); else WCN_NR(1, 0); }
   else { if (vec) WCN_NR(VEC, 1); else WCN_NR(1, 1); }
 #undef WCN_NR
@@ -376,16 +381,17 @@ template <typename T>
 static int bn_bwd_apply_t(const void* dy, const void* x, const float* rscale, const float* rshift, int64_t n, int c,
                           const float* mean,
                           const float* rstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat, void* dx,
-                          hipStream_t s, const void* zmask = nullptr, void* dres = nullptr) {
+                          hipStream_t s, const void* zmask = nullptr, void* dres = nullptr, int64_t dy_ld = 0) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  if (c % VEC == 0)
+  if (dy_ld <= 0) dy_ld = c;
+  if (c % VEC == 0 && dy_ld % VEC == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0)
     hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC>), dim3(norm_grid(n * (c / VEC), 4096)), dim3(256), (size_t)5 * c * 4, s,
                        (const T*)dy, (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx,
-                       (const T*)zmask, (T*)dres);
+                       (const T*)zmask, (T*)dres, dy_ld);
   else
     hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(norm_grid(n * c, 4096)), dim3(256), (size_t)5 * c * 4, s, (const T*)dy,
                        (const T*)x, rscale, rshift, n, c, mean, rstd, gamma, sum_dy, sum_dy_xhat, (T*)dx, (const T*)zmask,
-                       (T*)dres);
+                       (T*)dres, dy_ld);
   return launch_status();
 }
 
@@ -456,25 +462,34 @@ int wcn_bn_apply(const void* x, int64_t n, int32_t channels, int32_t dtype, cons
   }
 }
 
-int wcn_bn_backward_reduce(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
-                           int32_t channels, int32_t dtype, const float* mean, const float* rstd, float* sum_dy,
-                           float* sum_dy_xhat, void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
+static int bn_backward_reduce_ld(const void* dy, int64_t dy_ld, const void* x, const float* relu_scale, const float* relu_shift,
+                                int64_t n, int32_t channels, int32_t dtype, const float* mean, const float* rstd, float* sum_dy,
+                                float* sum_dy_xhat, void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
   if (n < 1 || channels < 1 || !bn_dtype_ok(dtype) || !dy || !x || !mean || !rstd || !sum_dy || !sum_dy_xhat ||
       !workspace || workspace_bytes < wcn_bn_workspace(channels) || ((relu_scale == nullptr) != (relu_shift == nullptr)))
     return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
   float* p = (float*)workspace;
   switch (dtype) {
-    case WCN_F32: return bn_reduce_t<float>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
-    case WCN_F16: return bn_reduce_t<__half>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
+    case WCN_F32:
+      return bn_reduce_t<float>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, BnFold(), nullptr, dy_ld);
+    case WCN_F16:
+      return bn_reduce_t<__half>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, BnFold(), nullptr, dy_ld);
     default:
-      return bn_reduce_t<__hip_bfloat16>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s);
+      return bn_reduce_t<__hip_bfloat16>(1, x, dy, relu_scale, relu_shift, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, BnFold(),
+                                         nullptr, dy_ld);
   }
 }
+int wcn_bn_backward_reduce(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
+                           int32_t channels, int32_t dtype, const float* mean, const float* rstd, float* sum_dy,
+                           float* sum_dy_xhat, void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
+  return bn_backward_reduce_ld(dy, 0, x, relu_scale, relu_shift, n, channels, dtype, mean, rstd, sum_dy, sum_dy_xhat, workspace,
+                               workspace_bytes, stream);
+}
 
-int wcn_bn_backward_apply(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
-                          int32_t channels, int32_t dtype, const float* mean, const float* rstd, const float* gamma,
-                          const float* sum_dy, const float* sum_dy_xhat, void* dx, wcn_stream_t stream) {
+static int bn_backward_apply_ld(const void* dy, int64_t dy_ld, const void* x, const float* relu_scale, const float* relu_shift,
+                               int64_t n, int32_t channels, int32_t dtype, const float* mean, const float* rstd, const float* gamma,
+                               const float* sum_dy, const float* sum_dy_xhat, void* dx, wcn_stream_t stream) {
   if (n < 0 || channels < 1 || !bn_dtype_ok(dtype) || ((relu_scale == nullptr) != (relu_shift == nullptr)))
     return WCN_ERROR_INVALID_PARAMETERS;
   if (n == 0) return WCN_SUCCESS;
@@ -482,12 +497,20 @@ int wcn_bn_backward_apply(const void* dy, const void* x, const float* relu_scale
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case WCN_F32:
-      return bn_bwd_apply_t<float>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
+      return bn_bwd_apply_t<float>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, nullptr,
+                                   nullptr, dy_ld);
     case WCN_F16:
-      return bn_bwd_apply_t<__half>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
+      return bn_bwd_apply_t<__half>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, nullptr,
+                                    nullptr, dy_ld);
     default:
-      return bn_bwd_apply_t<__hip_bfloat16>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s);
+      return bn_bwd_apply_t<__hip_bfloat16>(dy, x, relu_scale, relu_shift, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s,
+                                            nullptr, nullptr, dy_ld);
   }
+}
+int wcn_bn_backward_apply(const void* dy, const void* x, const float* relu_scale, const float* relu_shift, int64_t n,
+                          int32_t channels, int32_t dtype, const float* mean, const float* rstd, const float* gamma,
+                          const float* sum_dy, const float* sum_dy_xhat, void* dx, wcn_stream_t stream) {
+  return bn_backward_apply_ld(dy, 0, x, relu_scale, relu_shift, n, channels, dtype, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, stream);
 }
 
 // ---- residual tail: z = [ReLU](BN(x) + residual), reference models/mink_unet.py:160-172 ----
@@ -505,9 +528,9 @@ int wcn_bn_apply_residual(const void* x, const void* residual, int64_t n, int32_
   }
 }
 
-int wcn_bn_backward_reduce_masked(const void* dy, const void* x, const void* z, int64_t n, int32_t channels, int32_t dtype,
-                                  const float* mean, const float* rstd, float* sum_dy, float* sum_dy_xhat, void* workspace,
-                                  size_t workspace_bytes, wcn_stream_t stream) {
+static int bn_backward_reduce_masked_ld(const void* dy, int64_t dy_ld, const void* x, const void* z, int64_t n, int32_t channels,
+                                       int32_t dtype, const float* mean, const float* rstd, float* sum_dy, float* sum_dy_xhat,
+                                       void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
   if (n < 1 || channels < 1 || !bn_dtype_ok(dtype) || !dy || !x || !z || !mean || !rstd || !sum_dy || !sum_dy_xhat ||
       !workspace || workspace_bytes < wcn_bn_workspace(channels))
     return WCN_ERROR_INVALID_PARAMETERS;
@@ -515,29 +538,39 @@ int wcn_bn_backward_reduce_masked(const void* dy, const void* x, const void* z, 
   float* p = (float*)workspace;
   const BnFold nf;
   switch (dtype) {
-    case WCN_F32: return bn_reduce_t<float>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z);
-    case WCN_F16: return bn_reduce_t<__half>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z);
+    case WCN_F32: return bn_reduce_t<float>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z, dy_ld);
+    case WCN_F16: return bn_reduce_t<__half>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z, dy_ld);
     default:
-      return bn_reduce_t<__hip_bfloat16>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z);
+      return bn_reduce_t<__hip_bfloat16>(1, x, dy, nullptr, nullptr, n, channels, mean, rstd, sum_dy, sum_dy_xhat, p, s, nf, z, dy_ld);
   }
 }
+int wcn_bn_backward_reduce_masked(const void* dy, const void* x, const void* z, int64_t n, int32_t channels, int32_t dtype,
+                                  const float* mean, const float* rstd, float* sum_dy, float* sum_dy_xhat, void* workspace,
+                                  size_t workspace_bytes, wcn_stream_t stream) {
+  return bn_backward_reduce_masked_ld(dy, 0, x, z, n, channels, dtype, mean, rstd, sum_dy, sum_dy_xhat, workspace, workspace_bytes, stream);
+}
 
-int wcn_bn_backward_apply_masked(const void* dy, const void* x, const void* z, int64_t n, int32_t channels, int32_t dtype,
-                                 const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
-                                 const float* sum_dy_xhat, void* dx, void* dres, wcn_stream_t stream) {
+static int bn_backward_apply_masked_ld(const void* dy, int64_t dy_ld, const void* x, const void* z, int64_t n, int32_t channels,
+                                      int32_t dtype, const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
+                                      const float* sum_dy_xhat, void* dx, void* dres, wcn_stream_t stream) {
   if (n < 0 || channels < 1 || !bn_dtype_ok(dtype)) return WCN_ERROR_INVALID_PARAMETERS;
   if (n == 0) return WCN_SUCCESS;
   if (!dy || !x || !z || !dx || !mean || !rstd || !sum_dy || !sum_dy_xhat) return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case WCN_F32:
-      return bn_bwd_apply_t<float>(dy, x, nullptr, nullptr, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, z, dres);
+      return bn_bwd_apply_t<float>(dy, x, nullptr, nullptr, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, z, dres, dy_ld);
     case WCN_F16:
-      return bn_bwd_apply_t<__half>(dy, x, nullptr, nullptr, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, z, dres);
+      return bn_bwd_apply_t<__half>(dy, x, nullptr, nullptr, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, z, dres, dy_ld);
     default:
       return bn_bwd_apply_t<__hip_bfloat16>(dy, x, nullptr, nullptr, n, channels, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, s, z,
-                                            dres);
+                                            dres, dy_ld);
   }
+}
+int wcn_bn_backward_apply_masked(const void* dy, const void* x, const void* z, int64_t n, int32_t channels, int32_t dtype,
+                                 const float* mean, const float* rstd, const float* gamma, const float* sum_dy,
+                                 const float* sum_dy_xhat, void* dx, void* dres, wcn_stream_t stream) {
+  return bn_backward_apply_masked_ld(dy, 0, x, z, n, channels, dtype, mean, rstd, gamma, sum_dy, sum_dy_xhat, dx, dres, stream);
 }
 
 // ---- layer entries: the BatchNorm of a training step in one call per direction ----
@@ -563,10 +596,12 @@ int wcn_bn_train_forward(const void* x, const void* residual, int64_t n, int32_t
 // `z`: the stored output of a residual tail (mask = its sign), or NULL (`relu`: the mask is recomputed from x and the forward's
 // scale / shift).  `sums`: [2][channels] = sum_dy (bias gradient) | sum_dy_xhat (weight gradient).  `dx` NULL: sums only.
 // `training` 0: the statistics were constants (eval mode) - dx without the mean terms.
-int wcn_bn_train_backward(const void* dy, const void* x, const void* z, int32_t relu, int64_t n, int32_t channels, int32_t dtype,
-                          const float* stats, const float* gamma, int32_t training, float* sums, void* dx, void* dres,
-                          void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
-  if (!stats || !sums || channels < 1) return WCN_ERROR_INVALID_PARAMETERS;
+// `dy_ld`: row pitch of dy in elements (>= channels; 0 = channels) - a column slice of a wider row-major tensor, e.g. the
+// gradient a channel concatenation hands to one of its inputs, is read where it is instead of through a contiguous copy.
+int wcn_bn_train_backward_ld(const void* dy, int64_t dy_ld, const void* x, const void* z, int32_t relu, int64_t n, int32_t channels,
+                             int32_t dtype, const float* stats, const float* gamma, int32_t training, float* sums, void* dx,
+                             void* dres, void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
+  if (!stats || !sums || channels < 1 || (dy_ld != 0 && dy_ld < channels)) return WCN_ERROR_INVALID_PARAMETERS;
   const float* mean = stats;
   const float* rstd = stats + channels;
   const float* rsc = (relu && !z) ? stats + 2 * (int64_t)channels : nullptr;
@@ -574,10 +609,10 @@ int wcn_bn_train_backward(const void* dy, const void* x, const void* z, int32_t 
   float* sum_dy = sums;
   float* sum_dy_xhat = sums + channels;
   const bool masked = z && relu;
-  int rc = masked ? wcn_bn_backward_reduce_masked(dy, x, z, n, channels, dtype, mean, rstd, sum_dy, sum_dy_xhat, workspace,
-                                                  workspace_bytes, stream)
-                  : wcn_bn_backward_reduce(dy, x, rsc, rsh, n, channels, dtype, mean, rstd, sum_dy, sum_dy_xhat, workspace,
-                                           workspace_bytes, stream);
+  int rc = masked ? bn_backward_reduce_masked_ld(dy, dy_ld, x, z, n, channels, dtype, mean, rstd, sum_dy, sum_dy_xhat, workspace,
+                                                 workspace_bytes, stream)
+                  : bn_backward_reduce_ld(dy, dy_ld, x, rsc, rsh, n, channels, dtype, mean, rstd, sum_dy, sum_dy_xhat, workspace,
+                                          workspace_bytes, stream);
   if (rc != WCN_SUCCESS || !dx) return rc;
   const float* a0 = sum_dy;
   const float* a1 = sum_dy_xhat;
@@ -587,8 +622,15 @@ int wcn_bn_train_backward(const void* dy, const void* x, const void* z, int32_t 
       return WCN_ERROR_KERNEL_EXECUTION;
     a0 = a1 = zeros;
   }
-  return masked ? wcn_bn_backward_apply_masked(dy, x, z, n, channels, dtype, mean, rstd, gamma, a0, a1, dx, dres, stream)
-                : wcn_bn_backward_apply(dy, x, rsc, rsh, n, channels, dtype, mean, rstd, gamma, a0, a1, dx, stream);
+  return masked ? bn_backward_apply_masked_ld(dy, dy_ld, x, z, n, channels, dtype, mean, rstd, gamma, a0, a1, dx, dres, stream)
+                : bn_backward_apply_ld(dy, dy_ld, x, rsc, rsh, n, channels, dtype, mean, rstd, gamma, a0, a1, dx, stream);
+}
+
+int wcn_bn_train_backward(const void* dy, const void* x, const void* z, int32_t relu, int64_t n, int32_t channels, int32_t dtype,
+                          const float* stats, const float* gamma, int32_t training, float* sums, void* dx, void* dres,
+                          void* workspace, size_t workspace_bytes, wcn_stream_t stream) {
+  return wcn_bn_train_backward_ld(dy, 0, x, z, relu, n, channels, dtype, stats, gamma, training, sums, dx, dres, workspace,
+                                  workspace_bytes, stream);
 }
 
 }  // extern "C"

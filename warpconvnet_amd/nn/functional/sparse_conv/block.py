@@ -83,6 +83,22 @@ def _bn_forward(plan: _Plan, y: Tensor, gamma: Optional[Tensor], beta: Optional[
     return out, stats
 
 
+def _grad_rows(grad_out: Tensor, like: Tensor):
+    """-> (tensor to read, row pitch in elements).  The gradient a channel concatenation hands to one of its inputs is a column
+    slice of a wider row-major tensor (`torch.cat` backward: `narrow`): the BatchNorm backward kernels read it in place."""
+    g = grad_out
+    if g.dtype != like.dtype:
+        return g.contiguous().to(like.dtype), like.shape[1]
+    if g.is_contiguous():
+        return g, g.shape[1]
+    if (g.ndim == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1] and g.shape[0] > 0
+            and g.data_ptr() % 16 == 0 and (g.stride(0) * g.element_size()) % 16 == 0):
+        # (16-B aligned rows only: a misaligned slice would take the kernels' element path, whose reduction order differs from
+        # the one a contiguous tensor gets - results must not depend on the layout of the incoming gradient)
+        return g, g.stride(0)
+    return g.contiguous(), g.shape[1]
+
+
 def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, stats: Tensor, gamma: Optional[Tensor], need_dy: bool,
                  z: Optional[Tensor] = None, need_dres: bool = False):
     """One C call (`wcn_bn_train_backward`: reduce + apply).  -> (gradient of the convolution's output or None, sums [2, C] =
@@ -91,19 +107,17 @@ def _bn_backward(plan: _Plan, grad_out: Tensor, y: Tensor, stats: Tensor, gamma:
     L = _lib.lib()
     dev = y.device
     M, cout, code = plan.num_out, plan.cout, plan.code
-    g = grad_out.contiguous()
-    if g.dtype != y.dtype:
-        g = g.to(y.dtype)
+    g, g_ld = _grad_rows(grad_out, y)
     sums = torch.empty((2, cout), dtype=torch.float32, device=dev)
     ws = _bn_workspace(cout, dev)
     masked = z is not None and plan.relu  # (BN(y) + r without activation: the gradient reaches both branches unmasked)
     want_dx = need_dy or (masked and need_dres)
     dyc = torch.empty_like(y) if want_dx else None
     dres = torch.empty_like(y) if (masked and need_dres) else None
-    _lib.check(L.wcn_bn_train_backward(_lib.ptr(g), _lib.ptr(y), _lib.ptr(z) if masked else None, int(plan.relu), M, cout, code,
-                                       stats.data_ptr(), _lib.ptr(gamma), int(plan.training), sums.data_ptr(), _lib.ptr(dyc),
-                                       _lib.ptr(dres), _lib.ptr(ws), ws.numel(), _lib.stream_handle(dev)),
-               "wcn_bn_train_backward")
+    _lib.check(L.wcn_bn_train_backward_ld(_lib.ptr(g), g_ld, _lib.ptr(y), _lib.ptr(z) if masked else None, int(plan.relu), M, cout,
+                                          code, stats.data_ptr(), _lib.ptr(gamma), int(plan.training), sums.data_ptr(),
+                                          _lib.ptr(dyc), _lib.ptr(dres), _lib.ptr(ws), ws.numel(), _lib.stream_handle(dev)),
+               "wcn_bn_train_backward_ld")
     if need_dres and not masked:
         dres = g
     return (dyc if need_dy else None), sums, dres
@@ -181,9 +195,7 @@ class _ConvBnAct(Function):
             ctx.plan = None
             return dx, dw, dgamma, dbeta, None, dres
         # one C call: BatchNorm reduce + apply -> dgrad on the reverse tables -> wgrad (wcn_conv_bn_backward)
-        g = grad_out.contiguous()
-        if g.dtype != y.dtype:
-            g = g.to(y.dtype)
+        g, g_ld = _grad_rows(grad_out, y)
         masked = z is not None and plan.relu
         sums = torch.empty((2, cout), dtype=torch.float32, device=dev)
         dyc = torch.empty_like(y)
@@ -213,12 +225,12 @@ class _ConvBnAct(Function):
             ws_bytes = hip_gemm._wgrad_workspace(K, cin, cout, _lib.WCN_ALGO_MFMA)
             wws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         bws = _bn_workspace(cout, dev)
-        _lib.check(L.wcn_conv_bn_backward(
-            _lib.ptr(g), _lib.ptr(x), _lib.ptr(y), _lib.ptr(z) if masked else None, int(plan.relu), stats.data_ptr(), _lib.ptr(gamma),
+        _lib.check(L.wcn_conv_bn_backward_ld(
+            _lib.ptr(g), g_ld, _lib.ptr(x), _lib.ptr(y), _lib.ptr(z) if masked else None, int(plan.relu), stats.data_ptr(), _lib.ptr(gamma),
             int(plan.training), sums.data_ptr(), _lib.ptr(dyc), _lib.ptr(dres), _lib.ptr(wpd), _lib.ptr(tbl), _lib.ptr(msk),
             _lib.ptr(perm), int(flip), _lib.ptr(dx), _lib.ptr(km.in_maps_device) if need_dw else None,
             _lib.ptr(km.out_maps_device) if need_dw else None, _lib.ptr(km._offsets_dev) if need_dw else None, _lib.ptr(dw),
-            _lib.ptr(wws), ws_bytes, plan.num_in, M, cin, cout, K, code, _lib.ptr(bws), bws.numel(), stream), "wcn_conv_bn_backward")
+            _lib.ptr(wws), ws_bytes, plan.num_in, M, cin, cout, K, code, _lib.ptr(bws), bws.numel(), stream), "wcn_conv_bn_backward_ld")
         if need_dres and not masked:
             dres = g
         if dw is not None and dw.dtype != w.dtype:
