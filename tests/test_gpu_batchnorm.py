@@ -494,3 +494,39 @@ def test_fused_blocks_under_a_channel_concatenation_take_the_sliced_gradient():
 
     for u, v in zip(run(True), run(False)):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 32), (20, 48), (64, 20)])
+def test_narrow_stem_node_reads_fp32_rows_and_returns_an_fp32_gradient(cin, cout):
+    """A 1 x 1 x 1 conv -> BN -> ReLU block on fp32 features under bf16 autocast whose shape belongs to the narrow-layer kernel
+    (`wcn_dense_rows`): the fused node hands the fp32 rows to the kernel (rounded there) instead of casting them first.  Output,
+    parameter gradients and the gradient of the fp32 input leaf equal the module-by-module run bit for bit."""
+    import os
+
+    from warpconvnet_amd.geometry.types.voxels import Voxels
+    from warpconvnet_amd.nn.modules.sequential import Sequential
+    from warpconvnet_amd.nn.modules.sparse_conv import SparseConv3d
+
+    dev = torch.device(DEV)
+    coords = torch.from_numpy(scene_u(9000, 21)[:, 1:]).to(dev)
+    n = coords.shape[0]
+    torch.manual_seed(cin + cout)
+    blk = Sequential(SparseConv3d(cin, cout, 1, bias=False), nn.BatchNorm1d(cout), nn.ReLU()).to(dev)
+    feats = torch.randn(n, cin, device=dev)
+    off = torch.tensor([0, n], dtype=torch.int32)
+
+    def run(fused):
+        os.environ["WARPCONVNET_AMD_FUSED_BLOCK"] = "1" if fused else "0"
+        try:
+            blk.zero_grad(set_to_none=True)
+            f = feats.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = blk(Voxels(coords, f, offsets=off)).feature_tensor
+            out.float().square().mean().backward()
+            assert f.grad.dtype == torch.float32
+            return [out.detach().clone(), f.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+        finally:
+            os.environ.pop("WARPCONVNET_AMD_FUSED_BLOCK", None)
+
+    for u, v in zip(run(True), run(False)):
+        assert torch.equal(u, v)
