@@ -181,14 +181,17 @@ class BuildHints:
       million voxels at 16); the device reports TABLE_FULL for sparser scenes and the bound moves to N / 4, then N;
     * ``pairs_per_row``: pairs per output row of the last maps - sizes the pair lists an OPTIMISTIC build writes before the
       host has read the pair count (an underestimate is caught on the host: the pair count exceeds the capacity, the
-      kernel wrote nothing past it, and the lists are written again at their exact length).
+      kernel wrote nothing past it, and the lists are written again at their exact length).  Remembered PER KERNEL VOLUME: a
+      network alternates 3 x 3 x 3 maps (9 - 18 pairs per row) with stride-window ones (4 - 6), and one shared estimate was
+      short for every map that followed a sparser kind - four lists written twice per MinkUNet iteration.
 
     ``generate_kernel_map(..., hints=...)`` takes an explicit object (tests pass fresh ones so that the rebuild branches
     are reached deterministically); the default is one object per process, `default_hints()`."""
 
     def __init__(self, div: int = 16, pairs_per_row: float = 12.0):
         self.div = int(div)
-        self.pairs_per_row = float(pairs_per_row)
+        self.pairs_per_row = float(pairs_per_row)  # kernel volumes not seen yet
+        self._by_volume = {}                       # kernel volume -> pairs per row of its last maps
 
     def reset(self) -> None:
         self.__init__()
@@ -197,12 +200,16 @@ class BuildHints:
         return max(1024, n // self.div) if self.div > 1 else max(n, 1)
 
     def pair_capacity(self, rows: int, num_offsets: int) -> int:
-        return int(min(num_offsets * rows, rows * self.pairs_per_row * 1.25 + 4096))
+        per_row = self._by_volume.get(int(num_offsets), self.pairs_per_row)
+        return int(min(num_offsets * rows, rows * per_row * 1.25 + 4096))
 
-    def observe_pairs(self, rows: int, pairs: int) -> None:
+    def observe_pairs(self, rows: int, pairs: int, num_offsets: int = 0) -> None:
         if rows > 0:
             seen = pairs / rows
             self.pairs_per_row = seen if seen > self.pairs_per_row else 0.5 * (self.pairs_per_row + seen)
+            if num_offsets > 0:
+                cur = self._by_volume.get(int(num_offsets))
+                self._by_volume[int(num_offsets)] = seen if cur is None or seen > cur else 0.5 * (cur + seen)
 
 
 _DEFAULT_HINTS = BuildHints()
@@ -446,7 +453,7 @@ def generate_kernel_map(
         identity = K // 2 if (odd and unit_stride and N == M) else None
         if has_duplicates and same_tensor:
             identity = None  # "output row i == input row i at the centre offset" fails for the rows that lost their coordinate
-        hints.observe_pairs(M, pair_capacity)
+        hints.observe_pairs(M, pair_capacity, K)
         if use_binned and not (flags & (_lib.WCN_FLAG_TABLE_FULL | _lib.WCN_FLAG_NEED_STRICT)):
             # the cell table of this coordinate set is complete and keeps the smallest row of every coordinate: strided
             # layers on the same tensor reuse it (down-sampling and their kernel maps, coords/ops/stride.py)
@@ -504,7 +511,8 @@ def generate_kernel_map(
             # the pair lists (the weight gradient's input) without knowing the pair count: capacity from the pairs per row of
             # earlier maps (`hints`; the kernel writes nothing past it, validate() rewrites a short guess at the exact length),
             # the scatter queued right behind the mask sort while the neighbour table is still in the Infinity Cache
-            first["spec_pairs"] = scatter(first, hints.pair_capacity(M, K))
+            # (a stride-window map pairs every input row with at most one cell: N bounds its lists exactly)
+            first["spec_pairs"] = scatter(first, min(N, K * M) if prebuilt is not None else hints.pair_capacity(M, K))
         attach_tables(result, first)
 
         def validate_fn(res, b=first):
