@@ -27,7 +27,7 @@ def timed(fn, reps=20):
     return a.elapsed_time(b) / reps * 1e3
 
 
-for cin, cout in ((96, 20), (3, 32), (32, 20), (128, 128), (48, 64)):
+for cin, cout in ((96, 20), (3, 32), (32, 20), (48, 64)):
     w = torch.randn(1, cin, cout, device=dev) / cin ** 0.5
     wb = w[0].to(torch.bfloat16)
     x = torch.randn(n, cin, device=dev).to(torch.bfloat16)

@@ -8,7 +8,8 @@
 // columns; this kernel takes everything else up to 128 input and 96 output channels:
 //   * one wave per 32 consecutive rows, transposed product (A = 32 output channels of W^T from LDS, B = the 32 rows): a lane
 //     requests all of its row's k-slices up front (16-B pieces of one contiguous 32 x cin block), the result tile holds, per
-//     lane, four runs of 4 consecutive channels of ONE row -> 8-B stores, no LDS round trip for the output;
+//     lane, four runs of 4 consecutive channels of ONE row -> 8-B stores (cout % 8 == 0: the lane pair (l, l + 32) swaps its
+//     middle runs with v_permlane32_swap and stores 16-B pieces), no LDS round trip for the output;
 //   * W is read in its storage type (fp32 master weights or T) and layout ([cin, cout], or transposed for the input gradient)
 //     and converted while the workgroup builds its fragment image in LDS: no packed image, no cast launch; rows may be fp32
 //     (the stem under autocast: rounded to T on the fly, as the cast in front of the vendor GEMM would);
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kDrThreads) void dense_rows_kernel(const XT* __rest
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5;
-  const bool vec_in = (cin & 3) == 0, vec8 = (cin & 7) == 0, vec_out = (cout & 3) == 0;
+  const bool vec_in = (cin & 3) == 0, vec8 = (cin & 7) == 0, vec_out = (cout & 3) == 0, vec16_out = (cout & 7) == 0;
   float bv[NB][4][4];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
@@ -130,7 +131,31 @@ __global__ __launch_bounds__(kDrThreads) void dense_rows_kernel(const XT* __rest
         for (int b = 0; b < NB; ++b) acc[b] = DFrag<T>::mfma(s_w[(b * kDrMaxSteps + s) * 64 + lane], xs[s], acc[b]);
       }
     }
-    if (row < n) {
+    if (vec16_out) {
+      // cout % 8 == 0: a lane pair (l, l + 32) holds channels {0-3, 8-11} / {4-7, 12-15} of every 16 of its row; one
+      // v_permlane32_swap per register exchanges the middle runs, and each lane stores 8 consecutive channels as one 16-B piece
+      T* yr = y + (row < n ? row : n - 1) * cout;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          typedef __attribute__((ext_vector_type(2))) T pair_t;
+          uint32_t ra[2], rb[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            pair_t pa, pb;
+            pa[0] = (T)acc[b][8 * m + 2 * q]; pa[1] = (T)acc[b][8 * m + 2 * q + 1];
+            pb[0] = (T)acc[b][8 * m + 4 + 2 * q]; pb[1] = (T)acc[b][8 * m + 4 + 2 * q + 1];
+            ra[q] = __builtin_bit_cast(uint32_t, pa);
+            rb[q] = __builtin_bit_cast(uint32_t, pb);
+            const auto sw = __builtin_amdgcn_permlane32_swap(ra[q], rb[q], false, false);  // ra lanes 32-63 <-> rb lanes 0-31
+            ra[q] = sw[0];
+            rb[q] = sw[1];
+          }
+          const int ch = b * 32 + 16 * m + 8 * half;
+          if (row < n && ch < cout) *reinterpret_cast<uint4*>(yr + ch) = make_uint4(ra[0], ra[1], rb[0], rb[1]);
+        }
+    } else if (row < n) {
       T* yr = y + row * cout;
 #pragma unroll
       for (int b = 0; b < NB; ++b)
