@@ -91,6 +91,7 @@ class IntSearchResult:
         self._num_out: Optional[int] = None
         self._pair_table_cache: Optional[Tensor] = None
         self._validate_fn = None  # optimistic builds: reads the status word, finishes / repeats the build (see validate)
+        self._stride_window = False  # kernel_size == stride map from the down-sampling pass: one (output, offset) per input row
         self._validating = False
         self._identity: Optional[int] = None
         self._validate_error: Optional[Exception] = None  # a build the device rejected for good: raised by every validate()

@@ -159,7 +159,14 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
                                _lib.stream_handle(dev)),
             "wcn_kmap_reverse",
         )
-        kmap._rev = (rev_nbr, rev_mask, mask_argsort(rev_mask, K))
+        if getattr(kmap, "_stride_window", False) and kmap.in_maps_device.shape[0] == num_in:
+            # a stride-window map (kernel_size == stride) pairs every input row with exactly one (output row, offset): the
+            # reverse masks are one-hot, and the input side of the pair lists - rows grouped by offset, CSR order - already IS
+            # a permutation of the input rows in which a tile meets one offset: no sort (3 launches per strided layer)
+            rev_perm = kmap.in_maps_device
+        else:
+            rev_perm = mask_argsort(rev_mask, K)
+        kmap._rev = (rev_nbr, rev_mask, rev_perm)
     return kmap._rev
 
 
@@ -500,6 +507,7 @@ def generate_kernel_map(
     result = IntSearchResult._blank(K, dev)
     result._num_in, result._num_out = N, M
     result._kernel_size = ksize
+    result._stride_window = prebuilt is not None  # (tables written by the down-sampling pass: every input row in one window)
     first = launch()
     if optimistic:
         # The caller launches its forward kernel on these tables BEFORE the status word is read (`IntSearchResult.validate`
