@@ -233,7 +233,8 @@ extern "C" {
 //    outputs wider than 128 channels on the channel-split kernels, wcn_bn_apply_residual / wcn_bn_backward_*_masked
 // 4 (additions only): wcn_mask_tile_order (the binned builder's row order as an entry point), wcn_pack_weight_f32_pair,
 //    mask = NULL with a binned 32-column table in wcn_conv_gather_gemm / wcn_conv_bn_backward (mask in column 31) +
-//    wcn_conv_mask_in_table_supported
+//    wcn_conv_mask_in_table_supported, wcn_dense_rows[_supported] (narrow 1 x 1 x 1 layers), wcn_bn_train_backward_ld /
+//    wcn_conv_bn_backward_ld (row pitch for the incoming gradient; the entries without _ld are unchanged)
 int wcn_abi_version(void) { return 4; }
 
 const char* wcn_status_string(int status) {
