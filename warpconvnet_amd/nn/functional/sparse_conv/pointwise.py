@@ -53,6 +53,8 @@ def _pad_channels(t: Tensor, mult: int = 32, dtype: Optional[torch.dtype] = None
     dtype = t.dtype if dtype is None else dtype
     if cp == c:
         return t.contiguous() if t.dtype == dtype else t.to(dtype).contiguous()
+    if t.dtype == dtype:
+        return torch.nn.functional.pad(t, (0, cp - c))  # (one launch)
     out = torch.zeros((t.shape[0], cp), dtype=dtype, device=t.device)
     out[:, :c] = t  # (rounds fp32 rows to the compute type in the same copy)
     return out
