@@ -119,6 +119,34 @@ class BatchedTensor:
     def equal_rigorous(self, value: "BatchedTensor") -> bool:
         return self.equal_shape(value) and bool((self.batched_tensor == value.batched_tensor).all())
 
+    # -- arithmetic with scalars / one-element tensors / batches of the same shape (reference batched.py:190-238) --
+    def binary_op(self, value: object, op: str) -> "BatchedTensor":
+        if isinstance(value, (int, float)) or (torch.is_tensor(value) and value.numel() == 1):
+            return self._new(getattr(self.batched_tensor, op)(value))
+        assert isinstance(value, BatchedTensor) and self.equal_shape(value), "operands must be batches of the same shape"
+        return self._new(getattr(self.batched_tensor, op)(value.batched_tensor))
+
+    def __add__(self, value):
+        return self.binary_op(value, "__add__")
+
+    def __sub__(self, value):
+        return self.binary_op(value, "__sub__")
+
+    def __mul__(self, value):
+        return self.binary_op(value, "__mul__")
+
+    def __truediv__(self, value):
+        return self.binary_op(value, "__truediv__")
+
+    def __floordiv__(self, value):
+        return self.binary_op(value, "__floordiv__")
+
+    def __mod__(self, value):
+        return self.binary_op(value, "__mod__")
+
+    def __pow__(self, value):
+        return self.binary_op(value, "__pow__")
+
     def __repr__(self) -> str:
         return (
             f"{self.__class__.__name__}(offsets={self.offsets.tolist()}, "

@@ -1,10 +1,10 @@
 """Point cloud with real coordinates (reference `warpconvnet/geometry/types/points.py:33-326`).
 
-Only the surface needed by the sparse-conv hot path and its immediate callers is provided
-(construction, neighbour search, voxel down-sampling, conversion to ``Voxels``); orderings, sinusoidal
-encodings and patch ops belong to other model families (out of scope).
+The surface the sparse-conv hot path and its immediate callers use: construction (incl. ``from_list_of_coordinates`` with
+sinusoidal features), neighbour search, voxel / random down-sampling, space-filling-curve ``sort``, ``contiguous`` and the
+conversion to ``Voxels``; patch ops belong to other model families (out of scope).
 """
-from typing import List, Optional, Union
+from typing import List, Optional, Tuple, Union
 
 import torch
 from torch import Tensor
@@ -45,6 +45,69 @@ class Points(Geometry):
     @property
     def voxel_size(self):
         return self._extra_attributes.get("voxel_size", None)
+
+    @property
+    def ordering(self):
+        return self._extra_attributes.get("ordering", None)
+
+    @classmethod
+    def from_list_of_coordinates(
+        cls,
+        coordinates: Union[List[Tensor], Tensor],
+        features: Optional[List[Tensor]] = None,
+        encoding_channels: Optional[int] = None,
+        encoding_range: Optional[Union[float, Tuple[float, float]]] = None,
+        encoding_dim: Optional[int] = -1,
+    ) -> "Points":
+        """Points from per-batch coordinate tensors (a [B, N, D] tensor is split along its first axis); without ``features``
+        every point gets the sinusoidal encoding of its coordinates, ``encoding_channels`` per axis
+        (reference `points.py:283-317`)."""
+        from warpconvnet_amd.nn.functional.encodings import sinusoidal_encoding
+
+        if isinstance(coordinates, Tensor):
+            coordinates = list(coordinates)
+        if features is None:
+            assert encoding_range is not None, "Encoding range must be provided if encoding channels are provided"
+            features = [sinusoidal_encoding(c, encoding_channels, encoding_range, encoding_dim) for c in coordinates]
+        return cls(RealCoords(coordinates), CatFeatures(features))
+
+    def sort(self, voxel_size: float, ordering="morton_xyz") -> "Points":
+        """Rows of every batch element in space-filling-curve order of their ``voxel_size`` cells; points of one cell keep
+        their input order (the sort is stable).  Reference `points.py:92-120` (device only there too: the codes come from a
+        device kernel)."""
+        from warpconvnet_amd.geometry.coords.ops.serialization import encode
+
+        assert self.device.type != "cpu", "Sorting is only supported on GPU"
+        result = encode(torch.floor(self.coordinate_tensor / voxel_size).int(), batch_offsets=self.offsets,
+                        order=ordering, return_perm=True)
+        return self.__class__(
+            RealCoords(self.coordinate_tensor[result.perm], self.offsets),
+            CatFeatures(self.feature_tensor[result.perm], self.offsets),
+            **self.extra_attributes.copy(),
+        )
+
+    def random_downsample(self, num_sample_points: int) -> "Points":
+        """``num_sample_points`` rows drawn with replacement from every batch element (reference `points.py:189-208`,
+        `coords/sample.py:11-31`): the result holds ``batch_size * num_sample_points`` points."""
+        from warpconvnet_amd.geometry.coords.sample import random_sample_per_batch
+
+        idx, offsets = random_sample_per_batch(self.offsets, num_sample_points)
+        idx = idx.to(self.coordinate_tensor.device, torch.int64)
+        return self.__class__(
+            RealCoords(self.coordinate_tensor[idx], offsets),
+            CatFeatures(self.feature_tensor[idx], offsets),
+            **self.extra_attributes,
+        )
+
+    def contiguous(self) -> "Points":
+        """``self`` when coordinates and features are already contiguous, else a copy that is (reference `points.py:210-236`)."""
+        if self.coordinate_tensor.is_contiguous() and self.feature_tensor.is_contiguous():
+            return self
+        return self.__class__(
+            RealCoords(self.coordinate_tensor.contiguous(), self.offsets),
+            CatFeatures(self.feature_tensor.contiguous(), self.offsets),
+            **self.extra_attributes,
+        )
 
     def neighbors(self, search_args, query_coords: Optional[Coords] = None):
         """CSR neighbour lists (``RealSearchResult``); cached per (config, offsets) like the reference."""
