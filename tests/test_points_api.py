@@ -136,3 +136,13 @@ def test_sort_orders_every_batch_element_along_the_curve(ordering):
     for b in range(points.batch_size):
         seg = codes[int(s.offsets[b]) : int(s.offsets[b + 1])]
         assert bool((seg[1:] >= seg[:-1]).all())
+
+
+def test_geometry_types_are_dataclasses_like_the_reference():  # reference geometry.py:38-63, test_points.py:61-74
+    p = Points([torch.rand(10, 3)], [torch.rand(10, 2)], voxel_size=0.1)
+    d = dataclasses.asdict(p)
+    assert set(d) == {"batched_coordinates", "batched_features", "_extra_attributes"}
+    assert d["_extra_attributes"]["voxel_size"] == 0.1
+    r = dataclasses.replace(p)
+    assert type(r) is Points and r.extra_attributes["voxel_size"] == 0.1 and r is not p
+    assert hash(p) != hash(r) and p != r  # identity semantics are kept

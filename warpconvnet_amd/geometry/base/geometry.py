@@ -4,6 +4,7 @@ API of the reference `warpconvnet/geometry/base/geometry.py:38-388`: ``replace()
 ``_extra_attributes`` (incl. the kernel-map ``_cache``) forward, ``feature_tensor`` follows the autocast
 dtype, arithmetic acts on features, ``to()`` returns new objects.
 """
+from dataclasses import dataclass, field
 from typing import Any, Dict, Optional, Union
 
 import torch
@@ -14,7 +15,15 @@ from warpconvnet_amd.geometry.base.features import Features
 from warpconvnet_amd.geometry.features.cat import to_batched_features
 
 
+@dataclass(eq=False)
 class Geometry:
+    # a dataclass like the reference's (geometry.py:38-63): `dataclasses.asdict / replace / fields` work on every geometry
+    # type (reference tests/types/test_points.py:61-74); the hand-written __init__ below is kept by the decorator.  eq=False:
+    # identity comparison and hashing stay (the generated __eq__ would compare tensors element-wise and drop __hash__).
+    batched_coordinates: Coords
+    batched_features: Features
+    _extra_attributes: Dict[str, Any] = field(default_factory=dict, init=True)
+
     def __init__(self, batched_coordinates: Union[Coords, Tensor], batched_features, **kwargs):
         offsets = kwargs.pop("offsets", None)
         device = kwargs.pop("device", None)
