@@ -259,14 +259,14 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
     bias = conv.bias.detach().float()
 
     def k_fwd(m):
-        # (as the module launches it: the rows of a binned table carry their masks - `hip_gemm.table_mask` -> NULL)
-        Lc.wcn_conv_gather_gemm(_lib.ptr(X), _lib.ptr(wp_f), _lib.ptr(y_buf), _lib.ptr(m._nbr),
-                                _lib.ptr(hip_gemm.table_mask(m, m._nbr, m._mask, CIN, COUT, KVOL, torch.bfloat16)),
+        # (as the module launches it: the binned builder's compact rows and no mask array - `hip_gemm.own_tables`)
+        tb, mk = hip_gemm.own_tables(m, CIN, COUT, KVOL, torch.bfloat16)
+        Lc.wcn_conv_gather_gemm(_lib.ptr(X), _lib.ptr(wp_f), _lib.ptr(y_buf), _lib.ptr(tb), _lib.ptr(mk),
                                 _lib.ptr(m._perm), _lib.ptr(bias), N, N, CIN, COUT, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 0, 0, stream)
 
     def k_dgrad(m):
-        Lc.wcn_conv_gather_gemm(_lib.ptr(grad_out), _lib.ptr(wp_d), _lib.ptr(dx_buf), _lib.ptr(m._nbr),
-                                _lib.ptr(hip_gemm.table_mask(m, m._nbr, m._mask, COUT, CIN, KVOL, torch.bfloat16)),
+        tb, mk = hip_gemm.own_tables(m, COUT, CIN, KVOL, torch.bfloat16)
+        Lc.wcn_conv_gather_gemm(_lib.ptr(grad_out), _lib.ptr(wp_d), _lib.ptr(dx_buf), _lib.ptr(tb), _lib.ptr(mk),
                                 _lib.ptr(m._perm), None, N, N, COUT, CIN, KVOL, _lib.WCN_BF16, _lib.WCN_ALGO_MFMA, 1, 1, stream)
 
     def k_wgrad(m):

@@ -54,8 +54,10 @@ enum wcn_kmap_flag {
   WCN_FLAG_PAIR_OVERFLOW = 4,   /* in_maps/out_maps capacity smaller than the number of pairs       */
   WCN_FLAG_DUPLICATE_COORD = 8, /* informational: the inserted coordinates are not all distinct (the smallest row wins,
                                    so the centre neighbour of a later duplicate is not the row itself)          */
-  WCN_FLAG_NEED_STRICT = 16     /* binned builder, strict = 0: a duplicate coordinate kept a row that is not the smallest
+  WCN_FLAG_NEED_STRICT = 16,    /* binned builder, strict = 0: a duplicate coordinate kept a row that is not the smallest
                                    one - the tables are NOT valid, rebuild with strict = 1                         */
+  WCN_FLAG_ROW_OVERFLOW = 32    /* binned builder, compact = 1: a row has more than 15 neighbours and does not fit a compact
+                                   row - the tables are NOT valid, rebuild with compact = 0                        */
 };
 
 /* ---- misc ------------------------------------------------------------------------------------ */
@@ -133,12 +135,22 @@ int wcn_morton_code(const int32_t* coords, int64_t n, int32_t num_dims, const in
  *               wcn_kmap_tally_sort repairs them, which is why K % 32 == 0 is not supported here
  * Returns WCN_ERROR_PROBLEM_NOT_SUPPORTED when the kernel halo (max |offset| per axis, dilation included) exceeds 8 cells or K % 32 == 0
  * (wcn_kmap_binned_supported == 0): the caller then uses the hash path.
+ *   compact     0: nbr is the dense [n, kp] table above.  1 (wcn_kmap_compact_supported: one mask word and 17 <= K <= 31, e.g. the
+ *               3 x 3 x 3 kernel): nbr is [n, 16] COMPACT rows - word 0 = the row's mask, words 1 .. popcount(mask) = the neighbour
+ *               rows of its SET offsets in ascending k, the rest unspecified - 64 B per row instead of 128 for 4 - 9 neighbours
+ *               (round 6: half the bytes for the builder's stores, the pair scatter and both gather GEMMs).  A row with more
+ *               than 15 neighbours raises WCN_FLAG_ROW_OVERFLOW (tables invalid, rebuild with compact = 0).  Consumers of compact
+ *               tables: wcn_kmap_tally_sort / wcn_kmap_scatter (compact = 1), the gather GEMMs where
+ *               wcn_conv_compact_table_supported (`mask` = NULL), wcn_kmap_densify for everything else.
  * reference being replaced: cuhash_hash_table.cu:179-220 + cuhash_kernel_map.cu:93-134. */
 size_t wcn_kmap_binned_workspace(int64_t n, int64_t max_blocks);
 int wcn_kmap_binned_supported(const int32_t ksize[3], const int32_t dilation[3]);
+int wcn_kmap_compact_supported(int32_t num_offsets);
 int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[3], const int32_t dilation[3],
-                          int64_t max_blocks, int32_t strict, void* workspace, size_t workspace_bytes, int32_t* nbr,
-                          uint32_t* mask, int32_t* status, wcn_stream_t stream);
+                          int64_t max_blocks, int32_t strict, int32_t compact, void* workspace, size_t workspace_bytes,
+                          int32_t* nbr, uint32_t* mask, int32_t* status, wcn_stream_t stream);
+/* compact rows [m, 16] -> the dense table nbr [m, kp] (-1 = absent): for consumers without a compact path. */
+int wcn_kmap_densify(const int32_t* nbr_compact, int64_t m, int32_t num_offsets, int32_t* nbr, wcn_stream_t stream);
 /* Everything between the neighbour table and the ONE host read of a build:
  *   tally  per-(offset, tile) pair counts from the masks, the first digit histogram of the mask sort, and - when
  *          `binned_workspace` (the workspace of the wcn_kmap_build_binned call that produced nbr / mask, with its n and
@@ -147,6 +159,11 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
  *          memory) is given, offsets ++ [*status] ++ [ready] there in the same launch: `ready` (cleared by the caller)
  *          becomes 1 last, behind a system-scope fence, so the host may spin on it instead of waiting for an event
  *   sort   perm = rows by descending mask (wcn_mask_argsort), the first digit already counted
+ *   pairs  (in_maps / out_maps given, pair_capacity > 0: round 6) the pair lists of wcn_kmap_scatter queued behind the sort by
+ *          the same call, at a capacity the caller guesses before the pair count is known.  A capacity below the pair count:
+ *          nothing past it is written, the caller compares it with offsets[K] (in the mirror by then) and runs
+ *          wcn_kmap_scatter at the exact length.
+ *   compact  nbr holds COMPACT rows (wcn_kmap_build_binned)
  * counts: wcn_kmap_counts_bytes(m, K) bytes, consumed by wcn_kmap_scatter.  sort_workspace:
  * wcn_kmap_tally_sort_workspace(m) bytes.  reference: postprocess_count + torch.cumsum + mask_argsort
  * (cuhash_kernel_map.cu:508-544, torch_discrete.py:268-272, mask_data_kernels.cu:187-220). */
@@ -154,7 +171,8 @@ size_t wcn_kmap_tally_sort_workspace(int64_t m);
 int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* counts, int32_t* offsets,
                         int32_t* status, int32_t* host_mirror, int32_t* perm, void* sort_workspace,
                         size_t sort_workspace_bytes, const int32_t* coords, void* binned_workspace, int64_t binned_n,
-                        int64_t max_blocks, wcn_stream_t stream);
+                        int64_t max_blocks, int32_t compact, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
+                        wcn_stream_t stream);
 /* counts[k][b] = pairs of offset k in the 256-row tile b (k-major, from the masks); counts = wcn_kmap_counts_bytes bytes.
  * reference: _C.cuhash.postprocess_count (cuhash_kernel_map.cu:508-544). */
 int wcn_kmap_count(const uint32_t* mask, int64_t m, int32_t num_offsets, int32_t* counts, wcn_stream_t stream);
@@ -173,7 +191,7 @@ int wcn_kmap_scan_to_host(int32_t* counts, int64_t num_blocks, int32_t num_offse
  * pair_capacity = length of in_maps/out_maps; sets WCN_FLAG_PAIR_OVERFLOW in *status if too small. */
 int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets,
                      const int32_t* counts, const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
-                     int32_t* status, wcn_stream_t stream);
+                     int32_t* status, int32_t compact, wcn_stream_t stream);
 /* ---- strided layers from the cell table of the FINE set (no global hash table) ------------------------------------------
  * `cells_workspace` = the workspace of a wcn_kmap_build_binned call on the fine coordinates (with its n and max_blocks)
  * whose status word came back without TABLE_FULL / NEED_STRICT.
@@ -300,12 +318,12 @@ int wcn_pack_weight_f32_pair(const float* w, int32_t num_offsets, int32_t cin, i
  *   w:   for WCN_ALGO_REF the plain [K, cin, cout] tensor (or [K, cout', cin'] with w_transposed=1),
  *        for WCN_ALGO_MFMA the image made by wcn_pack_weight.
  * reference: _C.mask_gemm.fwd / .dgrad (mask_gemm_bindings.cu:2074-2101). */
-/* Mask in the table (round 5).  A neighbour-table row of 32 columns for K <= 31 offsets has a free last column; wcn_kmap_build_binned
- * stores the row's MASK there (same 128-B store as the row).  Where wcn_conv_mask_in_table_supported (channel-split kernel shapes,
- * row pitch 32), wcn_conv_gather_gemm / wcn_conv_bn_backward accept `mask` = NULL with a table and read the mask with the index slab:
- * gathering mask[perm[i]] is one 128-B line per row (128 MB of fabric requests per launch at 1 M rows for 4 MB of masks).  Tables
- * from other builders (wcn_kmap_probe, wcn_kmap_from_csr, wcn_kmap_reverse, strided maps) do NOT carry it: pass their mask. */
-int wcn_conv_mask_in_table_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype);
+/* Compact tables (round 6; round 5 carried the mask in column 31 of a dense row instead).  Where wcn_conv_compact_table_supported
+ * (channel-split kernel shapes, wcn_kmap_compact_supported(K)), wcn_conv_gather_gemm / _fused / _f32out / wcn_conv_bn_backward accept
+ * `mask` = NULL with `nbr` = the COMPACT table of wcn_kmap_build_binned(compact = 1): the rows are expanded into the kernel's index
+ * slab - half the table bytes, and no gather of mask[perm[i]] (one 128-B line per row: 128 MB of fabric requests per launch at 1 M
+ * rows for 4 MB of masks).  Dense tables (every other builder) always come with their mask. */
+int wcn_conv_compact_table_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype);
 int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t* nbr,
                          const uint32_t* mask, const int32_t* perm, const float* bias, int64_t n_in,
                          int64_t n_out, int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype,

@@ -74,8 +74,15 @@ def test_pure_host_entry_points(hip_lib):
     assert L.wcn_bn_apply_residual(None, None, 4, 8, _lib.WCN_BF16, None, None, 1, None, None) == -5
     # ABI 4 additions: tile order as an entry point, both weight images in one launch, the row mask in the table's last column
     assert L.wcn_abi_version() >= 4
-    assert L.wcn_conv_mask_in_table_supported(64, 128, 27, _lib.WCN_BF16) == 1
-    assert L.wcn_conv_mask_in_table_supported(64, 128, 32, _lib.WCN_BF16) == 0  # no spare column at K = 32
+    # ABI 5: compact neighbour rows (17 <= K <= 31) replace the mask-in-column-31 convention of ABI 4
+    assert L.wcn_abi_version() >= 5
+    assert L.wcn_kmap_compact_supported(27) == 1 and L.wcn_kmap_compact_supported(25) == 1
+    assert L.wcn_kmap_compact_supported(9) == 0 and L.wcn_kmap_compact_supported(32) == 0 and L.wcn_kmap_compact_supported(125) == 0
+    assert L.wcn_conv_compact_table_supported(64, 128, 27, _lib.WCN_BF16) == 1
+    assert L.wcn_conv_compact_table_supported(64, 128, 32, _lib.WCN_BF16) == 0  # two mask words
+    assert L.wcn_conv_compact_table_supported(32, 32, 27, _lib.WCN_BF16) == 0   # not a channel-split shape
+    assert L.wcn_kmap_densify(None, 4, 27, None, None) == -5 and L.wcn_kmap_densify(None, 0, 27, None, None) == 0
+    assert L.wcn_kmap_densify(None, 4, 9, None, None) == -5
     assert L.wcn_pack_weight_pair_supported(27, 64, 128, _lib.WCN_BF16) == 1
     # narrow 1 x 1 x 1 layers (stem / head) as one streaming launch
     assert L.wcn_dense_rows_supported(96, 20, _lib.WCN_BF16) == 1 and L.wcn_dense_rows_supported(3, 32, _lib.WCN_F16) == 1

@@ -151,38 +151,81 @@ def test_forward_and_dgrad_weight_images_in_one_launch(dtype, cin, cout, flip):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (96, 96), (64, 256)])
-def test_mask_read_from_the_table_row_equals_the_mask_array(dtype, cin, cout):
-    """Round 5: the binned builder stores a row's mask in the free last column of its 32-column table row and the channel-split
-    kernels read it with the index slab (`mask` = NULL) instead of gathering mask[perm[i]].  Same tiles, same steps: forward and
-    dgrad bit-identical to the launches that are handed the mask array; duplicates and out-of-table rows included."""
+def test_compact_table_rows_equal_the_dense_table(dtype, cin, cout):
+    """Round 6: the binned builder writes COMPACT rows (mask + the neighbours of the set offsets, 64 B) and the channel-split
+    kernels expand them into their index slab (`mask` = NULL).  Same tiles, same steps: forward and dgrad bit-identical to the
+    launches on the dense table + mask array expanded from them; duplicates and out-of-table rows included."""
     from warpconvnet_amd import _lib
     from warpconvnet_amd.nn.functional.sparse_conv.detail import hip_gemm
 
     s = np.concatenate([scene_u(3000, 51, 0), scene_u(1100, 52, 1)], 0)
-    s = np.concatenate([s, s[:40]], 0)  # 40 duplicated coordinates: repaired rows copy their winner's row, mask column included
+    s = np.concatenate([s, s[:40]], 0)  # 40 duplicated coordinates: repaired rows copy their winner's compact row
     km = _kmap(s, s, (3, 3, 3), same=True)
-    assert km._mask_in_table
-    np.testing.assert_array_equal(km._nbr[:, 31].cpu().numpy().view(np.uint32), km._mask[:, 0].cpu().numpy().view(np.uint32))
+    assert km._nbrc is not None and km._nbr_dense is None and km.has_tables
+    tb, mk = hip_gemm.own_tables(km, cin, cout, 27, dtype)
+    assert tb is km._nbrc and mk is None
+    np.testing.assert_array_equal(km._nbrc[:, 0].cpu().numpy().view(np.uint32), km._mask[:, 0].cpu().numpy().view(np.uint32))
+    dense = km._nbr  # expanded on first use
+    assert dense.shape == (len(s), 32) and km._nbr_dense is dense
+    r = okmap.kernel_map(s, s, (3, 3, 3))
+    np.testing.assert_array_equal(dense.cpu().numpy()[:, :27].T, r["found"])
+    assert (dense[:, 27:] == -1).all()
     dev = _dev()
     g = torch.Generator().manual_seed(cin + cout)
     X = torch.randn(len(s), cin, generator=g).to(dev, dtype)
     W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev, dtype)
-    assert hip_gemm.table_mask(km, km._nbr, km._mask, cin, cout, 27, dtype) is None
-    y_tbl = hip_gemm._gather_gemm(X, W, km._nbr, None, km._perm, len(s), cin, cout, 27, _lib.WCN_ALGO_MFMA, False, False)
-    y_arr = hip_gemm._gather_gemm(X, W, km._nbr, km._mask, km._perm, len(s), cin, cout, 27, _lib.WCN_ALGO_MFMA, False, False)
+    y_tbl = hip_gemm._gather_gemm(X, W, km._nbrc, None, km._perm, len(s), cin, cout, 27, _lib.WCN_ALGO_MFMA, False, False)
+    y_arr = hip_gemm._gather_gemm(X, W, dense, km._mask, km._perm, len(s), cin, cout, 27, _lib.WCN_ALGO_MFMA, False, False)
     assert torch.equal(y_tbl, y_arr)
     dY = torch.randn(len(s), cout, generator=g).to(dev, dtype)
-    d_tbl = hip_gemm._gather_gemm(dY, W, km._nbr, None, km._perm, len(s), cout, cin, 27, _lib.WCN_ALGO_MFMA, True, True)
-    d_arr = hip_gemm._gather_gemm(dY, W, km._nbr, km._mask, km._perm, len(s), cout, cin, 27, _lib.WCN_ALGO_MFMA, True, True)
+    d_tbl = hip_gemm._gather_gemm(dY, W, km._nbrc, None, km._perm, len(s), cout, cin, 27, _lib.WCN_ALGO_MFMA, True, True)
+    d_arr = hip_gemm._gather_gemm(dY, W, dense, km._mask, km._perm, len(s), cout, cin, 27, _lib.WCN_ALGO_MFMA, True, True)
     assert torch.equal(d_tbl, d_arr)
-    # a table that does not carry masks (hash builder) keeps its mask argument
+    # a dense table (hash builder) keeps its mask argument; shapes outside the channel-split family get the dense table
     import os
     os.environ["WARPCONVNET_AMD_KMAP_METHOD"] = "hash"
     try:
         kh = _kmap(s[:-40], s[:-40], (3, 3, 3), same=True)
     finally:
         del os.environ["WARPCONVNET_AMD_KMAP_METHOD"]
-    assert not kh._mask_in_table and hip_gemm.table_mask(kh, kh._nbr, kh._mask, cin, cout, 27, dtype) is kh._mask
+    assert kh._nbrc is None and hip_gemm.own_tables(kh, cin, cout, 27, dtype) == (kh._nbr, kh._mask)
+    tb32, mk32 = hip_gemm.own_tables(km, 32, 32, 27, dtype)
+    assert tb32 is dense and mk32 is km._mask
+
+
+def test_a_row_with_more_than_15_neighbours_falls_back_to_dense_rows():
+    """A dense volume (every cell of a 6^3 cube occupied: interior rows have 27 neighbours) does not fit compact rows: the device
+    raises ROW_OVERFLOW, the build is redone with dense rows and the hints remember it for that kernel volume."""
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import BuildHints, generate_kernel_map
+
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(6), np.arange(6), indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(5)
+    rng.shuffle(g)
+    c = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+    t = torch.from_numpy(c).to(_dev())
+    hints = BuildHints()
+    assert hints.compact_rows(27)
+    km = generate_kernel_map(t, t, (1, 1, 1), (3, 3, 3), hints=hints)
+    assert km._nbrc is None and km._nbr_dense is not None and not hints.compact_rows(27) and hints.compact_rows(25)
+    r = okmap.kernel_map(c, c, (3, 3, 3))
+    np.testing.assert_array_equal(km._nbr.cpu().numpy()[:, :27].T, r["found"])
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+    np.testing.assert_array_equal(km.out_maps.cpu().numpy(), r["out_maps"])
+    # optimistic build of the same scene with fresh hints: the forward queued on the rejected tables is harmless and repeated
+    hints2 = BuildHints()
+    km2 = generate_kernel_map(t, t, (1, 1, 1), (3, 3, 3), optimistic=True, hints=hints2)
+    assert km2._nbrc is not None
+    assert km2.validate() is True and km2._nbrc is None
+    np.testing.assert_array_equal(km2._nbr.cpu().numpy()[:, :27].T, r["found"])
+    # ... and a scene at the limit (exactly 15 neighbours in some rows is fine): a 2-D sheet of 3 layers has rows of 18, a
+    # single layer rows of 9
+    sheet = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(1), indexing="ij"), -1).reshape(-1, 3)
+    cs = np.concatenate([np.zeros((len(sheet), 1), np.int64), sheet], 1).astype(np.int32)
+    ts = torch.from_numpy(cs).to(_dev())
+    ks = generate_kernel_map(ts, ts, (1, 1, 1), (3, 3, 3), hints=BuildHints())
+    assert ks._nbrc is not None
+    rs = okmap.kernel_map(cs, cs, (3, 3, 3))
+    np.testing.assert_array_equal(ks._nbr.cpu().numpy()[:, :27].T, rs["found"])
 
 
 @pytest.mark.parametrize("fused_block", [False, True])

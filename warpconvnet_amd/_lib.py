@@ -22,6 +22,7 @@ WCN_F32, WCN_F16, WCN_BF16 = 0, 1, 2
 WCN_ALGO_AUTO, WCN_ALGO_REF, WCN_ALGO_MFMA = 0, 1, 2
 WCN_FLAG_TABLE_FULL, WCN_FLAG_COORD_RANGE, WCN_FLAG_PAIR_OVERFLOW, WCN_FLAG_DUPLICATE_COORD = 1, 2, 4, 8
 WCN_FLAG_NEED_STRICT = 16
+WCN_FLAG_ROW_OVERFLOW = 32
 
 _I32P = c_void_p  # all pointers travel as void*
 _3I = c_int32 * 3
@@ -83,20 +84,22 @@ SIGNATURES = {
     "wcn_kmap_binned_supported": (c_int, [_3I, _3I]),
     "wcn_kmap_build_binned": (
         c_int,
-        [c_void_p, c_int64, _3I, _3I, c_int64, c_int32, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+        [c_void_p, c_int64, _3I, _3I, c_int64, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "wcn_kmap_compact_supported": (c_int, [c_int32]),
+    "wcn_kmap_densify": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_tally_sort_workspace": (c_size_t, [c_int64]),
     "wcn_kmap_tally_sort": (
         c_int,
         [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-         c_void_p, c_void_p, c_int64, c_int64, c_void_p],
+         c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p],
     ),
     "wcn_kmap_count": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "wcn_kmap_scan_to_host": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wcn_kmap_scatter": (
         c_int,
-        [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p],
     ),
     "wcn_kmap_cells_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wcn_cells_stride_supported": (c_int, [_3I]),
@@ -137,7 +140,7 @@ SIGNATURES = {
         [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p],
     ),
     "wcn_pack_weight_pair_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
-    "wcn_conv_mask_in_table_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
+    "wcn_conv_compact_table_supported": (c_int, [c_int32, c_int32, c_int32, c_int32]),
     "wcn_pack_weight_f32_pair": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_size_t,
                                          c_void_p]),
     "wcn_conv_gather_gemm": (

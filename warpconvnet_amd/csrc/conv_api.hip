@@ -90,13 +90,13 @@ int wcn_pack_weight_f32(const float* w, int32_t num_offsets, int32_t cin, int32_
   return pack_weight_mfma_f32(w, num_offsets, cin, cout, dtype, transpose, flip, packed, (hipStream_t)stream);
 }
 
-// A table row of 32 columns for K <= 31 offsets may carry the row's mask in its last column (wcn_kmap_build_binned writes it there):
-// the channel-split gather kernels then take `mask` = NULL and read it with the index slab.
-static bool mask_in_table_ok(int cin, int cout, int K, int dtype) {
-  return wcn_kmap_row_pitch(K) == 32 && K <= 31 && gather_gemm_cs_supported(cin, cout, K, dtype);
+// COMPACT tables (wcn_kmap_build_binned with compact = 1: 16 ints per row, the mask first): the channel-split gather kernels take
+// them with `mask` = NULL and expand the rows into their index slab.
+static bool compact_table_ok(int cin, int cout, int K, int dtype) {
+  return wcn_kmap_compact_supported(K) && gather_gemm_cs_supported(cin, cout, K, dtype);
 }
-int wcn_conv_mask_in_table_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype) {
-  return mask_in_table_ok(cin, cout, num_offsets, dtype) ? 1 : 0;
+int wcn_conv_compact_table_supported(int32_t cin, int32_t cout, int32_t num_offsets, int32_t dtype) {
+  return compact_table_ok(cin, cout, num_offsets, dtype) ? 1 : 0;
 }
 
 int wcn_pack_weight_pair_supported(int32_t num_offsets, int32_t cin, int32_t cout, int32_t dtype) {
@@ -132,7 +132,7 @@ int wcn_conv_gather_gemm(const void* in, const void* w, void* out, const int32_t
       return conv_gather_gemm_ref(in, w, out, nbr, bias, n_out, cin, cout, num_offsets, dtype, w_transposed, k_flip, s);
     case WCN_ALGO_MFMA:
       // `w` must be the packed image (wcn_pack_weight already applied transpose / flip)
-      if (!mask && !identity && !(nbr && mask_in_table_ok(cin, cout, num_offsets, dtype))) return WCN_ERROR_INVALID_PARAMETERS;
+      if (!mask && !identity && !(nbr && compact_table_ok(cin, cout, num_offsets, dtype))) return WCN_ERROR_INVALID_PARAMETERS;
       {
         ConvEpilogue epi;
         epi.bias = bias;
@@ -173,7 +173,8 @@ int wcn_conv_gather_gemm_f32out(const void* in, const void* w, float* out, const
   if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || num_offsets < 1 || (dtype != WCN_F16 && dtype != WCN_BF16))
     return WCN_ERROR_INVALID_PARAMETERS;
   if (n_out == 0) return WCN_SUCCESS;
-  if (!w || !out || !nbr || !mask || (n_in > 0 && !in)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (!w || !out || !nbr || (!mask && !compact_table_ok(cin, cout, num_offsets, dtype)) || (n_in > 0 && !in))
+    return WCN_ERROR_INVALID_PARAMETERS;
   ConvEpilogue epi;
   epi.bias = bias;
   return conv_gather_gemm_mfma(in, w, nullptr, nbr, mask, perm, epi, n_out, cin, cout, num_offsets, dtype, out,
@@ -188,7 +189,8 @@ int wcn_conv_gather_gemm_fused(const void* in, const void* w_packed, void* out, 
       ((scale == nullptr) != (shift == nullptr)))
     return WCN_ERROR_INVALID_PARAMETERS;
   if (n_out == 0) return WCN_SUCCESS;
-  if (!w_packed || !out || !nbr || !mask || (n_in > 0 && !in) || residual == out) return WCN_ERROR_INVALID_PARAMETERS;
+  if (!w_packed || !out || !nbr || (!mask && !compact_table_ok(cin, cout, num_offsets, dtype)) || (n_in > 0 && !in) || residual == out)
+    return WCN_ERROR_INVALID_PARAMETERS;
   ConvEpilogue epi;
   epi.bias = bias; epi.scale = scale; epi.shift = shift; epi.residual = residual; epi.relu = relu ? 1 : 0;
   return conv_gather_gemm_mfma(in, w_packed, out, nbr, mask, perm, epi, n_out, cin, cout, num_offsets, dtype, nullptr,
@@ -251,7 +253,7 @@ int wcn_conv_bn_backward_ld(const void* grad_out, int64_t grad_out_ld, const voi
                                     bn_workspace, bn_workspace_bytes, stream);
   if (rc != WCN_SUCCESS) return rc;
   if (dx) {
-    if (!w_packed_dgrad || !rev_nbr) return WCN_ERROR_INVALID_PARAMETERS;  // (rev_mask may ride in the table: wcn_conv_gather_gemm checks)
+    if (!w_packed_dgrad || !rev_nbr) return WCN_ERROR_INVALID_PARAMETERS;  // (rev_mask NULL: a compact table, wcn_conv_gather_gemm checks)
     rc = wcn_conv_gather_gemm(dy_conv, w_packed_dgrad, dx, rev_nbr, rev_mask, rev_perm, nullptr, n_out, n_in, cout, cin, num_offsets,
                               dtype, WCN_ALGO_MFMA, 1, flip, stream);
     if (rc != WCN_SUCCESS) return rc;

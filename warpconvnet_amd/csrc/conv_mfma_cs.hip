@@ -198,12 +198,63 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     s_epi[2 * CO + c] = epi.scale ? epi.shift[col0 + c] : 0.f;
   }
   __syncthreads();
-  {
-    // `mask` null with a table: the row's mask rides in the LAST column of its 128-B table row (kp = 32, K <= 31: wcn_kmap_build_binned
-    // writes it there, round 5), i.e. in the line the index slab is loaded from anyway.  A gather of mask[r] over the mask-sorted rows
-    // is a 128-B line per row - 128 MB of fabric requests per launch at 1 M rows for 4 MB of masks.
-    const bool mit = mask == nullptr && nbr != nullptr;
-    if (!mit) {
+  // `mask` null with a table: `nbr` holds COMPACT rows (kmap_cells.h: 16 ints - the row's mask, then the neighbour rows of its set
+  // offsets in ascending k; written by wcn_kmap_build_binned) - 64 B per row instead of a 128-B table row plus a 128-B line for the
+  // 4 bytes of mask[perm[i]].  The rows are staged in the (still unused) ring and expanded into the [TILE][SP] index slab.
+  const bool compact = mask == nullptr && nbr != nullptr;
+  if (compact) {
+    int32_t* s_c = reinterpret_cast<int32_t*>(s_ring);  // [TILE][16]
+    constexpr int kIterC = (TILE * 4 + NT - 1) / NT;
+    int32_t rr[kIterC];
+    int4 vv[kIterC];
+#pragma unroll
+    for (int t = 0; t < kIterC; ++t) {
+      const int e = tid + t * NT;
+      rr[t] = (e < TILE * 4) ? s_rows[e >> 2] : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < kIterC; ++t) {
+      const int e = tid + t * NT;
+      vv[t] = make_int4(0, 0, 0, 0);  // (no row: mask 0)
+      if (rr[t] >= 0) {  // read once: non-temporal
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * 16) + (e & 3));
+        vv[t] = make_int4(q.x, q.y, q.z, q.w);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kIterC; ++t) {
+      const int e = tid + t * NT;
+      if (e < TILE * 4) reinterpret_cast<int4*>(s_c)[e] = vv[t];
+    }
+    __syncthreads();
+    constexpr int kVec = SP / 4;
+    for (int e = tid; e < TILE * kVec; e += NT) {
+      const int row = e / kVec, c = e - row * kVec;
+      uint32_t m = (uint32_t)s_c[row * 16];
+      if (__popc(m) > 15) m = 0u;  // (a row that did not fit: such a build is flagged ROW_OVERFLOW and redone with dense rows)
+      int at = row * 16 + 1 + __popc(m & ((1u << (4 * c)) - 1u));
+      int v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool has = (m >> (4 * c + t)) & 1u;
+        v[t] = has ? s_c[at] : -1;
+        at += has ? 1 : 0;
+      }
+      reinterpret_cast<int4*>(s_nbr + row * SP)[c] = make_int4(v[0], v[1], v[2], v[3]);
+    }
+    if (tid < TILE) {
+      uint32_t m = (uint32_t)s_c[tid * 16];
+      if (__popc(m) > 15) m = 0u;
+      s_mask[tid] = m;
+      if (m) atomicOr(&s_wmask[tid >> 5], m);
+    }
+    if (last_pieces < 8) {  // the ring must hold finite values where it is never written (see above): clear the staged ids again
+      __syncthreads();
+      for (int e = tid; e < TILE * 4; e += NT) reinterpret_cast<int4*>(s_c)[e] = make_int4(0, 0, 0, 0);
+    }
+  } else {
+    {
       uint32_t my_mask = 0;
       if (tid < TILE) {
         const int32_t r = s_rows[tid];
@@ -214,20 +265,18 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     }
     // all row ids first, then all table loads, then all LDS writes (one global round trip)
     constexpr int kVec = SP / 4;  // 16-B pieces per slab row
-    constexpr int kVecL = kVec + 1;  // ... and the piece that carries the mask (mit)
-    constexpr int kIter = (TILE * kVecL + NT - 1) / NT;
-    const int kv = mit ? kVecL : kVec;
+    constexpr int kIter = (TILE * kVec + NT - 1) / NT;
     int32_t rr[kIter];
     int4 vv[kIter];
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
       const int e = tid + t * NT;
-      rr[t] = (e < TILE * kv) ? s_rows[e / kv] : -1;
+      rr[t] = (e < TILE * kVec) ? s_rows[e / kVec] : -1;
     }
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
       const int e = tid + t * NT;
-      const int c = e % kv;
+      const int c = e % kVec;
       vv[t] = make_int4(-1, -1, -1, -1);
       if (rr[t] >= 0 && (c * 4 < kp)) {  // read once: non-temporal
         typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -242,15 +291,8 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
 #pragma unroll
     for (int t = 0; t < kIter; ++t) {
       const int e = tid + t * NT;
-      if (e >= TILE * kv) continue;
-      const int row = e / kv, c = e % kv;
-      if (c < kVec) {
-        reinterpret_cast<int4*>(s_nbr + row * SP)[c] = vv[t];
-      } else {  // (mit) columns 28 .. 31: the mask is the last one
-        const uint32_t m = rr[t] >= 0 ? (uint32_t)vv[t].w : 0u;
-        s_mask[row] = m;
-        if (m) atomicOr(&s_wmask[row >> 5], m);
-      }
+      if (e >= TILE * kVec) continue;
+      reinterpret_cast<int4*>(s_nbr + (e / kVec) * SP)[e % kVec] = vv[t];
     }
   }
   __syncthreads();

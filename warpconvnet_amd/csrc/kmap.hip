@@ -235,7 +235,10 @@ extern "C" {
 //    mask = NULL with a binned 32-column table in wcn_conv_gather_gemm / wcn_conv_bn_backward (mask in column 31) +
 //    wcn_conv_mask_in_table_supported, wcn_dense_rows[_supported] (narrow 1 x 1 x 1 layers), wcn_bn_train_backward_ld /
 //    wcn_conv_bn_backward_ld (row pitch for the incoming gradient; the entries without _ld are unchanged)
-int wcn_abi_version(void) { return 4; }
+// 5 (signatures changed): COMPACT neighbour rows - `compact` argument of wcn_kmap_build_binned / wcn_kmap_tally_sort /
+//    wcn_kmap_scatter, wcn_kmap_compact_supported, wcn_kmap_densify, WCN_FLAG_ROW_OVERFLOW; mask = NULL in the gather GEMMs now means
+//    a compact table (wcn_conv_compact_table_supported replaces wcn_conv_mask_in_table_supported; dense rows no longer carry a mask)
+int wcn_abi_version(void) { return 5; }
 
 const char* wcn_status_string(int status) {
   switch (status) {

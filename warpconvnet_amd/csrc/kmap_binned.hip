@@ -101,6 +101,9 @@ __global__ __launch_bounds__(kInsertThreads) void cell_insert_kernel(BSlot* __re
                                                           int32_t* __restrict__ status, int kp, int mw,
                                                           int32_t* __restrict__ nbr, uint32_t* __restrict__ mask,
                                                           int strict) {
+  // kp: ints per table row - the dense pitch, or kCompactPitch with the top bit set for COMPACT rows (kmap_cells.h)
+  const bool compact = kp < 0;
+  kp &= 0x7FFFFFFF;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = PHASE == 0 ? tid * kInsertSample : tid;
   const int lane = threadIdx.x & 63;
@@ -114,8 +117,7 @@ __global__ __launch_bounds__(kInsertThreads) void cell_insert_kernel(BSlot* __re
         atomicOr(status, (int)WCN_FLAG_COORD_RANGE);
         // the voxel is in no block, so cell_neighbors never visits it: give its table row defined ("no neighbour")
         // content - consumers may already be queued behind this build when the host sees the flag
-        for (int k = 0; k < kp; ++k) nbr[i * kp + k] = -1;
-        if (kp == 32 && mw == 1) nbr[i * kp + 31] = 0;  // (the mask column of the row, see cell_neighbors)
+        for (int k = 0; k < kp; ++k) nbr[i * kp + k] = compact ? 0 : -1;  // (compact row: word 0 = mask = no offsets)
         for (int w = 0; w < mw; ++w) mask[i * mw + w] = 0u;
       }
     }
@@ -269,11 +271,18 @@ __device__ unsigned long long g_bprof[4096 * 8];
 // (-1 = empty) and own[512] u16 grid indices of the block's occupied cells.
 // FAST: every byte offset into nbr / mask fits 31 bits and every row index 24 bits (n < 2^24, n * kp * 4 < 2^31): the
 // addresses of the probe loop are one full-rate 24-bit multiply-add instead of two quarter-rate 64-bit ones.
-template <int LPR, bool FAST>
+// COMPACT (LPR == 32, one mask word): the voxel's row is 16 ints - its mask, then the neighbour rows of its SET offsets in
+// ascending k (kmap_cells.h: kCompactPitch) - instead of 32 columns of which 4 - 9 hold a neighbour on the scenes of the bench:
+// half the bytes for this kernel's stores and for every later reader of the table (pair scatter, both gather GEMMs).  Every
+// lane that found a neighbour stores it at its rank among the voxel's set offsets (ballot + popcount); words behind the last
+// neighbour stay unwritten.  A voxel with more than kCompactIds neighbours raises WCN_FLAG_ROW_OVERFLOW: the host rebuilds
+// with dense rows.
+template <int LPR, bool FAST, bool COMPACT>
 __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t, const uint32_t* __restrict__ halo,
                                                                     CellGeom g, int K, int kp, int mw,
                                                                     int32_t* __restrict__ nbr,
-                                                                    uint32_t* __restrict__ mask) {
+                                                                    uint32_t* __restrict__ mask,
+                                                                    int32_t* __restrict__ status) {
   extern __shared__ int s_mem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* s_halo = reinterpret_cast<uint32_t*>(s_mem);
@@ -406,13 +415,36 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
           bits_a = (uint32_t)(ball_a >> (vsel * LPR)) & ((1u << LPR) - 1u);
           bits_b = (uint32_t)(ball_b >> (vsel * LPR)) & ((1u << LPR) - 1u);
         }
-        // kp == 32 with one mask word (K <= 31): the row's LAST column is free - it carries the row's mask, in the same 128-B store,
-        // so that a consumer that loads the row (the gather GEMMs' index slab) needs no second, line-sized gather for 4 bytes
-        if (LPR == 32 && kp == 32 && mw == 1 && sub == 31) {
-          found_a = (int)bits_a;
-          found_b = (int)bits_b;
-        }
-        if (FAST) {
+        if (COMPACT) {
+          // lane sub stores its answer at word 1 + (set offsets below sub) of the voxel's 64-B row, lane 31 (never a real offset:
+          // K <= 31) the mask at word 0: the ~5 active lanes of a voxel hit one 64-B segment.  (Round-6 measurement: compacting
+          // the 32 answers in registers first - one ds_permute per voxel pair, a full 64-B store by 16 lanes - cost MORE than the
+          // dense rows, 68.4 vs 62.9 us: the kernel pays per store instruction and per dependent LDS round trip, not per byte.)
+          const uint32_t below = (1u << sub) - 1u;
+          int word_a = 1 + __popc(bits_a & below), word_b = 1 + __popc(bits_b & below);
+          bool put_a = row_a >= 0 && found_a >= 0, put_b = row_b >= 0 && found_b >= 0;
+          const bool over = (put_a && word_a > kCompactIds) || (put_b && word_b > kCompactIds);
+          put_a = put_a && word_a <= kCompactIds;
+          put_b = put_b && word_b <= kCompactIds;
+          if (sub == 31) {
+            word_a = 0; word_b = 0;
+            found_a = (int)bits_a; found_b = (int)bits_b;
+            put_a = row_a >= 0; put_b = row_b >= 0;
+          }
+          if (__any(over) && lane == 0) atomicOr(status, (int)WCN_FLAG_ROW_OVERFLOW);
+          if (FAST) {
+            char* nbr_b = reinterpret_cast<char*>(nbr);
+            if (put_a) *reinterpret_cast<int*>(nbr_b + (__umul24((uint32_t)row_a, kCompactPitch * 4u) + (uint32_t)word_a * 4u)) = found_a;
+            if (put_b) *reinterpret_cast<int*>(nbr_b + (__umul24((uint32_t)row_b, kCompactPitch * 4u) + (uint32_t)word_b * 4u)) = found_b;
+          } else {
+            if (put_a) nbr[(int64_t)row_a * kCompactPitch + word_a] = found_a;
+            if (put_b) nbr[(int64_t)row_b * kCompactPitch + word_b] = found_b;
+          }
+          if (sub == 0) {  // the dense mask array (tally, sort); also clears the "unwritten" mark
+            if (row_a >= 0) mask[row_a] = bits_a;
+            if (row_b >= 0) mask[row_b] = bits_b;
+          }
+        } else if (FAST) {
           char* nbr_b = reinterpret_cast<char*>(nbr);
           char* mask_b = reinterpret_cast<char*>(mask);
           const uint32_t kp4 = (uint32_t)kp * 4u, mw4 = (uint32_t)mw * 4u, k4 = (uint32_t)k * 4u, w4 = (uint32_t)w0 * 4u;
@@ -503,11 +535,17 @@ int wcn_kmap_binned_supported(const int32_t ksize[3], const int32_t dilation[3])
   return (K <= 4096 && (K & 31) != 0) ? 1 : 0;
 }
 
+int wcn_kmap_compact_supported(int32_t num_offsets) {
+  // one mask word and 32 lanes per voxel in cell_neighbors (row pitches 24 and 32)
+  return (num_offsets >= 17 && num_offsets <= 31) ? 1 : 0;
+}
+
 int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[3], const int32_t dilation[3],
-                          int64_t max_blocks, int32_t strict, void* workspace, size_t workspace_bytes, int32_t* nbr,
-                          uint32_t* mask, int32_t* status, wcn_stream_t stream) {
+                          int64_t max_blocks, int32_t strict, int32_t compact, void* workspace, size_t workspace_bytes,
+                          int32_t* nbr, uint32_t* mask, int32_t* status, wcn_stream_t stream) {
   if (n < 0 || !status || max_blocks < 1 || max_blocks > (1ll << 29)) return WCN_ERROR_INVALID_PARAMETERS;
   if (!wcn_kmap_binned_supported(ksize, dilation)) return WCN_ERROR_PROBLEM_NOT_SUPPORTED;
+  if (compact && (!ksize || !wcn_kmap_compact_supported(ksize[0] * ksize[1] * ksize[2]))) return WCN_ERROR_PROBLEM_NOT_SUPPORTED;
   if (n == 0) return WCN_SUCCESS;
   if (n >= (1ll << 31) || !coords || !nbr || !mask || !workspace ||
       workspace_bytes < wcn_kmap_binned_workspace(n, max_blocks))
@@ -520,7 +558,7 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   const int64_t capacity = t.capacity;
   const uint32_t cmask = (uint32_t)(capacity - 1);
 
-  launch_cell_table(t, g, (const int4*)coords, n, kp, mw, nbr, mask, status, (int)strict, s);
+  launch_cell_table(t, g, (const int4*)coords, n, compact ? (kCompactPitch | kCompactFlag) : kp, mw, nbr, mask, status, (int)strict, s);
   const int halo_pad = (g.halo_cells + 63) & ~63;
   // waves per workgroup: 4, fewer when halo list + one LDS grid per wave would not fit (halo 6..8: 20^3..24^3 cells)
   int nb_waves = kNbThreads / 64;
@@ -539,30 +577,35 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
     static unsigned long long attr_done = 0ull;
     const int rc = once_per_device(attr_done, [] {
       bool ok = true;
-      for (const void* f : {reinterpret_cast<const void*>(cell_neighbors_kernel<8, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<8, false>),
-                            reinterpret_cast<const void*>(cell_neighbors_kernel<16, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<16, false>),
-                            reinterpret_cast<const void*>(cell_neighbors_kernel<32, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<32, false>),
-                            reinterpret_cast<const void*>(cell_neighbors_kernel<64, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<64, false>)})
+      for (const void* f : {reinterpret_cast<const void*>(cell_neighbors_kernel<8, true, false>), reinterpret_cast<const void*>(cell_neighbors_kernel<8, false, false>),
+                            reinterpret_cast<const void*>(cell_neighbors_kernel<16, true, false>), reinterpret_cast<const void*>(cell_neighbors_kernel<16, false, false>),
+                            reinterpret_cast<const void*>(cell_neighbors_kernel<32, true, false>), reinterpret_cast<const void*>(cell_neighbors_kernel<32, false, false>),
+                            reinterpret_cast<const void*>(cell_neighbors_kernel<32, true, true>), reinterpret_cast<const void*>(cell_neighbors_kernel<32, false, true>),
+                            reinterpret_cast<const void*>(cell_neighbors_kernel<64, true, false>), reinterpret_cast<const void*>(cell_neighbors_kernel<64, false, false>)})
         ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       return ok;
     });
     if (rc != WCN_SUCCESS) return rc;
   }
   const bool fast = n < (1ll << 24) && n * kp * 4 < (1ll << 31);
-#define WCN_CELL_NB(L)                                                                                                 \
-  do {                                                                                                                 \
-    if (fast)                                                                                                          \
-      hipLaunchKernelGGL((cell_neighbors_kernel<L, true>), grid, block, shm, s, t, (const uint32_t*)t.halo, g, K, kp,  \
-                         mw, nbr, mask);                                                                               \
-    else                                                                                                               \
-      hipLaunchKernelGGL((cell_neighbors_kernel<L, false>), grid, block, shm, s, t, (const uint32_t*)t.halo, g, K, kp, \
-                         mw, nbr, mask);                                                                               \
+#define WCN_CELL_NB(L, C)                                                                                                 \
+  do {                                                                                                                    \
+    if (fast)                                                                                                             \
+      hipLaunchKernelGGL((cell_neighbors_kernel<L, true, C>), grid, block, shm, s, t, (const uint32_t*)t.halo, g, K, kp,  \
+                         mw, nbr, mask, status);                                                                          \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((cell_neighbors_kernel<L, false, C>), grid, block, shm, s, t, (const uint32_t*)t.halo, g, K, kp, \
+                         mw, nbr, mask, status);                                                                          \
   } while (0)
-  switch (lanes_per_row_b(kp)) {
-    case 8: WCN_CELL_NB(8); break;
-    case 16: WCN_CELL_NB(16); break;
-    case 32: WCN_CELL_NB(32); break;
-    default: WCN_CELL_NB(64); break;
+  if (compact) {
+    WCN_CELL_NB(32, true);  // (wcn_kmap_compact_supported: 32 lanes per voxel, one mask word)
+  } else {
+    switch (lanes_per_row_b(kp)) {
+      case 8: WCN_CELL_NB(8, false); break;
+      case 16: WCN_CELL_NB(16, false); break;
+      case 32: WCN_CELL_NB(32, false); break;
+      default: WCN_CELL_NB(64, false); break;
+    }
   }
 #undef WCN_CELL_NB
   return launch_status();

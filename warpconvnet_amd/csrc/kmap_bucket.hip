@@ -39,13 +39,15 @@ __device__ __noinline__ void repair_row(int64_t row, const int4* __restrict__ co
     const int cell = ((c.y & (kBlk - 1)) * kBlk + (c.z & (kBlk - 1))) * kBlk + (c.w & (kBlk - 1));
     w = t.cells[(int64_t)id * kCells + cell];
   }
+  // kp: ints per table row (the dense pitch, or kCompactPitch | kCompactFlag: a compact row is copied like a dense one)
+  const bool compact = kp < 0;
+  kp &= 0x7FFFFFFF;
   if (w >= 0 && w != row && !(mask[(int64_t)w * mw + (mw - 1)] & kMaskUnwritten)) {
     atomicOr(status, (int)(WCN_FLAG_DUPLICATE_COORD | (w > row ? WCN_FLAG_NEED_STRICT : 0)));
     for (int k = 0; k < kp; ++k) nbr[row * kp + k] = nbr[(int64_t)w * kp + k];
     for (int q = 0; q < mw; ++q) mask[row * mw + q] = mask[(int64_t)w * mw + q];
   } else {  // block table overflow (flagged by the builder): defined, empty content
-    for (int k = 0; k < kp; ++k) nbr[row * kp + k] = -1;
-    if (kp == 32 && mw == 1) nbr[row * kp + 31] = 0;  // (the mask column of a 32-column row, kmap_binned.hip)
+    for (int k = 0; k < kp; ++k) nbr[row * kp + k] = compact ? 0 : -1;  // (compact: word 0 = mask = no offsets)
     for (int q = 0; q < mw; ++q) mask[row * mw + q] = 0u;
   }
 }
@@ -250,8 +252,9 @@ struct KsArgs {
   int32_t* out_maps;
   int64_t pair_capacity;
   int32_t* status;
+  int compact;  // nbr holds COMPACT rows (kmap_cells.h); one mask word
 };
-constexpr size_t kKsLds = (size_t)2 * kStageCap * 4 + 32 * 8 + (size_t)(kBkThreads / 64) * 32 * 12 + 36 * 4 + kStageCap;
+constexpr size_t kKsLds = (size_t)2 * kStageCap * 4 + 32 * 8 + (size_t)(kBkThreads / 64) * 32 * 12 + 36 * 4 + kStageCap + kBkThreads * 4;
 
 __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_id, char* smem) {
   const int32_t* __restrict__ nbr = q.nbr;
@@ -269,6 +272,7 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
   int(*s_cnt)[32] = reinterpret_cast<int(*)[32]>(s_ball + kBkThreads / 64);  // pairs per (wave, offset), then exclusive over the waves
   int* s_seg = reinterpret_cast<int*>(s_cnt + kBkThreads / 64);               // [33] first staged position of every offset
   unsigned char* s_bk = reinterpret_cast<unsigned char*>(s_seg + 36);         // [kStageCap] offset (inside the word) of a staged pair
+  uint32_t* s_rowmask = reinterpret_cast<uint32_t*>(s_bk + kStageCap);        // [kBkThreads] masks of the tile's rows (compact tables)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = tile_id * kTileRows + wave * 64;
   const int64_t row = row0 + lane;
@@ -278,14 +282,30 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
     const int cols4 = ((kp - w * 32) < 32 ? (kp - w * 32) : 32) >> 2;  // 16-B chunks per row in this word
     // cols4 (<= 8) 16-B pieces per lane, all requested up front
     int4 piece[8];
+    if (q.compact) {  // 4 pieces per 64-B row: lane l holds piece l % 4 of rows l / 4 + 16 j
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = lane + 64 * j;
-      const int r = e / cols4, c = e - r * cols4;
-      piece[j] = make_int4(-1, -1, -1, -1);
-      if (j < cols4 && row0 + r < m) piece[j] = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kp + w * 32 + c * 4);
+      for (int j = 0; j < 4; ++j) {
+        const int r = (lane >> 2) + 16 * j;
+        piece[j] = make_int4(0, 0, 0, 0);
+        if (row0 + r < m) piece[j] = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kCompactPitch + (lane & 3) * 4);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = lane + 64 * j;
+        const int r = e / cols4, c = e - r * cols4;
+        piece[j] = make_int4(-1, -1, -1, -1);
+        if (j < cols4 && row0 + r < m) piece[j] = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kp + w * 32 + c * 4);
+      }
     }
-    const uint32_t bits = row < m ? mask[row * mw + w] : 0u;
+    uint32_t bits = row < m ? mask[row * mw + w] : 0u;
+    if (q.compact) {
+      // a row that did not fit its compact row (> 15 neighbours; the build is flagged ROW_OVERFLOW and redone): it stages
+      // NOTHING, and must not be counted either - a counted pair that is never staged leaves a slot of the staging area with
+      // a stale bucket id, and the flush would compute its position from it
+      if (__popc(bits) > kCompactIds) bits = 0u;
+      s_rowmask[tid] = bits;
+    }
     // row bitmaps and pair counts of the word's offsets (lane b keeps offset w*32+b)
     unsigned long long mine = 0ull;
     for (int b = 0; b < kend; ++b) {
@@ -320,7 +340,41 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
     __syncthreads();
     const int total = s_seg[32];
     const bool staged = total <= kStageCap;
-    if ((64 % cols4) == 0) {
+    if (q.compact) {
+      // word 4c + t of a row is the neighbour of its (4c + t - 1)-th SET offset: strip the offsets below from the row's mask,
+      // then walk the next ones with ctz
+      const int c = lane & 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = (lane >> 2) + 16 * j;
+        uint32_t rem = s_rowmask[wave * 64 + r];
+        for (int sk = 4 * c - 1; sk > 0; --sk) rem &= rem - 1u;
+        const unsigned long long below = (1ull << r) - 1ull;
+        const int vals[4] = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (c == 0 && t == 0) continue;  // word 0: the mask
+          if (rem == 0u) break;
+          const int b = __builtin_ctz(rem);
+          rem &= rem - 1u;
+          const int local = s_cnt[wave][b] + __popcll(s_ball[wave][b] & below);
+          if (staged) {
+            const int at = s_seg[b] + local;
+            s_in[at] = vals[t];
+            s_out[at] = (int32_t)(row0 + r);
+            s_bk[at] = (unsigned char)b;
+          } else {
+            const int64_t pos = s_gbase[b] + local;
+            if (pos < pair_capacity) {
+              in_maps[pos] = vals[t];
+              out_maps[pos] = (int32_t)(row0 + r);
+            } else {
+              overflow = true;
+            }
+          }
+        }
+      }
+    } else if ((64 % cols4) == 0) {
       // 1 / 2 / 4 / 8 pieces per row: a lane holds the SAME four table columns 4c .. 4c+3 in every piece (rows r0 + j * rstep), so
       // everything that depends on the offset alone - the wave's pair count below it, its row bitmap, the staged and the global
       // base - is read once per word instead of once per value (3 LDS reads of 4 per value were these)
@@ -416,6 +470,28 @@ __global__ __launch_bounds__(kBkThreads) void kmap_scatter_kernel(KsArgs q) {
 
 static inline bool valid_k(int32_t k) { return k >= 1 && k <= 4096; }
 
+// compact rows -> the dense [m, kp] table (-1 = absent): one thread per 16-B piece of a dense row
+__global__ __launch_bounds__(256) void kmap_densify_kernel(const int32_t* __restrict__ nbrc, int64_t m, int kp,
+                                                           int32_t* __restrict__ nbr) {
+  const int cols4 = kp >> 2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m * cols4) return;
+  const int64_t row = e / cols4;
+  const int c = (int)(e - row * cols4);
+  const int32_t* src = nbrc + row * kCompactPitch;
+  uint32_t bits = (uint32_t)src[0];
+  if (__popc(bits) > kCompactIds) bits = 0u;
+  int at = 1 + __popc(bits & ((1u << (4 * c)) - 1u));
+  int v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bool has = (bits >> (4 * c + t)) & 1u;
+    v[t] = has ? src[at] : -1;
+    at += has ? 1 : 0;
+  }
+  *reinterpret_cast<int4*>(nbr + row * kp + 4 * c) = make_int4(v[0], v[1], v[2], v[3]);
+}
+
 }  // namespace wcn
 
 using namespace wcn;
@@ -432,8 +508,8 @@ size_t wcn_kmap_counts_bytes(int64_t m, int32_t num_offsets) {
 
 static void launch_tally(uint32_t* mask, int32_t* nbr, int64_t m, int K, int32_t* counts, bool hist, int nblk_sort,
                          int32_t* dcounts, const int32_t* coords, const CellTable* cells, int32_t* status, int kc, int sort_shift,
-                         int sort_bits, hipStream_t s) {
-  const int kp = wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
+                         int sort_bits, hipStream_t s, bool compact = false) {
+  const int kp = compact ? (kCompactPitch | kCompactFlag) : wcn_kmap_row_pitch(K), mw = wcn_kmap_mask_words(K);
   const int64_t ntile = wcn_kmap_num_blocks(m);
   int32_t* ticket = counts + (int64_t)K * (ntile + 1);
   const dim3 grid((unsigned)ceil_div(m, kRsTile)), block(kTallyThreads);
@@ -487,11 +563,18 @@ int wcn_kmap_scan_to_host(int32_t* counts, int64_t num_blocks, int32_t num_offse
 
 size_t wcn_kmap_tally_sort_workspace(int64_t m) { return wcn_mask_argsort_workspace(m); }
 
+static KsArgs ks_args(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t K, const int32_t* counts,
+                      const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status,
+                      int compact);
+
 int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_offsets, int32_t* counts, int32_t* offsets,
                         int32_t* status, int32_t* host_mirror, int32_t* perm, void* sort_workspace,
                         size_t sort_workspace_bytes, const int32_t* coords, void* binned_workspace, int64_t binned_n,
-                        int64_t max_blocks, wcn_stream_t stream) {
+                        int64_t max_blocks, int32_t compact, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity,
+                        wcn_stream_t stream) {
   if (m < 0 || !valid_k(num_offsets) || !counts || !offsets || !status) return WCN_ERROR_INVALID_PARAMETERS;
+  if (pair_capacity < 0 || ((in_maps == nullptr) != (out_maps == nullptr))) return WCN_ERROR_INVALID_PARAMETERS;
+  if (compact && !wcn_kmap_compact_supported(num_offsets)) return WCN_ERROR_INVALID_PARAMETERS;
   hipStream_t s = (hipStream_t)stream;
   if (m == 0) {  // no rows: offsets are all zero, nothing to sort
     if (hipMemsetAsync(offsets, 0, (size_t)(num_offsets + 1) * 4, s) != hipSuccess) return WCN_ERROR_KERNEL_EXECUTION;
@@ -512,18 +595,29 @@ int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_off
   CellTable cells{};
   if (binned_workspace) cells = carve_cells(binned_workspace, binned_n, max_blocks);
   launch_tally(mask, nbr, m, num_offsets, counts, true, plan.nblk, plan.counts, coords, binned_workspace ? &cells : nullptr,
-               status, kc, plan.shift0, plan.bits, s);
+               status, kc, plan.shift0, plan.bits, s, compact != 0);
   launch_scan(counts, wcn_kmap_num_blocks(m), num_offsets, offsets, status, host_mirror, plan.nblk, plan.counts,
               plan.totals, 1 << plan.bits, s);
   RsLaunch l[12];
   const int count = sort_launches(plan, mask, wcn_kmap_mask_words(num_offsets), m, perm, true, kc, l);
   sort_run_range(l, 0, count, s);
+  if (in_maps && pair_capacity > 0) {
+    // the pair lists right behind the sort, in the same call (one C call per build instead of two).  Round 6 also measured the
+    // scatter INSIDE the sort's launches (workgroups [0, nsort) of every sort launch in the sort role, the rest pair-scatter
+    // tiles): 82.8 us for the four launches against 77.7 us for sort + scatter behind each other - a scatter workgroup lives
+    // ~16 us (2.5 rounds of 3 907 workgroups), so every launch that carries some lasts that long, and both kinds of
+    // workgroup are bound by the rate of scattered store requests, which does not overlap (OPTIMISATION_LOG appendix G)
+    const KsArgs q = ks_args(nbr, mask, m, num_offsets, counts, offsets, in_maps, out_maps, pair_capacity, status, compact ? 1 : 0);
+    hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(m, kTileRows)), dim3(kBkThreads), kKsLds, s, q);
+  }
   return launch_status();
 }
 
 static KsArgs ks_args(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t K, const int32_t* counts,
-                      const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status) {
+                      const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status,
+                      int compact) {
   KsArgs q;
+  q.compact = compact;
   q.nbr = nbr; q.mask = mask; q.m = m; q.K = K; q.kp = wcn_kmap_row_pitch(K); q.mw = wcn_kmap_mask_words(K);
   q.ntile = wcn_kmap_num_blocks(m); q.counts = counts; q.offsets = offsets; q.in_maps = in_maps; q.out_maps = out_maps;
   q.pair_capacity = pair_capacity; q.status = status;
@@ -532,12 +626,13 @@ static KsArgs ks_args(const int32_t* nbr, const uint32_t* mask, int64_t m, int32
 
 int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets, const int32_t* counts,
                      const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status,
-                     wcn_stream_t stream) {
+                     int32_t compact, wcn_stream_t stream) {
   if (m < 0 || !valid_k(num_offsets) || pair_capacity < 0 || !status) return WCN_ERROR_INVALID_PARAMETERS;
+  if (compact && !wcn_kmap_compact_supported(num_offsets)) return WCN_ERROR_INVALID_PARAMETERS;
   if (m == 0) return WCN_SUCCESS;
   if (!nbr || !mask || !counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps)))
     return WCN_ERROR_INVALID_PARAMETERS;
-  const KsArgs q = ks_args(nbr, mask, m, num_offsets, counts, offsets, in_maps, out_maps, pair_capacity, status);
+  const KsArgs q = ks_args(nbr, mask, m, num_offsets, counts, offsets, in_maps, out_maps, pair_capacity, status, compact ? 1 : 0);
   hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(m, kTileRows)), dim3(kBkThreads), kKsLds,
                      (hipStream_t)stream, q);
   return launch_status();

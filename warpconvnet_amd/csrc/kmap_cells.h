@@ -14,6 +14,14 @@ constexpr int kBlkCoordBits = kCoordBits - kBlkShift;  // 15-bit signed block co
 constexpr uint32_t kMaskUnwritten = 0x80000000u;       // top bit of a row's LAST mask word: no block has written the row
 constexpr uint32_t kMaskDeferred = 0x80000001u;        // ... and its cell is not stored yet (block created by the 2nd insert pass)
 
+// COMPACT neighbour rows (binned builder, one mask word, 17 <= K <= 31): 16 ints = 64 B per output row instead of 32 columns:
+//   word 0 = the row's mask (bit k <=> offset k has a neighbour), words 1 .. popcount(mask) = the neighbour rows of the SET
+//   offsets in ascending k, the rest unspecified.  Rows with more than kCompactIds neighbours do not fit: the builder raises
+//   WCN_FLAG_ROW_OVERFLOW and the host rebuilds with dense rows.
+constexpr int kCompactPitch = 16;
+constexpr int kCompactIds = kCompactPitch - 1;
+constexpr int kCompactFlag = (int)0x80000000;  // OR-ed into a `row pitch` kernel argument: the table is compact
+
 constexpr int kIdLateBit = 1 << 30;  // set in a slot's id when the block was created by the SECOND insert pass
 
 // block table slot: key 0 = empty; id = dense block id, valid for LATER launches than the one that created the block

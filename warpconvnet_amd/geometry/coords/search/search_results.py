@@ -6,8 +6,12 @@ HOST, ``identity_map_index``, ``__getitem__`` slices, ``to_csr``, ``neighbor_cou
 
 Build-specific device tables used by the HIP GEMMs ride along as private attributes:
 
-* ``_nbr [M, kp]``  row-major neighbour table (input row per (output row, offset), -1 if absent)
-* ``_mask [M, mw]`` neighbour bitmask, ``_perm [M]`` rows sorted by descending mask
+* ``_nbr [M, kp]``  row-major neighbour table (input row per (output row, offset), -1 if absent; every column of a row beyond
+  K holds -1 too).  A property: the binned builder writes COMPACT rows instead (``_nbrc [M, 16]``: word 0 = the row's mask,
+  words 1 .. popcount = the neighbour rows of its set offsets in ascending k - `csrc/kmap_cells.h`), which the channel-split
+  gather GEMMs and the pair scatter read directly; the dense table is expanded from them on first use (`wcn_kmap_densify`) for
+  every other consumer.  ``has_tables`` asks without expanding.
+* ``_mask [M, mw]`` neighbour bitmask, ``_perm [M]`` rows in tile order (`csrc/mask_sort.h`)
 * ``_offsets_dev [K+1]`` device copy of ``offsets``
 * ``_symmetric``    True for a submanifold map (same coordinate tensor, stride 1, odd kernel): the
   reverse table needed by dgrad is then ``_nbr`` with the offset index reversed, nothing to build
@@ -77,7 +81,8 @@ class IntSearchResult:
 
     def _init_tables(self):
         # build-specific device tables (see module docstring)
-        self._nbr: Optional[Tensor] = None
+        self._nbr_dense: Optional[Tensor] = None
+        self._nbrc: Optional[Tensor] = None  # compact rows [M, 16] (binned builder): read by the GEMMs that can, else densified
         self._mask: Optional[Tensor] = None
         self._perm: Optional[Tensor] = None
         self._offsets_dev: Optional[Tensor] = None
@@ -86,7 +91,6 @@ class IntSearchResult:
         self._has_duplicates: bool = False  # submanifold map over repeated coordinates: dgrad goes through the pair lists
         self._dup_symmetric: bool = False   # ... with an odd kernel at stride 1: dgrad on the gather kernels after all
         self._rev: Optional[Tuple[Tensor, Tensor, Tensor]] = None
-        self._mask_in_table: bool = False  # `_nbr[:, 31]` is the row's mask (binned builder, 32-column rows): GEMMs may skip `_mask`
         self._num_in: Optional[int] = None
         self._num_out: Optional[int] = None
         self._pair_table_cache: Optional[Tensor] = None
@@ -98,6 +102,29 @@ class IntSearchResult:
         self._on_invalid = None  # called once when validation fails (the convolution evicts the map from its cache)
         self._twin = None  # a map made by exchanging in / out of another one (transposed convolution): that map - its reverse
         #                    tables are this map's forward tables and vice versa, nothing is rebuilt from the pair lists
+
+    @property
+    def has_tables(self) -> bool:
+        """Do the device tables of the gather GEMMs exist (dense or compact)?  Never expands anything."""
+        return self._nbr_dense is not None or self._nbrc is not None
+
+    @property
+    def _nbr(self) -> Optional[Tensor]:
+        if self._nbr_dense is None and self._nbrc is not None:
+            from warpconvnet_amd import _lib
+
+            c = self._nbrc
+            K = self._num_offsets
+            dense = torch.empty((c.shape[0], _lib.lib().wcn_kmap_row_pitch(K)), dtype=torch.int32, device=c.device)
+            _lib.check(_lib.lib().wcn_kmap_densify(_lib.ptr(c), c.shape[0], K, _lib.ptr(dense), _lib.stream_handle(c.device)),
+                       "wcn_kmap_densify")
+            self._nbr_dense = dense
+        return self._nbr_dense
+
+    @_nbr.setter
+    def _nbr(self, value: Optional[Tensor]) -> None:
+        self._nbr_dense = value
+        self._nbrc = None  # (a new dense table replaces whatever the builder left)
 
     @classmethod
     def _blank(cls, num_offsets: int, device) -> "IntSearchResult":

@@ -102,14 +102,14 @@ def attach_tables_from_csr(kmap: IntSearchResult, num_in: int, num_out: int) -> 
     (`nn/functional/sparse_conv/detail/mask_gemm.py:127-254`).
     """
     kmap.validate()  # an optimistic map another consumer left unvalidated: settle (and possibly rebuild) it first
-    if kmap._nbr is not None:
+    if kmap.has_tables:
         return kmap
     twin = kmap._twin
     if twin is not None and not twin._has_duplicates:
         # in / out exchanged (transposed convolution on the cached forward map): this map's gather table is the forward map's
         # reverse table - built once and shared with the forward layer's dgrad - instead of a second pass over the pair lists
         twin.validate()
-        if twin._nbr is not None and twin._nbr.shape[0] == num_in:
+        if twin.has_tables and twin._num_out == num_in:
             kmap._nbr, kmap._mask, kmap._perm = reverse_tables(twin, num_out)
             kmap._offsets_dev = twin._offsets_dev
             kmap._num_in, kmap._num_out = num_in, num_out
@@ -142,7 +142,7 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
     twin = kmap._twin
     if kmap._rev is None and twin is not None and not twin._has_duplicates:
         twin.validate()
-        if twin._nbr is not None and twin._nbr.shape[0] == num_in:  # (an exchanged map: the forward map's own tables)
+        if twin.has_tables and twin._num_out == num_in:  # (an exchanged map: the forward map's own tables)
             kmap._rev = (twin._nbr, twin._mask, twin._perm)
     if kmap._rev is None:
         dev = kmap.in_maps_device.device
@@ -199,6 +199,15 @@ class BuildHints:
         self.div = int(div)
         self.pairs_per_row = float(pairs_per_row)  # kernel volumes not seen yet
         self._by_volume = {}                       # kernel volume -> pairs per row of its last maps
+        self._dense_volumes = set()                # kernel volumes whose scenes overflowed a compact row (> 15 neighbours)
+
+    def compact_rows(self, num_offsets: int) -> bool:
+        """First try of a submanifold build: compact 64-B table rows?  (Dense from then on once a scene has had a row with more
+        than 15 neighbours - the device reports ROW_OVERFLOW and the build is redone dense.)"""
+        return int(num_offsets) not in self._dense_volumes
+
+    def observe_row_overflow(self, num_offsets: int) -> None:
+        self._dense_volumes.add(int(num_offsets))
 
     def reset(self) -> None:
         self.__init__()
@@ -329,7 +338,9 @@ def generate_kernel_map(
     # binned path: capacity of the block table.  Most scenes have >= 4 voxels per occupied 8^3 block (uniform 12 % occupancy:
     # 28, surfaces: ~64); sparser ones raise TABLE_FULL on the device and are rebuilt with one block per voxel (always
     # enough).  `strict`: see wcn.h.
-    state = {"max_blocks": hints.max_blocks(N), "strict": 0}
+    # compact table rows (csrc/kmap_cells.h): the binned builder's own format where the kernel volume allows (17 <= K <= 31)
+    compact_ok = use_binned and bool(L.wcn_kmap_compact_supported(K)) and os.environ.get("WARPCONVNET_AMD_KMAP_COMPACT", "1") != "0"
+    state = {"max_blocks": hints.max_blocks(N), "strict": 0, "compact": bool(compact_ok and hints.compact_rows(K))}
     odd = all(k % 2 == 1 for k in ksize)
     # general maps: the cell table an earlier (validated) submanifold build left on the input coordinate tensor, or the
     # table the down-sampling pass wrote next to the output coordinates
@@ -341,10 +352,11 @@ def generate_kernel_map(
                 and pm[1].shape[0] == M):
             prebuilt = (pm[1], pm[2])
 
-    def launch():
-        """Queue one build (tables + tally + scans + mask sort) on the current stream; nothing waits."""
-        max_blocks, strict = state["max_blocks"], state["strict"]
-        nbr = torch.empty((M, kp), dtype=torch.int32, device=dev)
+    def launch(spec_capacity: int = 0):
+        """Queue one build (tables + tally + scans + mask sort) on the current stream; nothing waits.  ``spec_capacity`` > 0: the
+        pair lists too, at that (speculative) capacity, INSIDE the sort's launches (`wcn_kmap_tally_sort`)."""
+        max_blocks, strict, compact = state["max_blocks"], state["strict"], state["compact"]
+        nbr = torch.empty((M, 16 if compact else kp), dtype=torch.int32, device=dev)
         mask = torch.empty((M, mw), dtype=torch.int32, device=dev)
         block_counts = torch.empty(L.wcn_kmap_counts_bytes(M, K) // 4, dtype=torch.int32, device=dev)
         perm = torch.empty(M, dtype=torch.int32, device=dev)
@@ -356,7 +368,7 @@ def generate_kernel_map(
             ws_bytes = L.wcn_kmap_binned_workspace(N, max_blocks)
             bin_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(
-                L.wcn_kmap_build_binned(_lib.ptr(in_coords), N, _lib.i3(ksize), _lib.i3(dilation), max_blocks, strict,
+                L.wcn_kmap_build_binned(_lib.ptr(in_coords), N, _lib.i3(ksize), _lib.i3(dilation), max_blocks, strict, int(compact),
                                         _lib.ptr(bin_ws), ws_bytes, _lib.ptr(nbr), _lib.ptr(mask), _lib.ptr(meta[K + 1 :]),
                                         stream),
                 "wcn_kmap_build_binned",
@@ -389,17 +401,22 @@ def generate_kernel_map(
         ready.value = 0
         sort_bytes = L.wcn_kmap_tally_sort_workspace(M)
         sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
+        spec_capacity = max(int(spec_capacity), 0) if M > 0 else 0
+        spec_in = torch.empty(spec_capacity, dtype=torch.int32, device=dev) if spec_capacity else None
+        spec_out = torch.empty(spec_capacity, dtype=torch.int32, device=dev) if spec_capacity else None
         _lib.check(
             L.wcn_kmap_tally_sort(_lib.ptr(mask), _lib.ptr(nbr), M, K, _lib.ptr(block_counts), _lib.ptr(meta),
                                   _lib.ptr(meta[K + 1 :]), ctypes.c_void_p(meta_host.data_ptr()), _lib.ptr(perm),
                                   _lib.ptr(sort_ws), sort_bytes, _lib.ptr(in_coords) if use_binned else None,
-                                  _lib.ptr(bin_ws), N if use_binned else 0, max_blocks if use_binned else 0, stream),
+                                  _lib.ptr(bin_ws), N if use_binned else 0, max_blocks if use_binned else 0, int(compact),
+                                  _lib.ptr(spec_in), _lib.ptr(spec_out), spec_capacity, stream),
             "wcn_kmap_tally_sort",
         )
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev))
         return dict(nbr=nbr, mask=mask, perm=perm, block_counts=block_counts, meta=meta, meta_host=meta_host, ready=ready,
-                    event=event, table=table, keep=(bin_ws, sort_ws, cells), max_blocks=max_blocks)
+                    event=event, table=table, keep=(bin_ws, sort_ws, cells), max_blocks=max_blocks, compact=compact,
+                    spec_pairs=(spec_in, spec_out, spec_capacity) if spec_capacity else None)
 
     def scatter(b, capacity):
         """Pair lists of build `b` (buckets ordered by output row), `capacity` entries each; the kernel writes nothing past
@@ -409,7 +426,7 @@ def generate_kernel_map(
         out_maps = torch.empty(capacity, dtype=torch.int32, device=dev)
         _lib.check(
             L.wcn_kmap_scatter(_lib.ptr(b["nbr"]), _lib.ptr(b["mask"]), M, K, _lib.ptr(b["block_counts"]), _lib.ptr(b["meta"]),
-                               _lib.ptr(in_maps), _lib.ptr(out_maps), capacity, _lib.ptr(b["meta"][K + 1 :]),
+                               _lib.ptr(in_maps), _lib.ptr(out_maps), capacity, _lib.ptr(b["meta"][K + 1 :]), int(b["compact"]),
                                _lib.stream_handle(dev)),
             "wcn_kmap_scatter",
         )
@@ -433,6 +450,10 @@ def generate_kernel_map(
                 # with the next larger table from now on
                 hints.div = 4 if hints.div > 4 else 1
                 state["max_blocks"] = max(1024, N // 4) if hints.div == 4 and state["max_blocks"] < max(1024, N // 4) else N
+            elif use_binned and (flags & _lib.WCN_FLAG_ROW_OVERFLOW) and state["compact"]:
+                # a row with more than 15 neighbours (dense volumetric data): dense table rows for this kernel volume from now on
+                hints.observe_row_overflow(K)
+                state["compact"] = False
             elif use_binned and (flags & _lib.WCN_FLAG_NEED_STRICT) and not state["strict"]:
                 state["strict"] = 1
             else:
@@ -440,9 +461,11 @@ def generate_kernel_map(
             b, rebuilt = launch(), True
 
     def attach_tables(result, b):
-        result._nbr, result._mask, result._perm = b["nbr"], b["mask"], b["perm"]
-        # the binned builder stores a row's mask in the free last column of its 32-column table row (csrc/kmap_binned.hip)
-        result._mask_in_table = bool(use_binned and kp == 32 and mw == 1 and K <= 31)
+        result._nbr, result._mask, result._perm = None, b["mask"], b["perm"]
+        if b["compact"]:
+            result._nbrc = b["nbr"]  # (the dense table is expanded from it on first use: IntSearchResult._nbr)
+        else:
+            result._nbr = b["nbr"]
         result._offsets_dev = b["meta"][: K + 1]
         result._hashtable = b["table"]
         result._keepalive = b  # (workspaces the queued kernels still read)
@@ -461,7 +484,7 @@ def generate_kernel_map(
         if has_duplicates and same_tensor:
             identity = None  # "output row i == input row i at the centre offset" fails for the rows that lost their coordinate
         hints.observe_pairs(M, pair_capacity, K)
-        if use_binned and not (flags & (_lib.WCN_FLAG_TABLE_FULL | _lib.WCN_FLAG_NEED_STRICT)):
+        if use_binned and not (flags & (_lib.WCN_FLAG_TABLE_FULL | _lib.WCN_FLAG_NEED_STRICT | _lib.WCN_FLAG_ROW_OVERFLOW)):
             # the cell table of this coordinate set is complete and keeps the smallest row of every coordinate: strided
             # layers on the same tensor reuse it (down-sampling and their kernel maps, coords/ops/stride.py)
             attach_cells(in_coords, b["keep"][0], N, b["max_blocks"])
@@ -508,19 +531,22 @@ def generate_kernel_map(
     result._num_in, result._num_out = N, M
     result._kernel_size = ksize
     result._stride_window = prebuilt is not None  # (tables written by the down-sampling pass: every input row in one window)
-    first = launch()
+    # optimistic builds that need the pair lists (the weight gradient's input) write them without knowing the pair count:
+    # capacity from the pairs per row of earlier maps (`hints`; the kernel writes nothing past it, validate() rewrites a short
+    # guess at the exact length), inside the launches of the mask sort (a stride-window map pairs every input row with at most
+    # one cell: N bounds its lists exactly)
+    spec = 0
+    if optimistic and need_pairs and M > 0:
+        spec = min(N, K * M) if prebuilt is not None else hints.pair_capacity(M, K)
+    first = launch(spec)
     if optimistic:
         # The caller launches its forward kernel on these tables BEFORE the status word is read (`IntSearchResult.validate`
         # afterwards): the host never stands between the scan kernel and the forward, so the GPU runs the mask sort and the
         # forward back to back instead of idling for the host's round trip.  Every scene a voxeliser produces passes; a
         # build the device rejects (block table too small, duplicate coordinates that need the strict insert) is redone
         # inside validate(), which then reports that the tables changed.
-        if need_pairs:
-            # the pair lists (the weight gradient's input) without knowing the pair count: capacity from the pairs per row of
-            # earlier maps (`hints`; the kernel writes nothing past it, validate() rewrites a short guess at the exact length),
-            # the scatter queued right behind the mask sort while the neighbour table is still in the Infinity Cache
-            # (a stride-window map pairs every input row with at most one cell: N bounds its lists exactly)
-            first["spec_pairs"] = scatter(first, min(N, K * M) if prebuilt is not None else hints.pair_capacity(M, K))
+        if need_pairs and first.get("spec_pairs") is None:  # (M == 0)
+            first["spec_pairs"] = scatter(first, 0)
         attach_tables(result, first)
 
         def validate_fn(res, b=first):

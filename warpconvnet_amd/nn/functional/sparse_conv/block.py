@@ -151,8 +151,8 @@ class _ConvBnAct(Function):
         xp, wpp, yp = _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y)
 
         def launch():
-            mk = hip_gemm.table_mask(km, km._nbr, km._mask, cin, cout, K, x.dtype)  # (None: the rows of the table carry their masks)
-            _lib.check(L.wcn_conv_gather_gemm(xp, wpp, yp, _lib.ptr(km._nbr), _lib.ptr(mk), _lib.ptr(km._perm), None,
+            tb, mk = hip_gemm.own_tables(km, cin, cout, K, x.dtype)  # (compact rows and no mask where the kernel takes them)
+            _lib.check(L.wcn_conv_gather_gemm(xp, wpp, yp, _lib.ptr(tb), _lib.ptr(mk), _lib.ptr(km._perm), None,
                                               plan.num_in, M, cin, cout, K, code, _lib.WCN_ALGO_MFMA, 0, 0, stream),
                        "wcn_conv_gather_gemm")
 
@@ -204,10 +204,9 @@ class _ConvBnAct(Function):
         flip = False
         if need_dx:
             if km._symmetric:
-                tbl, msk, perm, flip = km._nbr, km._mask, km._perm, True
+                (tbl, msk), perm, flip = hip_gemm.own_tables(km, cout, cin, K, y.dtype), km._perm, True
             else:
                 tbl, msk, perm = reverse_tables(km, plan.num_in)
-            msk = hip_gemm.table_mask(km, tbl, msk, cout, cin, K, y.dtype)
             wpd = hip_gemm.pack_weight(w, True, flip, dtype=y.dtype)
             dx = torch.empty((plan.num_in, cin), dtype=y.dtype, device=dev)
         dw = wws = None
@@ -385,7 +384,7 @@ def conv_bn_act(x, conv, norm, relu: bool, residual=None, out_spatial=None):
         bcoords_out, out_offsets, km = generate_output_coords_and_kernel_map(
             x, conv.kernel_size, conv.dilation, conv.stride, need_pairs=torch.is_grad_enabled(), optimistic=True)
     M = bcoords_out.shape[0]
-    if M < 2 or km._nbr is None:
+    if M < 2 or not km.has_tables:
         # degenerate sizes, or a map that only has its CSR form (user-made): the general path (it finds the map in the cache)
         return None
     feats = x.feature_tensor

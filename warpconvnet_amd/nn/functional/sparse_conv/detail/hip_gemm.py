@@ -97,18 +97,21 @@ def resolve_wgrad_algo(algo: str, cin: int, cout: int, dtype: torch.dtype) -> in
 
 
 @functools.lru_cache(maxsize=None)
-def _mask_in_table_ok(cin: int, cout: int, K: int, code: int) -> bool:
-    return bool(_lib.lib().wcn_conv_mask_in_table_supported(cin, cout, K, code))
+def _compact_ok(cin: int, cout: int, K: int, code: int) -> bool:
+    return bool(_lib.lib().wcn_conv_compact_table_supported(cin, cout, K, code))
 
 
-def table_mask(kernel_map, tbl: Tensor, mask: Tensor, kin: int, kout: int, K: int, dtype: torch.dtype) -> Optional[Tensor]:
-    """The mask argument of a gather-GEMM launch on ``tbl``: None when the table is the map's own binned table (its rows carry
-    their masks in the last column) and the shape is one the channel-split kernels take - they then read it with the index slab
-    instead of gathering ``mask[perm[i]]``, a 128-B line per row."""
-    if (getattr(kernel_map, "_mask_in_table", False) and tbl is kernel_map._nbr and dtype in (torch.float16, torch.bfloat16)
-            and _mask_in_table_ok(kin, kout, K, _lib.dtype_code(dtype))):
-        return None
-    return mask
+def own_tables(kernel_map, kin: int, kout: int, K: int, dtype: torch.dtype, mfma: bool = True):
+    """``(table, mask)`` of a gather-GEMM launch on the map's OWN forward table (the forward product, or the dgrad of a
+    submanifold map, which reads the same table with the offsets reversed).  The binned builder leaves COMPACT rows
+    (``kernel_map._nbrc``, `csrc/kmap_cells.h`): where the channel-split kernels take the shape they are passed as they are, with
+    ``mask`` = None - half the table bytes of the launch and no gather of ``mask[perm[i]]`` (a 128-B line per row).  Everything
+    else gets the dense table (expanded from the compact rows on first use) and the mask array."""
+    c = getattr(kernel_map, "_nbrc", None)
+    if (mfma and c is not None and dtype in (torch.float16, torch.bfloat16)
+            and _compact_ok(kin, kout, K, _lib.dtype_code(dtype))):
+        return c, None
+    return kernel_map._nbr, kernel_map._mask
 
 
 @functools.lru_cache(maxsize=None)
@@ -306,7 +309,8 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
         if _fp32_via_fp16(algo, cin, cout, K, x.dtype):
             x16, sx = fp16_safe_cast(x)
             w16, sw = fp16_safe_cast(w)
-            y = _gather_gemm(x16, w16, kernel_map._nbr, kernel_map._mask, kernel_map._perm, num_out_coords, cin, cout, K,
+            tb, mk = own_tables(kernel_map, cin, cout, K, torch.float16)
+            y = _gather_gemm(x16, w16, tb, mk, kernel_map._perm, num_out_coords, cin, cout, K,
                              _lib.WCN_ALGO_MFMA, transposed=False, flip=False, bias=None, f32_out=True)
             y = y * (sx * sw)  # exact power-of-two multiply-back, no host sync
             return y if bias is None else y + bias
@@ -320,8 +324,8 @@ def hip_forward(in_features: Tensor, weight: Tensor, kernel_map: IntSearchResult
         else:
             ks = getattr(kernel_map, "_kernel_size", None)
             guess = bool(ks is not None and all(int(k) % 2 == 1 for k in ks) and kernel_map._num_in == kernel_map._num_out)
-        mk = table_mask(kernel_map, kernel_map._nbr, kernel_map._mask, cin, cout, K, x.dtype) if code == _lib.WCN_ALGO_MFMA else kernel_map._mask
-        return _gather_gemm(x, w, kernel_map._nbr, mk, kernel_map._perm, num_out_coords, cin, cout, K, code,
+        tb, mk = own_tables(kernel_map, cin, cout, K, x.dtype, mfma=code == _lib.WCN_ALGO_MFMA)
+        return _gather_gemm(x, w, tb, mk, kernel_map._perm, num_out_coords, cin, cout, K, code,
                             transposed=False, flip=False, bias=bias, dgrad_flip=guess)
 
     # An optimistic map (built by the convolution itself this very call) has not had its status word read: the forward is
@@ -378,6 +382,7 @@ def _dgrad_duplicates(dy: Tensor, w: Tensor, kernel_map: IntSearchResult, num_in
     dyp = torch.zeros((n, dy.shape[1]), dtype=torch.float32, device=dy.device).index_add_(0, winner, dy.float()).to(dy.dtype)
     shadow = IntSearchResult._blank(K, dy.device)  # the same tables, seen as a map without duplicates
     shadow._nbr, shadow._mask, shadow._perm = kernel_map._nbr, kernel_map._mask, kernel_map._perm
+    shadow._nbrc = getattr(kernel_map, "_nbrc", None)
     shadow._offsets_dev, shadow._offsets = kernel_map._offsets_dev, kernel_map._offsets
     shadow._symmetric, shadow._has_duplicates = True, False
     shadow._in_maps, shadow._out_maps = kernel_map._in_maps, kernel_map._out_maps
@@ -395,7 +400,7 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
     K, cin, cout = w.shape
     kernel_map.validate()
     if getattr(kernel_map, "_has_duplicates", False):
-        if getattr(kernel_map, "_dup_symmetric", False) and kernel_map._nbr is not None and dy.shape[0] == num_in_coords:
+        if getattr(kernel_map, "_dup_symmetric", False) and kernel_map.has_tables and dy.shape[0] == num_in_coords:
             return _dgrad_duplicates(dy, w, kernel_map, num_in_coords, algo)
         return _dgrad_pair_lists(dy, w, kernel_map, num_in_coords)
     if algo == "auto" and dy.is_cuda and not _gather_ok(cout, cin, K, _code16(dy.dtype)):
@@ -404,20 +409,20 @@ def hip_dgrad(grad_output: Tensor, weight: Tensor, kernel_map: IntSearchResult, 
             wp_ = torch.nn.functional.pad(w.to(dy.dtype) if w.dtype != dy.dtype else w, (0, plan[0] - cout, 0, plan[1] - cin))
             return hip_dgrad(_pad_cols(dy, plan[0]), wp_, kernel_map, num_in_coords, algo)[:, :cin].contiguous()
     attach_tables_from_csr(kernel_map, num_in_coords, dy.shape[0])
+    via16 = _fp32_via_fp16(algo, cout, cin, K, dy.dtype)
+    code = _lib.WCN_ALGO_MFMA if via16 else resolve_gather_algo(algo, cout, cin, K, dy.dtype)
     if kernel_map._symmetric:
-        tbl, mask, perm, flip = kernel_map._nbr, kernel_map._mask, kernel_map._perm, True
+        tbl, mask = own_tables(kernel_map, cout, cin, K, torch.float16 if via16 else dy.dtype, mfma=code == _lib.WCN_ALGO_MFMA)
+        perm, flip = kernel_map._perm, True
     else:
         tbl, mask, perm = reverse_tables(kernel_map, num_in_coords)
         flip = False
-    if _fp32_via_fp16(algo, cout, cin, K, dy.dtype):
+    if via16:
         g16, sg = fp16_safe_cast(dy)
         w16, sw = fp16_safe_cast(w)
         dx = _gather_gemm(g16, w16, tbl, mask, perm, num_in_coords, cout, cin, K, _lib.WCN_ALGO_MFMA, transposed=True,
                           flip=flip, f32_out=True)
         return dx * (sg * sw)
-    code = resolve_gather_algo(algo, cout, cin, K, dy.dtype)
-    if code == _lib.WCN_ALGO_MFMA:
-        mask = table_mask(kernel_map, tbl, mask, cout, cin, K, dy.dtype)
     return _gather_gemm(dy, w, tbl, mask, perm, num_in_coords, cout, cin, K, code, transposed=True, flip=flip)
 
 

@@ -75,9 +75,10 @@ def hip_forward_fused(in_features: Tensor, weight: Tensor, kernel_map, num_out_c
     if num_out_coords == 0:
         return out
     wp = hip_gemm.pack_weight(w, False, False)
+    tb, mk = hip_gemm.own_tables(kernel_map, cin, cout, K, x.dtype)
     _lib.check(
-        L.wcn_conv_gather_gemm_fused(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(out), _lib.ptr(kernel_map._nbr),
-                                     _lib.ptr(kernel_map._mask), _lib.ptr(kernel_map._perm), _lib.ptr(bias), _lib.ptr(scale),
+        L.wcn_conv_gather_gemm_fused(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(out), _lib.ptr(tb),
+                                     _lib.ptr(mk), _lib.ptr(kernel_map._perm), _lib.ptr(bias), _lib.ptr(scale),
                                      _lib.ptr(shift), _lib.ptr(residual), int(relu), x.shape[0], num_out_coords, cin, cout, K,
                                      _lib.dtype_code(x.dtype), _lib.stream_handle(dev)),
         "wcn_conv_gather_gemm_fused",
