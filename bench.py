@@ -159,6 +159,81 @@ def secondary_configs(dev, args):
                          "voxels": ns, "pairs_per_voxel": round(pairs[0] / ns, 2),
                          "whole_step_hbm_frac": round(sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
+    # ---- the headline step over a ROTATING set of resident U scenes of different size (0.6 / 0.8 / 1.0 / 1.2 x the headline):
+    # every build meets sizing hints (block-table bound, speculative pair capacity) learned on a DIFFERENT scene
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import default_hints
+
+    rot = []
+    for i, frac in enumerate((0.6, 0.8, 1.0, 1.2)):
+        cr = torch.from_numpy(scene_u(int(args.voxels * frac), seed=2000 + i)).to(dev)
+        gr = torch.Generator().manual_seed(20 + i)
+        rot.append((cr, torch.randn(cr.shape[0], CIN, generator=gr).to(dev, torch.bfloat16).requires_grad_(True),
+                    torch.randn(cr.shape[0], COUT, generator=gr).to(dev, torch.bfloat16), torch.tensor([0, cr.shape[0]], dtype=torch.int32)))
+    turn = [0]
+
+    def rotating_step():
+        cr, fr, gr_, offr = rot[turn[0] % len(rot)]
+        turn[0] += 1
+        for p in conv_s.parameters():
+            p.grad = None
+        fr.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv_s(Voxels(cr, fr, offsets=offr))
+        y.batched_features.batched_tensor.backward(gr_)
+
+    for _ in range(8):
+        rotating_step()
+    stats0 = dict(default_hints().stats)
+    turn[0] = 0
+    ms = time_events(rotating_step, 48, warmup=0)
+    stats1 = default_hints().stats
+    vox_per_step = sum(r[0].shape[0] for r in rot) / len(rot)
+    out["rotating_scenes"] = {"value": round(vox_per_step / (ms * 1e-3) / 1e6, 3), "unit": "M voxels/s", "ms_per_step": round(ms, 4),
+                              "scene_voxels": [int(r[0].shape[0]) for r in rot], "steps": 48,
+                              "builds": stats1["builds"] - stats0["builds"], "rebuilds": stats1["rebuilds"] - stats0["rebuilds"],
+                              "pair_list_rewrites": stats1["pair_rewrites"] - stats0["pair_rewrites"],
+                              "note": "headline step cycling over four resident U scenes: sizing hints always come from another scene"}
+    del rot
+
+    # ---- large kernel volumes on the 200 k surface scene, 32 -> 64: map build alone and the whole step ----
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import generate_kernel_map
+
+    c3 = torch.from_numpy(scene_surface(200_000, seed=3)).to(dev)
+    n3 = c3.shape[0]
+    b3 = torch.cat([torch.zeros(n3, 1, dtype=torch.int32, device=dev), c3], 1).contiguous()
+    g3 = torch.Generator().manual_seed(9)
+    f3 = torch.randn(n3, 32, generator=g3).to(dev, torch.bfloat16).requires_grad_(True)
+    d3 = torch.randn(n3, 64, generator=g3).to(dev, torch.bfloat16)
+    off3 = torch.tensor([0, n3], dtype=torch.int32)
+    big = {}
+    for label, ks, dil in (("k3", 3, 1), ("k5", 5, 1), ("k7", 7, 1), ("k3_dilation9_hash", 3, 9)):
+        torch.manual_seed(0)
+        conv3 = SparseConv3d(32, 64, ks, dilation=dil, bias=True).to(dev)
+        K3 = ks ** 3
+        km3 = generate_kernel_map(b3, b3, (1, 1, 1), (ks,) * 3, (dil,) * 3)
+        L3 = int(km3.offsets[-1])
+        t_map = time_events(lambda: generate_kernel_map(b3, b3, (1, 1, 1), (ks,) * 3, (dil,) * 3).in_maps_device, 10, warmup=2)
+
+        def big_step():
+            for p in conv3.parameters():
+                p.grad = None
+            f3.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = conv3(Voxels(c3, f3, offsets=off3))
+            y.batched_features.batched_tensor.backward(d3)
+
+        t_step = time_events(big_step, 10, warmup=3)
+        ab3 = algorithmic_bytes(n3, L3, 32, 64, K3)
+        big[label] = {"num_offsets": K3, "pairs": L3, "map_build_ms": round(t_map, 4), "step_ms": round(t_step, 4),
+                      "ns_per_probe": round(t_map * 1e6 / (K3 * n3), 3),
+                      "map_frac": round(ab3["kmap"] / (t_map * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "step_frac": round(sum(ab3.values()) / (t_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "builder": "hash" if dil * (ks // 2) > 8 else "cell table"}
+        del km3
+    out["large_kernels_200k"] = {"voxels": n3, "channels": "32->64", **big,
+                                 "note": "map build (incl. pair lists) and fwd+bwd step with a fresh map; frac = SURVEY 8d algorithmic bytes / time / 8 TB/s; "
+                                         "k3_dilation9 has a halo of 9 cells: beyond the cell table's 8, the global hash path"}
+
     # ---- config 3: MinkUNet-14 ----
     torch.manual_seed(0)
     net = MinkUNet14(3, 20).to(dev)
@@ -324,8 +399,8 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
                 "compulsory_frac": round(comp[key] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
                 "isolated_ms": round(iso[key], 4), "algorithmic_bytes_per_launch": int(ab[key])}
 
-    # the dominant kernel = the GEMM with the largest IN-STEP time (stable: dgrad moves the most bytes)
-    dom_key = max(("fwd", "dgrad", "wgrad"), key=lambda k: times[k])
+    # the dominant PHASE = the one with the largest IN-STEP time, the kernel-map build (a chain of launches) included
+    dom_key = max(("fwd", "dgrad", "wgrad", "kmap"), key=lambda k: times[k])
     dom = entry(dom_key)
     # HBM bytes per launch from the PMC passes (separate rocprofv3 runs of this same command, tools/collect_profiles.sh): a
     # STATIC figure read from the newest committed summary, not a measurement of this run - labelled as such in the line
@@ -335,10 +410,18 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
     if N == 1_000_000 and args.scene == "uniform" and pmc_files:
         with open(os.path.join(prof_dir, pmc_files[-1])) as f:
             pmc = json.load(f)
-        if dom_key in pmc:
+        from warpconvnet_amd.utils.codesig import phase_signatures
+
+        running = phase_signatures(_lib.LIB_PATH).get(dom_key)
+        stamped = (pmc.get("kernel_signatures") or {}).get(dom_key)
+        if dom_key in pmc and stamped is not None and stamped == running:
             traffic = pmc[dom_key]["hbm_bytes"]
             traffic_src = (f"profiles/{pmc_files[-1]} (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this "
-                           "command; static: read from the committed summary)")
+                           f"command; static: read from the committed summary, whose kernel signature {stamped} equals the running "
+                           "library's)")
+        elif dom_key in pmc:
+            traffic_src = (f"profiles/{pmc_files[-1]} was collected on other kernels (signature {stamped} vs the running library's "
+                           f"{running}): no traffic figure until tools/collect_profiles.sh has been rerun")
 
     # map-cached variant (networks amortise the map over the layers of a resolution level)
     x_cached = Voxels(coords, feats, offsets=offsets)
@@ -376,7 +459,7 @@ def report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, 
             "voxels_per_gpu": N, "pairs_per_scene": L, "coord_order": args.coord_order, "parallelism": f"dp{world} (scene-sharded, grad all-reduce)" + ("" if world == 1 else "; N > 1 has run under gloo on CPU only before this launch (no earlier RCCL measurement exists)"),
         },
         "roofline": {
-            "bound": "hbm", "kernel": names[dom_key], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": names[dom_key], "phase": dom_key, "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac"], "compulsory_frac": dom["compulsory_frac"], "traffic": traffic, "traffic_static": traffic is not None,
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
@@ -562,9 +645,29 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = N * world * args.steps / elapsed / 1e6
 
+    diag = None
+    if world > 1:
+        # the first multi-GPU run is also the first RCCL run: make it self-diagnosing - which ranks took part (all-gather), and
+        # what one gradient all-reduce of this step's size costs on its own (the step hides it behind the backward)
+        seen = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64, device=dev))
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(flat)
+        e1.record()
+        e1.synchronize()
+        diag = {"ranks_seen": sorted(int(t.item()) for t in seen), "grad_allreduce_ms": round(e0.elapsed_time(e1) / 20, 4),
+                "grad_allreduce_bytes": int(flat.numel() * 4), "backend": dist.get_backend()}
     result = None
     if rank == 0:
         result = report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, value, ms_per_step, second_half)
+        if diag is not None:
+            result["multi_gpu"] = diag
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -124,7 +124,7 @@ def traffic(fetch_db, write_db):
             "select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
         per_kernel = {}
         for k, v in rows:
-            if any(t in k for t in ("cell_", "kmap_", "rs_kernel")):
+            if any(t in k for t in ("cell_", "kmap_", "rs_kernel", "rs_pairs")):
                 a = per_kernel.setdefault(k, [0, 0.0])
                 a[0] += 1
                 a[1] += v
@@ -137,6 +137,12 @@ def traffic(fetch_db, write_db):
     kw, kwd = per_build(write_db, "WRITE_SIZE", w)
     out["kmap"] = {"fetch_bytes": int(2.0 * 1024 * kf), "write_bytes": int(1024 * kw), "hbm_bytes": int(2.0 * 1024 * kf + 1024 * kw),
                    "fetch_kib_per_build_by_kernel": kfd, "write_kib_per_build_by_kernel": kwd}
+    # stamp: the kernels these counters were collected on (bench.py reports the figures only while the library still has them)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from warpconvnet_amd.utils.codesig import phase_signatures
+    from warpconvnet_amd import _lib
+    out["kernel_signatures"] = phase_signatures(_lib.LIB_PATH)
     print(json.dumps(out, indent=1))
 
 

@@ -254,7 +254,7 @@ struct KsArgs {
   int32_t* status;
   int compact;  // nbr holds COMPACT rows (kmap_cells.h); one mask word
 };
-constexpr size_t kKsLds = (size_t)2 * kStageCap * 4 + 32 * 8 + (size_t)(kBkThreads / 64) * 32 * 12 + 36 * 4 + kStageCap + kBkThreads * 4;
+constexpr size_t kKsLds = (size_t)2 * kStageCap * 4 + 32 * 8 + (size_t)(kBkThreads / 64) * 32 * 12 + 36 * 4 + kStageCap;
 
 __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_id, char* smem) {
   const int32_t* __restrict__ nbr = q.nbr;
@@ -272,7 +272,6 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
   int(*s_cnt)[32] = reinterpret_cast<int(*)[32]>(s_ball + kBkThreads / 64);  // pairs per (wave, offset), then exclusive over the waves
   int* s_seg = reinterpret_cast<int*>(s_cnt + kBkThreads / 64);               // [33] first staged position of every offset
   unsigned char* s_bk = reinterpret_cast<unsigned char*>(s_seg + 36);         // [kStageCap] offset (inside the word) of a staged pair
-  uint32_t* s_rowmask = reinterpret_cast<uint32_t*>(s_bk + kStageCap);        // [kBkThreads] masks of the tile's rows (compact tables)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = tile_id * kTileRows + wave * 64;
   const int64_t row = row0 + lane;
@@ -282,30 +281,14 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
     const int cols4 = ((kp - w * 32) < 32 ? (kp - w * 32) : 32) >> 2;  // 16-B chunks per row in this word
     // cols4 (<= 8) 16-B pieces per lane, all requested up front
     int4 piece[8];
-    if (q.compact) {  // 4 pieces per 64-B row: lane l holds piece l % 4 of rows l / 4 + 16 j
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = (lane >> 2) + 16 * j;
-        piece[j] = make_int4(0, 0, 0, 0);
-        if (row0 + r < m) piece[j] = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kCompactPitch + (lane & 3) * 4);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int e = lane + 64 * j;
-        const int r = e / cols4, c = e - r * cols4;
-        piece[j] = make_int4(-1, -1, -1, -1);
-        if (j < cols4 && row0 + r < m) piece[j] = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kp + w * 32 + c * 4);
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int e = lane + 64 * j;
+      const int r = e / cols4, c = e - r * cols4;
+      piece[j] = make_int4(-1, -1, -1, -1);
+      if (j < cols4 && row0 + r < m) piece[j] = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kp + w * 32 + c * 4);
     }
-    uint32_t bits = row < m ? mask[row * mw + w] : 0u;
-    if (q.compact) {
-      // a row that did not fit its compact row (> 15 neighbours; the build is flagged ROW_OVERFLOW and redone): it stages
-      // NOTHING, and must not be counted either - a counted pair that is never staged leaves a slot of the staging area with
-      // a stale bucket id, and the flush would compute its position from it
-      if (__popc(bits) > kCompactIds) bits = 0u;
-      s_rowmask[tid] = bits;
-    }
+    const uint32_t bits = row < m ? mask[row * mw + w] : 0u;
     // row bitmaps and pair counts of the word's offsets (lane b keeps offset w*32+b)
     unsigned long long mine = 0ull;
     for (int b = 0; b < kend; ++b) {
@@ -340,41 +323,7 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
     __syncthreads();
     const int total = s_seg[32];
     const bool staged = total <= kStageCap;
-    if (q.compact) {
-      // word 4c + t of a row is the neighbour of its (4c + t - 1)-th SET offset: strip the offsets below from the row's mask,
-      // then walk the next ones with ctz
-      const int c = lane & 3;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = (lane >> 2) + 16 * j;
-        uint32_t rem = s_rowmask[wave * 64 + r];
-        for (int sk = 4 * c - 1; sk > 0; --sk) rem &= rem - 1u;
-        const unsigned long long below = (1ull << r) - 1ull;
-        const int vals[4] = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (c == 0 && t == 0) continue;  // word 0: the mask
-          if (rem == 0u) break;
-          const int b = __builtin_ctz(rem);
-          rem &= rem - 1u;
-          const int local = s_cnt[wave][b] + __popcll(s_ball[wave][b] & below);
-          if (staged) {
-            const int at = s_seg[b] + local;
-            s_in[at] = vals[t];
-            s_out[at] = (int32_t)(row0 + r);
-            s_bk[at] = (unsigned char)b;
-          } else {
-            const int64_t pos = s_gbase[b] + local;
-            if (pos < pair_capacity) {
-              in_maps[pos] = vals[t];
-              out_maps[pos] = (int32_t)(row0 + r);
-            } else {
-              overflow = true;
-            }
-          }
-        }
-      }
-    } else if ((64 % cols4) == 0) {
+    if ((64 % cols4) == 0) {
       // 1 / 2 / 4 / 8 pieces per row: a lane holds the SAME four table columns 4c .. 4c+3 in every piece (rows r0 + j * rstep), so
       // everything that depends on the offset alone - the wave's pair count below it, its row bitmap, the staged and the global
       // base - is read once per word instead of once per value (3 LDS reads of 4 per value were these)
@@ -463,12 +412,145 @@ __device__ __forceinline__ void kmap_scatter_body(const KsArgs& q, int64_t tile_
   if (overflow) atomicOr(q.status, (int)WCN_FLAG_PAIR_OVERFLOW);
 }
 
+// The same for COMPACT rows (kmap_cells.h; one mask word).  Word 4c + t of a row is the neighbour of its (4c + t - 1)-th SET
+// offset.  The dense body spends 4 LDS reads and 3 LDS writes per pair (counts, row bitmap, segment start, global base; row id,
+// output row, bucket) - at 4.2 M pairs that is what the kernel's time was (round 6: ~1.7 M wave-level LDS instructions, 41 us for
+// a kernel that moves 100 MB).  Here a pair costs ONE 16-B read ({row bitmap of the wave, staged position of the wave's first
+// pair} per (wave, offset)) and ONE 8-B write ({input row, output row inside the tile << 8 | offset}).
+struct __attribute__((aligned(16))) KcSlot {
+  unsigned long long ball;  // rows of the wave that have the offset
+  int base;                 // staged position of the wave's first pair of the offset
+  int pad;
+};
+constexpr size_t kKcLds = (size_t)kStageCap * 8 + (size_t)(kBkThreads / 64) * 32 * sizeof(KcSlot) + 32 * 8 + 36 * 4 + kBkThreads * 4;
+
+__global__ __launch_bounds__(kBkThreads) void kmap_scatter_compact_kernel(KsArgs q) {
+  extern __shared__ __attribute__((aligned(16))) char s_kc[];
+  uint2* s_pair = reinterpret_cast<uint2*>(s_kc);                                   // [kStageCap] staged pairs
+  KcSlot(*s_wb)[32] = reinterpret_cast<KcSlot(*)[32]>(s_pair + kStageCap);          // [waves][32]
+  int64_t* s_delta = reinterpret_cast<int64_t*>(s_wb + kBkThreads / 64);            // [32] global position minus staged position
+  int* s_seg = reinterpret_cast<int*>(s_delta + 32);                                // [33] first staged position of every offset
+  uint32_t* s_rowmask = reinterpret_cast<uint32_t*>(s_seg + 36);                    // [kBkThreads]
+  const int32_t* __restrict__ nbr = q.nbr;
+  const int64_t m = q.m, pair_capacity = q.pair_capacity;
+  const int K = q.K;
+  int32_t* __restrict__ in_maps = q.in_maps;
+  int32_t* __restrict__ out_maps = q.out_maps;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tile_row0 = (int64_t)blockIdx.x * kTileRows;
+  const int64_t row0 = tile_row0 + wave * 64;
+  const int64_t row = row0 + lane;
+  // 4 pieces per 64-B row: lane l holds piece l % 4 of rows l / 4 + 16 j - the wave's 4 KB of rows are one contiguous stream
+  int4 piece[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (lane >> 2) + 16 * j;
+    piece[j] = make_int4(0, 0, 0, 0);
+    if (row0 + r < m) piece[j] = *reinterpret_cast<const int4*>(nbr + (row0 + r) * kCompactPitch + (lane & 3) * 4);
+  }
+  uint32_t bits = row < m ? q.mask[row] : 0u;
+  // a row that did not fit its compact row (> 15 neighbours; the build is flagged ROW_OVERFLOW and redone) stages NOTHING and
+  // must not be counted either: a counted pair that is never staged leaves a stale slot in the staging area
+  if (__popc(bits) > kCompactIds) bits = 0u;
+  s_rowmask[tid] = bits;
+  unsigned long long mine = 0ull;
+  for (int b = 0; b < K; ++b) {
+    const unsigned long long ball = __ballot((bits >> b) & 1u);
+    if (lane == b) mine = ball;
+  }
+  if (lane < 32) {
+    s_wb[wave][lane].ball = mine;
+    s_wb[wave][lane].base = __popcll(mine);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int tot = 0, cw[kBkThreads / 64];
+    if (lane < 32) {
+#pragma unroll
+      for (int w2 = 0; w2 < kBkThreads / 64; ++w2) {
+        cw[w2] = tot;
+        tot += s_wb[w2][lane].base;
+      }
+    }
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    if (lane < 32) {
+      const int seg = incl - tot;
+      s_seg[lane] = seg;
+#pragma unroll
+      for (int w2 = 0; w2 < kBkThreads / 64; ++w2) s_wb[w2][lane].base = seg + cw[w2];
+      int64_t g = 0;
+      if (lane < K) g = (int64_t)q.offsets[lane] + q.counts[(int64_t)lane * q.ntile + blockIdx.x];
+      s_delta[lane] = g - seg;
+    }
+    if (lane == 31) s_seg[32] = incl;
+  }
+  __syncthreads();
+  const int total = s_seg[32];
+  const bool staged = total <= kStageCap;
+  bool overflow = false;
+  const int c = lane & 3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (lane >> 2) + 16 * j;
+    uint32_t rem = s_rowmask[wave * 64 + r];
+    for (int sk = 4 * c - 1; sk > 0; --sk) rem &= rem - 1u;  // strip the offsets of the words in front of this piece
+    const unsigned long long below = (1ull << r) - 1ull;
+    const int vals[4] = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (c == 0 && t == 0) continue;  // word 0: the mask
+      if (rem == 0u) break;
+      const int b = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      const uint4 slot = *reinterpret_cast<const uint4*>(&s_wb[wave][b]);
+      const unsigned long long ball = ((unsigned long long)slot.y << 32) | slot.x;
+      const int at = (int)slot.z + __popcll(ball & below);
+      if (staged) {
+        s_pair[at] = make_uint2((uint32_t)vals[t], (uint32_t)(((wave * 64 + r) << 8) | b));
+      } else {
+        const int64_t pos = s_delta[b] + at;
+        if (pos < pair_capacity) {
+          in_maps[pos] = vals[t];
+          out_maps[pos] = (int32_t)(row0 + r);
+        } else {
+          overflow = true;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (staged) {
+    for (int e = tid; e < total; e += kBkThreads) {
+      const uint2 pr = s_pair[e];
+      const int64_t pos = s_delta[pr.y & 31u] + e;
+      if (pos < pair_capacity) {
+        in_maps[pos] = (int32_t)pr.x;
+        out_maps[pos] = (int32_t)(tile_row0 + (pr.y >> 8));
+      } else {
+        overflow = true;
+      }
+    }
+  }
+  if (overflow) atomicOr(q.status, (int)WCN_FLAG_PAIR_OVERFLOW);
+}
+
 __global__ __launch_bounds__(kBkThreads) void kmap_scatter_kernel(KsArgs q) {
   extern __shared__ char s_ks[];
   kmap_scatter_body(q, blockIdx.x, s_ks);
 }
 
 static inline bool valid_k(int32_t k) { return k >= 1 && k <= 4096; }
+
+static void launch_scatter(const KsArgs& q, hipStream_t s) {
+  const dim3 grid((unsigned)ceil_div(q.m, kTileRows)), block(kBkThreads);
+  if (q.compact) hipLaunchKernelGGL(kmap_scatter_compact_kernel, grid, block, kKcLds, s, q);
+  else hipLaunchKernelGGL(kmap_scatter_kernel, grid, block, kKsLds, s, q);
+}
 
 // compact rows -> the dense [m, kp] table (-1 = absent): one thread per 16-B piece of a dense row
 __global__ __launch_bounds__(256) void kmap_densify_kernel(const int32_t* __restrict__ nbrc, int64_t m, int kp,
@@ -608,7 +690,7 @@ int wcn_kmap_tally_sort(uint32_t* mask, int32_t* nbr, int64_t m, int32_t num_off
     // ~16 us (2.5 rounds of 3 907 workgroups), so every launch that carries some lasts that long, and both kinds of
     // workgroup are bound by the rate of scattered store requests, which does not overlap (OPTIMISATION_LOG appendix G)
     const KsArgs q = ks_args(nbr, mask, m, num_offsets, counts, offsets, in_maps, out_maps, pair_capacity, status, compact ? 1 : 0);
-    hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(m, kTileRows)), dim3(kBkThreads), kKsLds, s, q);
+    launch_scatter(q, s);
   }
   return launch_status();
 }
@@ -624,6 +706,16 @@ static KsArgs ks_args(const int32_t* nbr, const uint32_t* mask, int64_t m, int32
   return q;
 }
 
+int wcn_kmap_densify(const int32_t* nbr_compact, int64_t m, int32_t num_offsets, int32_t* nbr, wcn_stream_t stream) {
+  if (m < 0 || !wcn_kmap_compact_supported(num_offsets)) return WCN_ERROR_INVALID_PARAMETERS;
+  if (m == 0) return WCN_SUCCESS;
+  if (!nbr_compact || !nbr) return WCN_ERROR_INVALID_PARAMETERS;
+  const int kp = wcn_kmap_row_pitch(num_offsets);
+  hipLaunchKernelGGL(kmap_densify_kernel, dim3((unsigned)ceil_div(m * (kp >> 2), 256)), dim3(256), 0, (hipStream_t)stream,
+                     nbr_compact, m, kp, nbr);
+  return launch_status();
+}
+
 int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_t num_offsets, const int32_t* counts,
                      const int32_t* offsets, int32_t* in_maps, int32_t* out_maps, int64_t pair_capacity, int32_t* status,
                      int32_t compact, wcn_stream_t stream) {
@@ -633,8 +725,7 @@ int wcn_kmap_scatter(const int32_t* nbr, const uint32_t* mask, int64_t m, int32_
   if (!nbr || !mask || !counts || !offsets || (pair_capacity > 0 && (!in_maps || !out_maps)))
     return WCN_ERROR_INVALID_PARAMETERS;
   const KsArgs q = ks_args(nbr, mask, m, num_offsets, counts, offsets, in_maps, out_maps, pair_capacity, status, compact ? 1 : 0);
-  hipLaunchKernelGGL(kmap_scatter_kernel, dim3((unsigned)ceil_div(m, kTileRows)), dim3(kBkThreads), kKsLds,
-                     (hipStream_t)stream, q);
+  launch_scatter(q, (hipStream_t)stream);
   return launch_status();
 }
 

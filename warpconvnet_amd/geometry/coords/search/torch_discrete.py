@@ -200,6 +200,9 @@ class BuildHints:
         self.pairs_per_row = float(pairs_per_row)  # kernel volumes not seen yet
         self._by_volume = {}                       # kernel volume -> pairs per row of its last maps
         self._dense_volumes = set()                # kernel volumes whose scenes overflowed a compact row (> 15 neighbours)
+        # what the guesses cost so far: builds the device sent back (block table too small, strict insert, dense rows) and
+        # speculative pair lists that were too short and written again at their exact length
+        self.stats = {"builds": 0, "rebuilds": 0, "pair_rewrites": 0}
 
     def compact_rows(self, num_offsets: int) -> bool:
         """First try of a submanifold build: compact 64-B table rows?  (Dense from then on once a scene has had a row with more
@@ -458,6 +461,7 @@ def generate_kernel_map(
                 state["strict"] = 1
             else:
                 return b, flags, rebuilt
+            hints.stats["rebuilds"] += 1
             b, rebuilt = launch(), True
 
     def attach_tables(result, b):
@@ -497,6 +501,7 @@ def generate_kernel_map(
         spec = b.get("spec_pairs")
         if spec is not None and spec[2] < pair_capacity:
             spec = None  # the optimistic capacity (pairs per row of earlier maps) was short: exact lists below
+            hints.stats["pair_rewrites"] += 1
         if spec is not None:
             # written speculatively right behind the mask sort: the first L entries are the lists.  A guess far above the
             # need (first build of a process) is copied to exact-size buffers instead of pinning the memory for the lifetime
@@ -538,6 +543,7 @@ def generate_kernel_map(
     spec = 0
     if optimistic and need_pairs and M > 0:
         spec = min(N, K * M) if prebuilt is not None else hints.pair_capacity(M, K)
+    hints.stats["builds"] += 1
     first = launch(spec)
     if optimistic:
         # The caller launches its forward kernel on these tables BEFORE the status word is read (`IntSearchResult.validate`
