@@ -359,3 +359,32 @@ def test_radius_search_cpu_matches_reference_golden(golden_dir, tag):
     np.testing.assert_array_equal(split.numpy(), gz[f"{tag}_split"])
     np.testing.assert_array_equal(idx.numpy(), gz[f"{tag}_index"])
     np.testing.assert_allclose(dist.numpy(), gz[f"{tag}_distance"], rtol=1e-6, atol=1e-7)
+
+
+def test_grad_slot_claim_survives_an_abandoned_backward():
+    """`dist.claim_grad_slot`: one producer per parameter and backward pass; a claim left behind by a pass that never reached
+    AccumulateGrad (`torch.autograd.grad`, an exception mid-backward) must not switch the slot off for the passes that follow."""
+    from warpconvnet_amd import dist as wdist
+
+    p = torch.nn.Parameter(torch.zeros(4))
+    p._wcn_grad_slot = torch.zeros(4)
+    got = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            got.append(wdist.claim_grad_slot(p) is not None)
+            got.append(wdist.claim_grad_slot(p) is not None)  # a second producer in the same pass
+            return g, None
+
+    x = torch.ones(4, requires_grad=True)
+    torch.autograd.grad(Probe.apply(x, p).sum(), x)   # no AccumulateGrad for p: the claim is never released
+    assert got == [True, False] and p._wcn_grad_claimed is not False
+    got.clear()
+    torch.autograd.grad(Probe.apply(x, p).sum(), x)   # a NEW backward pass: the stale claim is recognised
+    assert got == [True, False]
+    assert wdist.claim_grad_slot(p) is None           # outside a backward pass a held claim stays held

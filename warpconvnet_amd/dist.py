@@ -81,12 +81,28 @@ def claim_grad_slot(param) -> Optional[torch.Tensor]:
     parameter in this backward pass: with the parameter used by several nodes of one graph (weight tying, a block applied
     twice, siamese branches) ``param.grad`` is still None when every node runs - AccumulateGrad fires after ALL producers -
     so a second writer would overwrite the first and the engine would sum two aliases of the same memory (N x the last
-    gradient instead of the sum).  The claim is released by the post-accumulate hook, ``finish()`` and ``zero_grad()``."""
+    gradient instead of the sum).  The claim is released by the post-accumulate hook, ``finish()`` and ``zero_grad()``; it also
+    carries the id of the autograd graph task that made it, so a claim left behind by a backward pass that never reached
+    AccumulateGrad (``torch.autograd.grad``, an exception in the middle of a backward) is recognised as stale by the next pass
+    instead of silently switching the write-into-bucket path off for good."""
     slot = getattr(param, "_wcn_grad_slot", None)
-    if slot is None or param.grad is not None or getattr(param, "_wcn_grad_claimed", False):
+    if slot is None or param.grad is not None:
         return None
-    param._wcn_grad_claimed = True
+    task = _graph_task_id()
+    held = getattr(param, "_wcn_grad_claimed", False)
+    if held is not False and (task < 0 or held == ("task", task)):
+        return None  # claimed in THIS backward pass (or no way to tell the passes apart)
+    param._wcn_grad_claimed = ("task", task)
     return slot
+
+
+def _graph_task_id() -> int:
+    """Id of the autograd graph task being executed (-1 outside a backward pass / on builds without the accessor)."""
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    try:
+        return int(fn()) if fn is not None else -1
+    except Exception:  # pragma: no cover
+        return -1
 
 
 class GradientBuckets:

@@ -159,7 +159,10 @@ def reverse_tables(kmap: IntSearchResult, num_in: int) -> Tuple[Tensor, Tensor, 
                                _lib.stream_handle(dev)),
             "wcn_kmap_reverse",
         )
-        if getattr(kmap, "_stride_window", False) and kmap.in_maps_device.shape[0] == num_in:
+        # (the real pair count, not the length of the buffer: in_maps_device may be longer than the lists - an uninitialised tail
+        # must never become row ids)
+        if (getattr(kmap, "_stride_window", False) and int(kmap.offsets[-1]) == num_in
+                and kmap.in_maps_device.shape[0] == num_in):
             # a stride-window map (kernel_size == stride) pairs every input row with exactly one (output row, offset): the
             # reverse masks are one-hot, and the input side of the pair lists - rows grouped by offset, CSR order - already IS
             # a permutation of the input rows in which a tile meets one offset: no sort (3 launches per strided layer)

@@ -251,7 +251,8 @@ class _PointwiseBnAct(Function):
 
         y = narrow_rows(x, w, False, dtype=_lib.torch_dtype(plan.code)) if x.dtype == torch.float32 else dense_rows(x, w, False)
         if y is None:  # (shapes outside the streaming kernels: the vendor GEMM on a cast copy of the weight)
-            y = x @ (w[0] if w.dtype == x.dtype else w[0].to(x.dtype))
+            xc = x if x.dtype == _lib.torch_dtype(plan.code) else x.to(_lib.torch_dtype(plan.code))  # (fp32 rows under autocast)
+            y = xc @ (w[0] if w.dtype == xc.dtype else w[0].to(xc.dtype))
         out, stats = _bn_forward(plan, y, gamma, beta)
         ctx.save_for_backward(x, y, stats, gamma, w)  # (w: the parameter itself - no copy, and autograd's version check applies)
         ctx.plan, ctx.wdtype = plan, w.dtype

@@ -101,6 +101,8 @@ def narrow_rows(x: Tensor, weight3: Tensor, transposed: bool, bias: Optional[Ten
             or weight3.device != x.device or not _narrow_ok(kin, kout, _lib.dtype_code(out_dtype))):
         return None
     x = x.contiguous()
+    if x.data_ptr() & 15:  # (the kernel's 16-B / 8-B row loads: a contiguous view at an odd storage offset gets its own buffer)
+        x = x.clone()
     w = weight3.detach()
     if not w.is_contiguous():
         w = w.contiguous()
