@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs ON the GPU box (through gpurun): rocprofv3 kernel trace + separate PMC passes of the default bench command
 # (counters in their own runs, never combined with runtime / marker traces), summaries into gpurun_out/prof/ as text.
-# Usage: bash tools/collect_profiles.sh [round-tag, default r05]
-R=${1:-r05}
+# Usage: bash tools/collect_profiles.sh [round-tag, default r06]
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof
 CMD="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
