@@ -61,7 +61,11 @@ constexpr int kCsCIC = 64;         // input channels per step (one 128-B row pie
 //   CO =  64: RBW 2, WR 2 -> 4 waves, 128-row tile;  RBW 2, WR 1 -> 2 waves, 64-row tile (same weight traffic per row)
 template <int CO, int RBW_, int WR_>
 struct CsCfg {
+#ifdef WCN_CS_PAIR  // ablation build (round 6): two (offset, chunk) steps per barrier, four ring stages - profiles/r06_gemm_limits.md
+  static constexpr int D = 4;
+#else
   static constexpr int D = 2;                    // ring depth (deeper rings need counted waits)
+#endif
   static constexpr int WC = CO / 32;             // channel slices (waves across the output width)
   static constexpr int WR = WR_;                 // row groups
   static constexpr int RBW = RBW_;               // 32-row blocks per wave
@@ -397,6 +401,40 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       __syncthreads();
     };
 
+#ifdef WCN_CS_PAIR
+    // TWO steps per barrier: the rows and weight fragments of steps s+2, s+3 are requested while s, s+1 multiply
+    frag_t W0[4], W1[4], W2[4], W3[4];
+    int ka = -1, ca = 0, kb = -1, cb = 0, kc = -1, cc = 0, kd = -1, cd = 0;
+    bool hb, hc, hd;
+    next_step(ka, ca);
+    kb = ka; cb = ca;
+    hb = next_step(kb, cb);
+    issue_rows(0, ka, ca);
+    load_w(W0, ka, ca);
+    if (hb) { issue_rows(1, kb, cb); load_w(W1, kb, cb); }
+    for (;;) {
+      kc = hb ? kb : ka; cc = hb ? cb : ca;
+      hc = hb && next_step(kc, cc);
+      kd = kc; cd = cc;
+      hd = hc && next_step(kd, cd);
+      sync_step();
+      if (hc) { issue_rows(2, kc, cc); load_w(W2, kc, cc); }
+      if (hd) { issue_rows(3, kd, cd); load_w(W3, kd, cd); }
+      compute(W0, 0, ka);
+      if (hb) compute(W1, 1, kb);
+      if (!hc) break;
+      ka = hd ? kd : kc; ca = hd ? cd : cc;
+      const bool ha = hd && next_step(ka, ca);
+      kb = ka; cb = ca;
+      hb = ha && next_step(kb, cb);
+      sync_step();
+      if (ha) { issue_rows(0, ka, ca); load_w(W0, ka, ca); }
+      if (hb) { issue_rows(1, kb, cb); load_w(W1, kb, cb); }
+      compute(W2, 2, kc);
+      if (hd) compute(W3, 3, kd);
+      if (!ha) break;
+    }
+#else
     frag_t Wa[4], Wb[4];
     int k0 = -1, c0 = 0, k1 = -1, c1 = 0;
     next_step(k0, c0);
@@ -409,7 +447,11 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       CS_PROF(pa = CS_CLK());
       sync_step();  // stage 0 has landed for every wave; every wave is done reading stage 1
       CS_PROF(pw += CS_CLK() - pa; pa = CS_CLK());
+#ifdef WCN_CS_WFIRST  // ablation build (round 6): the L2-resident weight fragments requested in front of the row DMA
+      if (has1) { load_w(Wb, k1, c1); issue_rows(1, k1, c1); }
+#else
       if (has1) { issue_rows(1, k1, c1); load_w(Wb, k1, c1); }
+#endif
       CS_PROF(pi += CS_CLK() - pa; pa = CS_CLK());
       compute(Wa, 0, k0);
       CS_PROF(pc += CS_CLK() - pa; ++pn);
@@ -419,12 +461,17 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       CS_PROF(pa = CS_CLK());
       sync_step();
       CS_PROF(pw += CS_CLK() - pa; pa = CS_CLK());
+#ifdef WCN_CS_WFIRST
+      if (has0) { load_w(Wa, k0, c0); issue_rows(0, k0, c0); }
+#else
       if (has0) { issue_rows(0, k0, c0); load_w(Wa, k0, c0); }
+#endif
       CS_PROF(pi += CS_CLK() - pa; pa = CS_CLK());
       compute(Wb, 1, k1);
       CS_PROF(pc += CS_CLK() - pa; ++pn);
       if (!has0) break;
     }
+#endif
     CS_PROF(pt2 = CS_CLK());
   }
 
@@ -571,9 +618,15 @@ static int dispatch_cs(const void* in, const void* wp, void* out, const int32_t*
   // 238 / 272 (twice the weight traffic per row); CO = 64 with 2 waves x 64 rows 256 / 374 vs 4 waves x 128 rows 264 / 378
   // vs 2 waves x 128 rows 275 / 392.
   switch (cs_col_block(cout)) {
+#ifdef WCN_CS_PAIR  // (four ring stages and four weight-fragment sets: one wave per SIMD less)
+    case 64: return launch_cs<T, 64, 2, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+    case 96: return launch_cs<T, 96, 3, 1, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+    case 128: return launch_cs<T, 128, 4, 1, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+#else
     case 64: return launch_cs<T, 64, 2, 1, 4>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
     case 96: return launch_cs<T, 96, 3, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);  // 3 waves x 96 rows
     case 128: return launch_cs<T, 128, 4, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+#endif
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
 }
