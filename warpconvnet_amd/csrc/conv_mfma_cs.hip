@@ -85,8 +85,12 @@ struct CsCfg {
   static constexpr size_t OFF_ZERO = OFF_WMASK + 16;
   static constexpr size_t OFF_EPI = OFF_ZERO + 128;                     // bias / scale / shift, CO floats each
   static constexpr size_t LDS_BYTES = OFF_EPI + 3 * (size_t)CO * 4;
+  // compact table rows (kmap_cells.h) stay compact in LDS - [TILE][16] ints instead of the [TILE][28] slab - and everything behind
+  // the slab moves up: CO = 64 (dgrad of the headline layer) 24.4 -> 21.4 KB per workgroup = 7 instead of 6 workgroups per CU
+  static constexpr size_t SLAB_SAVED = (size_t)TILE * (kCsSlabPitch - 16) * 4;
+  static constexpr size_t LDS_BYTES_COMPACT = LDS_BYTES - SLAB_SAVED;
   static constexpr int OUT_PITCH = CO * 2 + 16;  // epilogue stage: +16 B keeps the b128 stage writes conflict-free
-  static_assert((size_t)TILE * OUT_PITCH <= OFF_ROWS, "the epilogue stage reuses the ring and the index slab");
+  static_assert((size_t)TILE * OUT_PITCH <= OFF_ROWS - SLAB_SAVED, "the epilogue stage reuses the ring and the index slab");
 };
 
 // ---- weight packing: [k][chunk][cs][s][lane][j], lane = (h << 5) | m ------------------------------------------------
@@ -160,13 +164,18 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   constexpr int kCsStageBytes = G::STAGE_BYTES;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // `mask` null with a table: `nbr` holds COMPACT rows (kmap_cells.h: 16 ints - the row's mask, then the neighbour rows of its set
+  // offsets in ascending k; written by wcn_kmap_build_binned) - 64 B per row instead of a 128-B table row plus a 128-B line for the
+  // 4 bytes of mask[perm[i]].  They stay compact in LDS: the row DMA derives its source row from (mask, k) on the fly.
+  const bool compact = mask == nullptr && nbr != nullptr;
+  const size_t shift = compact ? G::SLAB_SAVED : 0;                         // (launch_cs sizes the dynamic LDS accordingly)
   char* s_ring = smem;                                                     // [D][128 rows][128 B]
-  int32_t* s_nbr = reinterpret_cast<int32_t*>(smem + G::OFF_NBR);         // [TILE][SP]
-  int32_t* s_rows = reinterpret_cast<int32_t*>(smem + G::OFF_ROWS);       // [TILE]
-  uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem + G::OFF_MASK);     // [TILE]
-  uint32_t* s_wmask = reinterpret_cast<uint32_t*>(smem + G::OFF_WMASK);   // [4]: OR of the row masks per 32-row block
-  char* s_zero = smem + G::OFF_ZERO;                                       // 128 B of zeros
-  float* s_epi = reinterpret_cast<float*>(smem + G::OFF_EPI);             // [3][CO]: bias, scale, shift
+  int32_t* s_nbr = reinterpret_cast<int32_t*>(smem + G::OFF_NBR);         // [TILE][SP], or [TILE][16] compact rows
+  int32_t* s_rows = reinterpret_cast<int32_t*>(smem + G::OFF_ROWS - shift);       // [TILE]
+  uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem + G::OFF_MASK - shift);     // [TILE]
+  uint32_t* s_wmask = reinterpret_cast<uint32_t*>(smem + G::OFF_WMASK - shift);   // [4]: OR of the row masks per 32-row block
+  char* s_zero = smem + G::OFF_ZERO - shift;                                       // 128 B of zeros
+  float* s_epi = reinterpret_cast<float*>(smem + G::OFF_EPI - shift);             // [3][CO]: bias, scale, shift
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, n = lane & 31;
@@ -202,12 +211,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     s_epi[2 * CO + c] = epi.scale ? epi.shift[col0 + c] : 0.f;
   }
   __syncthreads();
-  // `mask` null with a table: `nbr` holds COMPACT rows (kmap_cells.h: 16 ints - the row's mask, then the neighbour rows of its set
-  // offsets in ascending k; written by wcn_kmap_build_binned) - 64 B per row instead of a 128-B table row plus a 128-B line for the
-  // 4 bytes of mask[perm[i]].  The rows are staged in the (still unused) ring and expanded into the [TILE][SP] index slab.
-  const bool compact = mask == nullptr && nbr != nullptr;
   if (compact) {
-    int32_t* s_c = reinterpret_cast<int32_t*>(s_ring);  // [TILE][16]
     constexpr int kIterC = (TILE * 4 + NT - 1) / NT;
     int32_t rr[kIterC];
     int4 vv[kIterC];
@@ -229,33 +233,17 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
 #pragma unroll
     for (int t = 0; t < kIterC; ++t) {
       const int e = tid + t * NT;
-      if (e < TILE * 4) reinterpret_cast<int4*>(s_c)[e] = vv[t];
-    }
-    __syncthreads();
-    constexpr int kVec = SP / 4;
-    for (int e = tid; e < TILE * kVec; e += NT) {
-      const int row = e / kVec, c = e - row * kVec;
-      uint32_t m = (uint32_t)s_c[row * 16];
-      if (__popc(m) > 15) m = 0u;  // (a row that did not fit: such a build is flagged ROW_OVERFLOW and redone with dense rows)
-      int at = row * 16 + 1 + __popc(m & ((1u << (4 * c)) - 1u));
-      int v[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bool has = (m >> (4 * c + t)) & 1u;
-        v[t] = has ? s_c[at] : -1;
-        at += has ? 1 : 0;
+      if (e >= TILE * 4) continue;
+      if ((e & 3) == 0) {  // word 0 of the row: its mask
+        // (a row that did not fit its compact row - more than 15 neighbours - belongs to a build that is flagged ROW_OVERFLOW and
+        // redone with dense rows: here it has no neighbours)
+        uint32_t m = (uint32_t)vv[t].x;
+        if (__popc(m) > 15) m = 0u;
+        vv[t].x = (int)m;
+        s_mask[e >> 2] = m;
+        if (m) atomicOr(&s_wmask[e >> 7], m);
       }
-      reinterpret_cast<int4*>(s_nbr + row * SP)[c] = make_int4(v[0], v[1], v[2], v[3]);
-    }
-    if (tid < TILE) {
-      uint32_t m = (uint32_t)s_c[tid * 16];
-      if (__popc(m) > 15) m = 0u;
-      s_mask[tid] = m;
-      if (m) atomicOr(&s_wmask[tid >> 5], m);
-    }
-    if (last_pieces < 8) {  // the ring must hold finite values where it is never written (see above): clear the staged ids again
-      __syncthreads();
-      for (int e = tid; e < TILE * 4; e += NT) reinterpret_cast<int4*>(s_c)[e] = make_int4(0, 0, 0, 0);
+      reinterpret_cast<int4*>(s_nbr)[e] = vv[t];
     }
   } else {
     {
@@ -333,13 +321,17 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     uint32_t boff[4];                                 // byte offset of k-slice s inside a staged row
 #pragma unroll
     for (int s = 0; s < 4; ++s) boff[s] = (uint32_t)(((2 * s + h) ^ sw) << 4);
-    const uint32_t zaddr = lds0 + (uint32_t)G::OFF_ZERO;
+    const uint32_t zaddr = lds0 + (uint32_t)(G::OFF_ZERO - shift);
     const uint32_t rowaddr = lds0 + (uint32_t)(rg * RBW * 32 + n) * 128u;  // + stage, + rb * 4096
     const char* wbase = reinterpret_cast<const char*>(wp) + (size_t)cs * 4096 + lane * 16;
     const size_t wstep = (size_t)WC * 4096;           // bytes of one (k, chunk) weight slab
     const uint32_t rowbytes = (uint32_t)cin * 2u;
     // DMA: lane covers row (lane >> 3) of an 8-row instruction, 16-B position (lane & 7); source piece = position ^ swizzle
     const uint32_t idxaddr = lds0 + (uint32_t)G::OFF_NBR + (uint32_t)((wave * G::DMA_ROWS + (lane >> 3)) * SP) * 4u;
+    const uint32_t cptaddr = lds0 + (uint32_t)G::OFF_NBR + (uint32_t)((wave * G::DMA_ROWS + (lane >> 3)) * 16) * 4u;  // compact rows
+    uint32_t mdma[G::DMA_INSTR];  // masks of the rows this lane requests (compact rows)
+#pragma unroll
+    for (int it = 0; it < G::DMA_INSTR; ++it) mdma[it] = compact ? s_mask[wave * G::DMA_ROWS + it * 8 + (lane >> 3)] : 0u;
     // (tile row >> 1) & 7 of the row a lane requests: (lane >> 4) + 4 * (instruction index + first instruction of the wave)
     const int first_odd = ((wave * G::DMA_ROWS) >> 3) & 1;
     const int piece_e = (lane & 7) ^ ((lane >> 4) + 4 * first_odd), piece_o = (lane & 7) ^ ((lane >> 4) + 4 * (1 - first_odd));
@@ -350,8 +342,17 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       if (!((dma_mask >> k) & 1u)) return;  // wave-uniform: none of this wave's 32 DMA rows has the offset
       const uint32_t dst = lds0 + (uint32_t)buf * kCsStageBytes + (uint32_t)wave_u * (G::DMA_ROWS * 128u);
       int32_t idx[G::DMA_INSTR];
+      if (compact) {  // the neighbour at offset k is word 1 + (set offsets below k) of the row
+        const uint32_t below = (1u << k) - 1u;
 #pragma unroll
-      for (int it = 0; it < G::DMA_INSTR; ++it) idx[it] = *(lds_i32_p)(uintptr_t)(idxaddr + (uint32_t)(k * 4 + it * 8 * SP * 4));
+        for (int it = 0; it < G::DMA_INSTR; ++it) {
+          const int32_t v = *(lds_i32_p)(uintptr_t)(cptaddr + (uint32_t)((it * 8 * 16 + 1 + __popc(mdma[it] & below)) * 4));
+          idx[it] = ((mdma[it] >> k) & 1u) ? v : -1;
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < G::DMA_INSTR; ++it) idx[it] = *(lds_i32_p)(uintptr_t)(idxaddr + (uint32_t)(k * 4 + it * 8 * SP * 4));
+      }
       const int npieces = chunk + 1 < nchunk ? 8 : last_pieces;  // pieces of this chunk that exist in the row
 #pragma unroll
       for (int it = 0; it < G::DMA_INSTR; ++it) {
@@ -578,8 +579,9 @@ static int launch_cs(const void* in, const void* wp, void* out, const int32_t* n
   });
   if (rc != WCN_SUCCESS) return rc;
   const int kp = wcn_kmap_row_pitch(K);
+  const size_t lds = (mask == nullptr && nbr != nullptr) ? G::LDS_BYTES_COMPACT : G::LDS_BYTES;  // (compact rows: a smaller slab)
   hipLaunchKernelGGL((gather_gemm_cs_kernel<T, CO, RBW, WR, MINW>), dim3((unsigned)ceil_div(n_out, G::TILE), (unsigned)(cout / CO)),
-                     dim3(G::NT), G::LDS_BYTES, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp,
+                     dim3(G::NT), lds, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp,
                      out32, cout);
   return launch_status();
 }
