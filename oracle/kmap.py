@@ -113,3 +113,36 @@ def stride_coords(coords, stride) -> Tuple[np.ndarray, np.ndarray]:
     first = np.empty(coords.shape[0], dtype=np.int32)
     cnt = int(_lib().oracle_stride_coords(_p(coords), coords.shape[0], _p(st), _p(out), _p(first)))
     return out[:cnt].copy(), first[:cnt].copy()
+
+
+def compact_rows(found: np.ndarray, pitch: int = 16):
+    """The COMPACT neighbour rows the product's binned builder writes for one-word masks (`warpconvnet_amd/csrc/kmap_cells.h`;
+    no reference counterpart - the reference keeps the dense `found_in_coord_index` [K, M] of `cuhash_kernel_map.cu:93-134`):
+    row m = [mask, ids of its SET offsets in ascending k ..., don't-care].  ``found``: the oracle's [K, M] table (-1 = absent).
+    Returns ``(rows [M, pitch] int32 with the don't-care words zeroed, mask [M] uint32, fits [M] bool)`` - a row with more
+    than ``pitch - 1`` neighbours does not fit (the product then rebuilds with dense rows)."""
+    K, M = found.shape
+    assert K <= 31
+    present = found >= 0
+    mask = (present.astype(np.uint32) << np.arange(K, dtype=np.uint32)[:, None]).sum(0).astype(np.uint32)
+    count = present.sum(0)
+    rows = np.zeros((M, pitch), np.int32)
+    rows[:, 0] = mask.view(np.int32)
+    rank = np.cumsum(present, 0) - 1  # position of offset k among the set offsets of its row
+    ks, ms = np.nonzero(present)
+    ok = rank[ks, ms] < pitch - 1
+    rows[ms[ok], 1 + rank[ks, ms][ok]] = found[ks, ms][ok]
+    return rows, mask, count <= pitch - 1
+
+
+def densify_rows(rows: np.ndarray, num_offsets: int) -> np.ndarray:
+    """Inverse of :func:`compact_rows` for rows that fit: the dense [M, K] table (-1 = absent)."""
+    M = rows.shape[0]
+    mask = rows[:, 0].view(np.uint32)
+    out = np.full((M, num_offsets), -1, np.int32)
+    at = np.ones(M, np.int64)
+    for k in range(num_offsets):
+        has = ((mask >> np.uint32(k)) & np.uint32(1)).astype(bool)
+        out[has, k] = rows[has, at[has]]
+        at += has
+    return out

@@ -191,3 +191,28 @@ def test_morton_and_pool_oracle_known_answers():
     np.testing.assert_array_equal(oser.sparse_reduce(f, im, om, 3, "min"), [[1, -2], [0, 0], [-4, 0.5]])
     np.testing.assert_array_equal(oser.sparse_reduce(f, im, om, 3, "sum"), [[4, 3], [0, 0], [-4, 0.5]])
     np.testing.assert_array_equal(oser.sparse_reduce(f, im, om, 3, "mean"), [[2, 1.5], [0, 0], [-4, 0.5]])
+
+
+def test_compact_rows_restatement_round_trips():
+    """`oracle.kmap.compact_rows` (the format of the product's compact neighbour table, checked against it on the GPU in
+    tests/test_gpu_kmap.py) is the inverse of `densify_rows` on rows that fit, flags the ones that do not, and agrees with the
+    oracle's own masks."""
+    from oracle import kmap as okmap
+    from tests.util import scene_u
+
+    c = scene_u(4000, 3)
+    r = okmap.kernel_map(c, c, (3, 3, 3))
+    rows, mask, fits = okmap.compact_rows(r["found"])
+    assert fits.all() and rows.shape == (len(c), 16)
+    np.testing.assert_array_equal(mask, r["mask"][:, 0])
+    np.testing.assert_array_equal(okmap.densify_rows(rows, 27).T, r["found"])
+    # a dense cube: interior rows have 27 neighbours and do not fit
+    g = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(5), indexing="ij"), -1).reshape(-1, 3)
+    cc = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+    rd = okmap.kernel_map(cc, cc, (3, 3, 3))
+    rows_d, mask_d, fits_d = okmap.compact_rows(rd["found"])
+    # 27 interior voxels (27 neighbours incl. themselves) + 6 x 9 face voxels (18) do not fit; edges (12) and corners (8) do
+    assert int((~fits_d).sum()) == 27 + 54
+    np.testing.assert_array_equal(mask_d, rd["mask"][:, 0])
+    ok_rows = np.nonzero(fits_d)[0]
+    np.testing.assert_array_equal(okmap.densify_rows(rows_d[ok_rows], 27), rd["found"].T[ok_rows])
