@@ -589,6 +589,34 @@ def timed_loop(step, args, dev, world):
     return elapsed, ms_half
 
 
+def multi_gpu_diag(dev, rank, world, params, iters=20):
+    """The first multi-GPU run is also the first RCCL run: make it self-diagnosing - which ranks took part (an all-gather of the
+    ranks), and what ONE gradient all-reduce of this step's size costs on its own (the step hides it behind the backward).
+    Collective: every rank calls it.  Also runs under gloo on CPU (`tests/test_dist_gloo.py`)."""
+    cuda = dev.type == "cuda"
+    seen = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64, device=dev))
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+    for _ in range(3):
+        dist.all_reduce(flat)
+    if cuda:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(flat)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+    else:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            dist.all_reduce(flat)
+        ms = (time.perf_counter() - t0) * 1e3 / iters
+    return {"ranks_seen": sorted(int(t.item()) for t in seen), "grad_allreduce_ms": round(ms, 4),
+            "grad_allreduce_bytes": int(flat.numel() * 4), "backend": str(dist.get_backend())}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -645,24 +673,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = N * world * args.steps / elapsed / 1e6
 
-    diag = None
-    if world > 1:
-        # the first multi-GPU run is also the first RCCL run: make it self-diagnosing - which ranks took part (all-gather), and
-        # what one gradient all-reduce of this step's size costs on its own (the step hides it behind the backward)
-        seen = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64, device=dev))
-        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
-        for _ in range(3):
-            dist.all_reduce(flat)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            dist.all_reduce(flat)
-        e1.record()
-        e1.synchronize()
-        diag = {"ranks_seen": sorted(int(t.item()) for t in seen), "grad_allreduce_ms": round(e0.elapsed_time(e1) / 20, 4),
-                "grad_allreduce_bytes": int(flat.numel() * 4), "backend": dist.get_backend()}
+    diag = multi_gpu_diag(dev, rank, world, params) if world > 1 else None
     result = None
     if rank == 0:
         result = report(args, dev, world, coords, feats, grad_out, offsets, conv, params, N, value, ms_per_step, second_half)

@@ -169,8 +169,9 @@ def _bench_worker(rank, world, init_file, out_dir):
     step, buckets = bench.make_step(dev, world, coords, feats, grad_out, offsets, conv, params, attach=_attach_oracle_map)
     assert buckets is not None and buckets.world == world
     elapsed, ms_half = bench.timed_loop(step, args, dev, world)
+    diag = bench.multi_gpu_diag(dev, rank, world, params, iters=2)  # (what the N > 1 line carries as `multi_gpu`)
     torch.save({"w": conv.weight.grad.clone(), "b": conv.bias.grad.clone(), "elapsed": elapsed, "ms_half": ms_half,
-                "n": coords.shape[0], "coords": coords.clone()}, os.path.join(out_dir, f"bench{rank}.pt"))
+                "n": coords.shape[0], "coords": coords.clone(), "diag": diag}, os.path.join(out_dir, f"bench{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -188,6 +189,9 @@ def test_bench_step_wiring_under_gloo():
         r0, r1 = torch.load(os.path.join(tmp, "bench0.pt")), torch.load(os.path.join(tmp, "bench1.pt"))
     assert not torch.equal(r0["coords"], r1["coords"])  # one scene per rank
     assert r0["elapsed"] == r1["elapsed"] > 0 and r0["ms_half"] > 0  # max over ranks, agreed
+    for r in (r0, r1):  # the self-diagnosis of the first multi-GPU run: every rank seen, one all-reduce of the gradient's size timed
+        assert r["diag"]["ranks_seen"] == [0, 1] and r["diag"]["backend"] == "gloo"
+        assert r["diag"]["grad_allreduce_bytes"] == 4 * (27 * 64 * 128 + 128) and r["diag"]["grad_allreduce_ms"] > 0
     torch.testing.assert_close(r0["w"], r1["w"], rtol=0, atol=0)
     torch.testing.assert_close(r0["b"], r1["b"], rtol=0, atol=0)
     # single process: the same two workloads, gradients averaged by hand
