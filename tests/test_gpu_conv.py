@@ -228,6 +228,34 @@ def test_a_row_with_more_than_15_neighbours_falls_back_to_dense_rows():
     np.testing.assert_array_equal(ks._nbr.cpu().numpy()[:, :27].T, rs["found"])
 
 
+def test_rows_with_exactly_15_neighbours_keep_their_last_id():
+    """The limit case of compact rows: 15 neighbours, the last of them NOT at the last kernel offset (so absent offsets are
+    probed after the row is full - an append that writes before it advances must not land on word 15), over many random
+    neighbour sets, several voxels per 8^3 block and blocks of more than 64 voxels (two probe passes)."""
+    from warpconvnet_amd.geometry.coords.search.torch_discrete import BuildHints, generate_kernel_map
+
+    rng = np.random.default_rng(15)
+    offs = np.stack(np.meshgrid(np.arange(-1, 2), np.arange(-1, 2), np.arange(-1, 2), indexing="ij"), -1).reshape(-1, 3)
+    pts = []
+    for i in range(200):  # isolated centres 4 apart, each with 14 random neighbours besides itself (14 + 1 = 15)
+        centre = np.array([4 * (i % 10), 4 * ((i // 10) % 10), 4 * (i // 100)]) + 2
+        others = rng.choice(np.delete(np.arange(27), 13), size=14, replace=False)
+        pts.append(centre[None])
+        pts.append(centre[None] + offs[others])
+    g = np.unique(np.concatenate(pts), axis=0)
+    rng.shuffle(g)
+    c = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+    r = okmap.kernel_map(c, c, (3, 3, 3))
+    counts = (r["found"] >= 0).sum(0)
+    assert counts.max() == 15 and (counts == 15).sum() >= 100
+    t = torch.from_numpy(c).to(_dev())
+    km = generate_kernel_map(t, t, (1, 1, 1), (3, 3, 3), hints=BuildHints())
+    assert km._nbrc is not None
+    np.testing.assert_array_equal(km._nbr.cpu().numpy()[:, :27].T, r["found"])
+    np.testing.assert_array_equal(km.in_maps.cpu().numpy(), r["in_maps"])
+    np.testing.assert_array_equal(km.out_maps.cpu().numpy(), r["out_maps"])
+
+
 @pytest.mark.parametrize("fused_block", [False, True])
 def test_the_training_forward_packs_both_weight_images(fused_block):
     """The module path (and the fused conv -> BatchNorm node) must reach the pair packer: grad mode is OFF inside

@@ -1,4 +1,4 @@
-"""Dev tool: per-wave phase times of cell_neighbors (needs kmap_binned.hip built with -DWCN_PROF)."""
+"""Dev tool: per-wave phase times of cell_neighbors (needs kmap_binned.hip built with -DWCN_PROF: make prof)."""
 import ctypes, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -14,17 +14,15 @@ lib.wcn_debug_read_bprof.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 for _ in range(3):
     km = generate_kernel_map(c, c, (1, 1, 1), (3, 3, 3))
 torch.cuda.synchronize()
-buf = np.zeros((4096, 8), dtype=np.uint64)
+buf = np.zeros((4096, 12), dtype=np.uint64)
 assert lib.wcn_debug_read_bprof(buf.ctypes.data, buf.nbytes) == 0
-p = buf[buf[:, 3] > 0].astype(np.int64)  # stamps of the LAST block every wave processed
-t0 = p[:, 0].min()
-print("waves sampled", len(p), "last-block span us", (p[:, 3].max() - t0) / 100.0)
-for a, b, nm in ((0, 1, "halo gather"), (1, 2, "own cells + enumerate + prefetch"), (2, 3, "probe")):
-    d = (p[:, b] - p[:, a]) / 100.0
-    print(f"  {nm:34s} mean {d.mean():6.2f} p50 {np.median(d):6.2f} p95 {np.percentile(d,95):6.2f}")
-life = (p[:, 3] - p[:, 0]) / 100.0
-print("  block life mean", life.mean(), "own_cnt mean", p[:, 4].mean(), "max", p[:, 4].max())
-st = (p[:, 5] - p[:, 5].min()) / 100.0
-en = (p[:, 3] - p[:, 5].min()) / 100.0
-print("  wave start percentiles [0,10,50,90,99,100]", np.percentile(st, [0, 10, 50, 90, 99, 100]).round(1))
-print("  wave end   percentiles [0,10,50,90,99,100]", np.percentile(en, [0, 10, 50, 90, 99, 100]).round(1))
+p = buf[buf[:, 11] > 0].astype(np.int64)
+nb = p[:, 8]
+print("waves", len(p), "blocks per wave mean", nb.mean(), "max", nb.max())
+t0 = p[:, 9].min()
+for i, nm in ((0, "wait at the loop top"), (1, "halo scatter"), (4, "own cells + enumerate"), (5, "flush previous rows"), (6, "gather issue (next block)"), (2, "head loads issue + fence"), (3, "probe")):
+    d = p[:, i] / 100.0
+    print(f"  {nm:36s} per wave {d.mean():6.2f} us   per block {(d / np.maximum(nb, 1)).mean():6.2f}")
+print("  prologue (kernel entry -> loop)      per wave", ((p[:, 10] - p[:, 9]) / 100.0).mean())
+print("  wave start percentiles [0,50,100]", np.percentile((p[:, 9] - t0) / 100.0, [0, 50, 100]).round(1))
+print("  wave end   percentiles [0,10,50,90,100]", np.percentile((p[:, 11] - t0) / 100.0, [0, 10, 50, 90, 100]).round(1))

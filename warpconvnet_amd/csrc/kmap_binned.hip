@@ -36,6 +36,12 @@ constexpr int kInsertSample = 8;  // cell_insert<0>: 1 voxel in 8 goes first (se
 // scene to the second pass, whose creation path is the expensive one: uniform 1 M scene 58.5 -> 53.4 us for the three insert launches, surface
 // scene 92 -> 76 us; 4 costs the sampled pass more than it saves: 60 / 70 us)
 constexpr int kInsertThreads = 512;
+constexpr int kRowBufPitch = 66;  // cell_neighbors<COMPACT>: LDS row buffer [16 words + 1 spare][66]
+constexpr int kRowBufInts = (kCompactPitch + 1) * kRowBufPitch;
+#ifndef WCN_NB_WPE
+#define WCN_NB_WPE 3
+#endif
+constexpr int kNbWavesPerSimd = WCN_NB_WPE;  // cell_neighbors<COMPACT>: register budget 512 / this
 constexpr int kNbThreads = 256;    // cell_neighbors: up to 4 independent waves per workgroup (fewer when the LDS grid is large)
 
 __device__ __forceinline__ int wrap_blk(int v) {  // wrap to the signed range of the block coordinate field
@@ -261,8 +267,9 @@ __global__ __launch_bounds__(256) void cell_finish_kernel(const BSlot* __restric
 }
 
 #ifdef WCN_PROF
-__device__ unsigned long long g_bprof[4096 * 8];
-#define BSTAMP(i) do { if ((threadIdx.x & 63) == 0 && gwave < 4096) g_bprof[gwave * 8 + (i)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_bprof[4096 * 12];
+// per wave: time accumulated up to stamp i from the previous stamp, over all the wave's blocks (slot 0: the wait at the loop top)
+#define BSTAMP(i) do { const unsigned long long now_ = wall_clock64(); prof_acc[i] += now_ - prof_prev; prof_prev = now_; } while (0)
 #else
 #define BSTAMP(i)
 #endif
@@ -278,7 +285,7 @@ __device__ unsigned long long g_bprof[4096 * 8];
 // neighbour stay unwritten.  A voxel with more than kCompactIds neighbours raises WCN_FLAG_ROW_OVERFLOW: the host rebuilds
 // with dense rows.
 template <int LPR, bool FAST, bool COMPACT>
-__global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t, const uint32_t* __restrict__ halo,
+__global__ __launch_bounds__(kNbThreads) __attribute__((amdgpu_waves_per_eu(kNbWavesPerSimd))) void cell_neighbors_kernel(CellTable t, const uint32_t* __restrict__ halo,
                                                                     CellGeom g, int K, int kp, int mw,
                                                                     int32_t* __restrict__ nbr,
                                                                     uint32_t* __restrict__ mask,
@@ -286,8 +293,13 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
   extern __shared__ int s_mem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* s_halo = reinterpret_cast<uint32_t*>(s_mem);
-  const int halo_pad = (g.halo_cells + 63) & ~63;  // whole 64-lane gather rounds
-  const int per_wave = g.cells + 4 + kCells / 2 + 8;  // ints: grid, null cell, own list (+ padding entries)
+  const int rounds = (g.halo_cells + 63) >> 6;  // 64-lane gather rounds
+  // The first 8 rounds of the halo list (all of a 3x3x3 kernel's) live in registers - the list is the same for every block -
+  // and only a larger halo (or the dense-row instantiations, which keep their registers for 6 waves a SIMD) reads it from LDS.
+  const bool halo_regs = COMPACT && rounds <= 8;
+  const int halo_pad = halo_regs ? 0 : rounds * 64;
+  // ints per wave: grid, null cell, own list (+ padding entries), COMPACT: the 64 rows being assembled
+  const int per_wave = g.cells + 4 + kCells / 2 + 8 + (COMPACT ? kRowBufInts : 0);
   int* s_grid = s_mem + halo_pad + wave * per_wave;
   // byte offsets (into s_grid) of the block's occupied cells, padded to whole probe trips with the NULL cell: a cell
   // behind the grid that holds -1, so the probe loop needs no bounds checks (row -1 = nothing stored)
@@ -307,7 +319,15 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
   // Software pipeline over the wave's blocks (stride nwaves).  While block i is probed out of LDS, the halo cells of
   // block i+1 (gathered with the neighbour ids that arrived during block i-1) and the neighbour ids + own 2 KB of block
   // i+2 are in flight: a block costs two dependent memory round trips, and a wave owns only two or three blocks.
-  const int rounds = (g.halo_cells + 63) >> 6;
+  uint32_t he[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = u * 64 + lane;
+    uint32_t e = COMPACT && idx < g.halo_cells ? halo[idx] : 0xFFFFFFFFu;
+    // no entry: neighbour slot 31 (never a block) and a dump cell behind the NULL cell, so the rounds need no validity checks
+    if (e == 0xFFFFFFFFu) e = (31u << 27) | (uint32_t)(g.cells + 1);
+    he[u] = e;
+  }
   auto load_head = [&](int seq, int& nb, int4& v0, int4& v1) {
     nb = -1;
     v0 = make_int4(-1, -1, -1, -1);
@@ -336,6 +356,25 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
       }
     }
   };
+  // rounds 0..7 out of the registers, branch-free: all the neighbour ids first (one LDS round trip for the 8 shuffles, where
+  // the loop above pays two dependent ones PER ROUND - in-kernel stamps: 2.4 us a block went into issuing these 8 loads), an
+  // absent neighbour block reads block 0 instead and is turned into "empty" when the value is scattered.
+  int nidv[8];
+  auto gather8 = [&](int nb) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) nidv[u] = __shfl(nb, (int)(he[u] >> 27));
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u < rounds) {
+        const int safe = nidv[u] < 0 ? 0 : nidv[u];
+        hv[u] = t.cells[(int64_t)safe * kCells + ((he[u] >> 16) & (kCells - 1))];
+      }
+  };
+  auto scatter8 = [&]() {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u < rounds) s_grid[he[u] & 0xFFFFu] = nidv[u] >= 0 ? hv[u] : -1;
+  };
   auto scatter_halo = [&](int r0) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -344,14 +383,60 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
         if (e != 0xFFFFFFFFu) s_grid[e & 0xFFFFu] = hv[u];
       }
   };
+  // COMPACT: 64 assembled rows ([word][lane], kRowBufPitch) -> the table, whole 64-B segments, 4 lanes per row; plus their
+  // masks.  Deferred for the last 64 voxels of a block: the wave waits for ALL its outstanding memory operations before it
+  // stages the next block (vmcnt counts stores too), so rows stored at the end of the probe exposed a full write round trip
+  // per block; stored after the next block's staging they - and the gathers issued behind them - have the whole probe of
+  // that block to complete.
+  int* s_rows = s_grid + g.cells + 4 + kCells / 2 + 8;
+  int pend_row = -1;
+  auto flush_rows = [&](int row) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (row >= 0) mask[row] = (uint32_t)s_rows[lane];  // the dense mask array (tally, sort); also clears the "unwritten" mark
+    const int piece = lane & 3;
+    int rid[4];
+    int4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rid[q] = __shfl(row, (lane >> 2) + 16 * q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = (lane >> 2) + 16 * q;
+      v[q].x = s_rows[(piece * 4 + 0) * kRowBufPitch + r];
+      v[q].y = s_rows[(piece * 4 + 1) * kRowBufPitch + r];
+      v[q].z = s_rows[(piece * 4 + 2) * kRowBufPitch + r];
+      v[q].w = s_rows[(piece * 4 + 3) * kRowBufPitch + r];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (rid[q] >= 0) {
+        if (FAST)
+          *reinterpret_cast<int4*>(reinterpret_cast<char*>(nbr) + (__umul24((uint32_t)rid[q], kCompactPitch * 4u) + (uint32_t)piece * 16u)) = v[q];
+        else
+          *reinterpret_cast<int4*>(nbr + (int64_t)rid[q] * kCompactPitch + piece * 4) = v[q];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the rows are reused by the next 64 voxels
+    __builtin_amdgcn_wave_barrier();
+  };
 #ifdef WCN_PROF
-  if (lane == 0 && gwave < 4096) g_bprof[gwave * 8 + 5] = wall_clock64();
+  if (lane == 0 && gwave < 4096) g_bprof[gwave * 12 + 9] = wall_clock64();
 #endif
-  if (seq < nblocks) gather(nb_c, 0);
+  if (seq < nblocks) {
+    if (halo_regs) gather8(nb_c);
+    else gather(nb_c, 0);
+  }
+#ifdef WCN_PROF
+  unsigned long long prof_prev = wall_clock64(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_blocks = 0;
+  const unsigned long long prof_loop0 = prof_prev;
+#endif
   for (; seq < nblocks; seq += nwaves) {
     BSTAMP(0);
+#ifdef WCN_PROF
+    ++prof_blocks;
+#endif
     // ---- halo cells into the grid (absent neighbour: empty) ----
-    scatter_halo(0);
+    if (halo_regs) scatter8();
+    else scatter_halo(0);
     for (int r0 = 8; r0 < rounds; r0 += 8) {  // kernels with a halo above 1: the rest of the list, not pipelined
       gather(nb_c, r0);
       scatter_halo(r0);
@@ -378,15 +463,75 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
     for (int z = 0; z < 8; ++z)
       if (vals[z] >= 0) s_own[at++] = (unsigned short)((cell0 + z) * 4);
     if (lane < 2 * kVoxPerIter) s_own[own_cnt + lane] = (unsigned short)(null_cell * 4);
+    BSTAMP(4);
+    if (COMPACT) {  // the previous block's last rows
+      flush_rows(pend_row);
+      pend_row = -1;
+    }
+    BSTAMP(5);
     // ---- advance the pipeline: gather for block i+1, head loads for block i+2 ----
     nb_c = nb_n; c0 = n0; c1 = n1;
-    if (seq + nwaves < nblocks) gather(nb_c, 0);
+    if (seq + nwaves < nblocks) {
+      if (halo_regs) gather8(nb_c);
+      else gather(nb_c, 0);
+    }
+    BSTAMP(6);
     load_head(seq + 2 * nwaves, nb_n, n0, n1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     BSTAMP(2);
-    // ---- answer the K probes of the block's voxels: one lane per (voxel, offset) ----
     const char* grid_bytes = reinterpret_cast<const char*>(s_grid);
+    if (COMPACT) {
+      // ---- compact rows: one lane per VOXEL, the K probes in a wave-uniform loop ----
+      // A lane appends the neighbours it finds to its row in LDS ([word][lane], word pitch 66: the appends of one k are
+      // conflict-free, the transposed read below is 2-way); then the wave writes the 64 rows out as whole 64-B segments,
+      // 4 lanes per row.  Per block: K LDS probes + 4 stores per 64 voxels, where one lane per (voxel, offset) took
+      // 16 trips of ~100 instructions (in-kernel stamps: 6.45 of the 8.3 us a block took were that loop).
+      // lane k holds the grid byte offset of kernel offset k
+      int delta_lane = 0;
+      if (lane < K) {
+        const int l = lane % g.kz, j = (lane / g.kz) % g.ky, i = lane / (g.kz * g.ky);
+        delta_lane = ((i - g.cx) * g.dx * g.px + (j - g.cy) * g.dy * g.py + (l - g.cz) * g.dz) * 4;
+      }
+      bool over = false;
+      char* rows_bytes = reinterpret_cast<char*>(s_rows);
+      const int origin4 = (g.hx * g.px + g.hy * g.py + g.hz) * 4;  // an interior cell: every probe from it stays in the grid
+      const uint32_t wp0 = (uint32_t)(kRowBufPitch + lane) * 4u, wp_max = (uint32_t)(kCompactPitch * kRowBufPitch + lane) * 4u;
+      for (int e0 = 0; e0 < own_cnt; e0 += 64) {
+        const bool live = e0 + lane < own_cnt;
+        // (a lane past the block's last voxel probes from the origin cell into its own column of the rows and stores nothing)
+        const int cell = live ? (int)s_own[e0 + lane] : origin4;
+        const int row = live ? *reinterpret_cast<const int*>(grid_bytes + cell) : -1;
+        // Branch-free append: the answer is ALWAYS written at the lane's write pointer, the pointer advances only past a
+        // neighbour (the word behind the last one holds a don't-care: a spare 17th word takes it when the row is full).  The
+        // pointer stops there: a row with more neighbours than fit is caught by the popcount below.  The mask is collected bit-reversed (one shift-or a probe).
+        uint32_t wp = wp0, rev = 0;
+        auto answer = [&](int f) {
+          *reinterpret_cast<int*>(rows_bytes + wp) = f;
+          const uint32_t h = f >= 0 ? 1u : 0u;
+          rev = (rev << 1) | h;
+          wp = min(wp + h * (uint32_t)(kRowBufPitch * 4), wp_max);
+        };
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {  // four probes in flight
+          int f[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            f[u] = *reinterpret_cast<const int*>(grid_bytes + cell + __builtin_amdgcn_readlane(delta_lane, k + u));
+#pragma unroll
+          for (int u = 0; u < 4; ++u) answer(f[u]);
+        }
+        for (; k < K; ++k) answer(*reinterpret_cast<const int*>(grid_bytes + cell + __builtin_amdgcn_readlane(delta_lane, k)));
+        const uint32_t m = __brev(rev) >> (32 - K);
+        over = over || (live && __popc(m) > kCompactIds);
+        s_rows[lane] = (int)m;
+        // every 64 rows but the block's last go out now; the last wait in LDS until the next block is staged (see flush_rows)
+        if (e0 + 64 < own_cnt) flush_rows(row);
+        else pend_row = row;
+      }
+      if (__any(over) && lane == 0) atomicOr(status, (int)WCN_FLAG_ROW_OVERFLOW);
+    } else
+    // ---- answer the K probes of the block's voxels: one lane per (voxel, offset) ----
     for (int kc = 0; kc < num_chunks; ++kc) {
       const int k = kc * LPR + sub;
       const bool k_real = k < K, k_store = k < kp;
@@ -415,36 +560,7 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
           bits_a = (uint32_t)(ball_a >> (vsel * LPR)) & ((1u << LPR) - 1u);
           bits_b = (uint32_t)(ball_b >> (vsel * LPR)) & ((1u << LPR) - 1u);
         }
-        if (COMPACT) {
-          // lane sub stores its answer at word 1 + (set offsets below sub) of the voxel's 64-B row, lane 31 (never a real offset:
-          // K <= 31) the mask at word 0: the ~5 active lanes of a voxel hit one 64-B segment.  (Round-6 measurement: compacting
-          // the 32 answers in registers first - one ds_permute per voxel pair, a full 64-B store by 16 lanes - cost MORE than the
-          // dense rows, 68.4 vs 62.9 us: the kernel pays per store instruction and per dependent LDS round trip, not per byte.)
-          const uint32_t below = (1u << sub) - 1u;
-          int word_a = 1 + __popc(bits_a & below), word_b = 1 + __popc(bits_b & below);
-          bool put_a = row_a >= 0 && found_a >= 0, put_b = row_b >= 0 && found_b >= 0;
-          const bool over = (put_a && word_a > kCompactIds) || (put_b && word_b > kCompactIds);
-          put_a = put_a && word_a <= kCompactIds;
-          put_b = put_b && word_b <= kCompactIds;
-          if (sub == 31) {
-            word_a = 0; word_b = 0;
-            found_a = (int)bits_a; found_b = (int)bits_b;
-            put_a = row_a >= 0; put_b = row_b >= 0;
-          }
-          if (__any(over) && lane == 0) atomicOr(status, (int)WCN_FLAG_ROW_OVERFLOW);
-          if (FAST) {
-            char* nbr_b = reinterpret_cast<char*>(nbr);
-            if (put_a) *reinterpret_cast<int*>(nbr_b + (__umul24((uint32_t)row_a, kCompactPitch * 4u) + (uint32_t)word_a * 4u)) = found_a;
-            if (put_b) *reinterpret_cast<int*>(nbr_b + (__umul24((uint32_t)row_b, kCompactPitch * 4u) + (uint32_t)word_b * 4u)) = found_b;
-          } else {
-            if (put_a) nbr[(int64_t)row_a * kCompactPitch + word_a] = found_a;
-            if (put_b) nbr[(int64_t)row_b * kCompactPitch + word_b] = found_b;
-          }
-          if (sub == 0) {  // the dense mask array (tally, sort); also clears the "unwritten" mark
-            if (row_a >= 0) mask[row_a] = bits_a;
-            if (row_b >= 0) mask[row_b] = bits_b;
-          }
-        } else if (FAST) {
+        if (FAST) {
           char* nbr_b = reinterpret_cast<char*>(nbr);
           char* mask_b = reinterpret_cast<char*>(mask);
           const uint32_t kp4 = (uint32_t)kp * 4u, mw4 = (uint32_t)mw * 4u, k4 = (uint32_t)k * 4u, w4 = (uint32_t)w0 * 4u;
@@ -472,13 +588,20 @@ __global__ __launch_bounds__(kNbThreads) void cell_neighbors_kernel(CellTable t,
         }
       }
     }
-#ifdef WCN_PROF
-    if (lane == 0 && gwave < 4096) g_bprof[gwave * 8 + 4] = own_cnt;
-#endif
     BSTAMP(3);
+
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the grid is rewritten for the next block
     __builtin_amdgcn_wave_barrier();
   }
+  if (COMPACT) flush_rows(pend_row);
+#ifdef WCN_PROF
+  if (lane == 0 && gwave < 4096) {
+    for (int i = 0; i < 8; ++i) g_bprof[gwave * 12 + i] = prof_acc[i];
+    g_bprof[gwave * 12 + 8] = prof_blocks;
+    g_bprof[gwave * 12 + 10] = prof_loop0;
+    g_bprof[gwave * 12 + 11] = wall_clock64();
+  }
+#endif
 }
 
 // prepare -> sampled insert -> insert -> finish: the cell table of `coords` (and the halo list / neighbour-block ids of geometry g)
@@ -559,16 +682,20 @@ int wcn_kmap_build_binned(const int32_t* coords, int64_t n, const int32_t ksize[
   const uint32_t cmask = (uint32_t)(capacity - 1);
 
   launch_cell_table(t, g, (const int4*)coords, n, compact ? (kCompactPitch | kCompactFlag) : kp, mw, nbr, mask, status, (int)strict, s);
-  const int halo_pad = (g.halo_cells + 63) & ~63;
+  const int halo_rounds = (g.halo_cells + 63) >> 6;
+  const int halo_pad = compact && halo_rounds <= 8 ? 0 : halo_rounds * 64;  // (compact rows: a list of up to 8 rounds lives in registers)
   // waves per workgroup: 4, fewer when halo list + one LDS grid per wave would not fit (halo 6..8: 20^3..24^3 cells)
   int nb_waves = kNbThreads / 64;
-  auto shm_for = [&](int waves) { return ((size_t)halo_pad + (size_t)waves * (g.cells + 4 + kCells / 2 + 8)) * 4; };
+  auto shm_for = [&](int waves) {
+    return ((size_t)halo_pad + (size_t)waves * (g.cells + 4 + kCells / 2 + 8 + (compact ? kRowBufInts : 0))) * 4;
+  };
   while (nb_waves > 1 && shm_for(nb_waves) > 156 * 1024) nb_waves >>= 1;
   const size_t shm = shm_for(nb_waves);
   if (shm > 160 * 1024) return WCN_ERROR_PROBLEM_NOT_SUPPORTED;
   // resident waves only (the loop strides over the blocks): LDS allows 160 KB / shm workgroups per CU
   int per_cu = (int)((160 * 1024) / (shm + 512));
   if (per_cu > 8) per_cu = 8;
+  if (compact && per_cu * nb_waves > 4 * kNbWavesPerSimd) per_cu = 4 * kNbWavesPerSimd / nb_waves;  // (amdgpu_waves_per_eu)
   if (per_cu < 1) per_cu = 1;
   int64_t want = ceil_div(max_blocks < n ? max_blocks : n, nb_waves);  // never more waves than blocks
   if (want > 256 * per_cu) want = 256 * per_cu;
