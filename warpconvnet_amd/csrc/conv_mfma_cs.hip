@@ -143,6 +143,8 @@ __global__ void pack_weight_cs_pair_kernel(const float* __restrict__ w, TD* __re
 // dev build (`make prof`, tools/prof_phases.py): thread 0 of every 4th workgroup stamps its phases - per slot: prologue, step
 // loop, epilogue clocks | 1 | steps | in-loop wait + barrier, request issue, LDS reads + MFMAs
 __device__ unsigned long long g_csprof[2048 * 8];
+// wall-clock start / end (100 MHz) and XCC_ID : HW_ID of every workgroup of the LAST launch (tools/prof_cs_timeline.py)
+__device__ unsigned long long g_cstime[16384 * 4];
 #define CS_CLK() __builtin_readcyclecounter()
 #define CS_PROF(stmt) do { if (cs_prof) { stmt; } } while (0)
 #else
@@ -188,6 +190,10 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
 #ifdef WCN_PROF
   const bool cs_prof = tid == 0 && (blockIdx.x & 3) == 0 && (blockIdx.x >> 2) < 2048;
   unsigned long long pt0 = CS_CLK(), pt1 = 0, pt2 = 0, pa = 0, pw = 0, pi = 0, pc = 0, pn = 0;
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 16384) {
+    g_cstime[blockIdx.x * 4] = wall_clock64();
+    g_cstime[blockIdx.x * 4 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
+  }
 #endif
 
   // ---- output row ids (through the mask-sorted permutation), masks, index slab ----
@@ -559,6 +565,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     }
   }
 #ifdef WCN_PROF
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 16384) g_cstime[blockIdx.x * 4 + 1] = wall_clock64();
   if (cs_prof) {
     unsigned long long* p = g_csprof + (size_t)(blockIdx.x >> 2) * 8;
     const unsigned long long pt3 = CS_CLK();
@@ -683,6 +690,9 @@ int pack_weight_cs_pair(const float* w, int K, int cin, int cout, int dtype, int
 #ifdef WCN_PROF
 extern "C" int wcn_debug_read_prof_cs(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wcn::g_csprof), bytes);
+}
+extern "C" int wcn_debug_read_time_cs(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wcn::g_cstime), bytes);
 }
 extern "C" int wcn_debug_reset_prof_cs(void) {
   static unsigned long long zeros[2048 * 8];

@@ -407,9 +407,11 @@ __global__ __launch_bounds__(kNbThreads) __attribute__((amdgpu_waves_per_eu(kNbW
       v[q].z = s_rows[(piece * 4 + 2) * kRowBufPitch + r];
       v[q].w = s_rows[(piece * 4 + 3) * kRowBufPitch + r];
     }
+    // a 16-B piece goes out only if the row reaches it (words 4p .. 4p+3 hold ids 4p-1 .. 4p+2): 5 - 6 neighbours a row on the
+    // scenes of the bench, so half of the pieces stay home
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (rid[q] >= 0) {
+      if (rid[q] >= 0 && __popc((uint32_t)s_rows[(lane >> 2) + 16 * q]) >= 4 * piece) {
         if (FAST)
           *reinterpret_cast<int4*>(reinterpret_cast<char*>(nbr) + (__umul24((uint32_t)rid[q], kCompactPitch * 4u) + (uint32_t)piece * 16u)) = v[q];
         else
