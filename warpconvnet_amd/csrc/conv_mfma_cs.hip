@@ -382,6 +382,10 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     };
     auto compute = [&](const frag_t (&w)[4], int buf, int k) {
       const uint32_t sbase = rowaddr + (uint32_t)buf * kCsStageBytes;
+      // ONE set of B fragments: the LDS reads of row block rb + 1 are issued behind the MFMAs of block rb and ride under their
+      // execution.  (Round 6: the double-buffered set - reads of rb + 1 in front of the MFMAs of rb - cost 27 VGPRs and bought
+      // nothing: forward 204.7 vs 203.6 us, dgrad 222.0 vs 229.0 us WITH the single set, same box; `-DWCN_CS_BDOUBLE`.)
+#ifdef WCN_CS_BDOUBLE
       frag_t b[2][4];
       if ((rb_mask[0] >> k) & 1u) load_b(b[0], sbase, 0, k);
 #pragma unroll
@@ -392,6 +396,17 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
           for (int s = 0; s < 4; ++s) acc[rb] = CFrag<T>::mfma(w[s], b[rb & 1][s], acc[rb]);
         }
       }
+#else
+      frag_t b[4];
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb) {
+        if ((rb_mask[rb] >> k) & 1u) {  // wave-uniform: some row of this block has the offset
+          load_b(b, sbase, rb, k);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[rb] = CFrag<T>::mfma(w[s], b[s], acc[rb]);
+        }
+      }
+#endif
     };
     // step iterator over (set bits of block_mask ascending) x (channel chunks)
     uint32_t rem = block_mask;
