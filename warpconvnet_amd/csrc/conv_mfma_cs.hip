@@ -82,7 +82,7 @@ struct CsCfg {
   static constexpr size_t OFF_ROWS = OFF_NBR + (size_t)TILE * kCsSlabPitch * 4;
   static constexpr size_t OFF_MASK = OFF_ROWS + (size_t)TILE * 4;
   static constexpr size_t OFF_WMASK = OFF_MASK + (size_t)TILE * 4;
-  static constexpr size_t OFF_ZERO = OFF_WMASK + 16;
+  static constexpr size_t OFF_ZERO = OFF_WMASK + 32;                   // (up to 8 row blocks)
   static constexpr size_t OFF_EPI = OFF_ZERO + 128;                     // bias / scale / shift, CO floats each
   static constexpr size_t LDS_BYTES = OFF_EPI + 3 * (size_t)CO * 4;
   // compact table rows (kmap_cells.h) stay compact in LDS - [TILE][16] ints instead of the [TILE][28] slab - and everything behind
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     s_rows[tid] = r;
   }
   if (tid < 8) reinterpret_cast<int4*>(s_zero)[tid] = make_int4(0, 0, 0, 0);
-  if (tid < 4) s_wmask[tid] = 0;
+  if (tid < 8) s_wmask[tid] = 0;
   if (last_pieces < 8) {
     // cin % 64 == 32: the upper half of the last chunk is never requested; it meets zero weights in the packed image, so it
     // only has to be FINITE - clear the ring once (uninitialised LDS may hold NaN patterns)
@@ -550,7 +550,8 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       int32_t orow[kBatch];
       frag_t ov[kBatch], rv[kBatch];
 #pragma unroll
-      for (int j = 0; j < kBatch; ++j) orow[j] = s_rows[wave * G::DMA_ROWS + (j0 + j) * kRowsPerInstr + rsub];
+      for (int j = 0; j < kBatch; ++j)
+        orow[j] = j0 + j < kStores ? s_rows[wave * G::DMA_ROWS + (j0 + j) * kRowsPerInstr + rsub] : -1;  // (kStores % kBatch != 0: 160-row tiles)
       if (epi.residual) {  // residual rows are read the way the output is written: whole rows, adjacent lanes, all in flight
 #pragma unroll
         for (int j = 0; j < kBatch; ++j)
@@ -560,8 +561,9 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       }
 #pragma unroll
       for (int j = 0; j < kBatch; ++j)
-        ov[j] = *reinterpret_cast<const frag_t*>(
-            smem + (size_t)(wave * G::DMA_ROWS + (j0 + j) * kRowsPerInstr + rsub) * G::OUT_PITCH + piece * 16);
+        if (j0 + j < kStores)
+          ov[j] = *reinterpret_cast<const frag_t*>(
+              smem + (size_t)(wave * G::DMA_ROWS + (j0 + j) * kRowsPerInstr + rsub) * G::OUT_PITCH + piece * 16);
 #pragma unroll
       for (int j = 0; j < kBatch; ++j) {
         if (orow[j] < 0 || piece >= kPieces) continue;
@@ -649,6 +651,8 @@ static int dispatch_cs(const void* in, const void* wp, void* out, const int32_t*
 #else
     case 64: return launch_cs<T, 64, 2, 1, 4>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
     case 96: return launch_cs<T, 96, 3, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);  // 3 waves x 96 rows
+    // (round 6, with the 27 VGPRs the single B-fragment set freed: 160-row tiles `<T, 128, 5, 1, 3>` - weight fragments per row
+    // -20 %, 166 VGPRs, 54.2 KB of LDS - run 244.6 vs 204.7 us: the third workgroup of a CU no longer fits)
     case 128: return launch_cs<T, 128, 4, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
 #endif
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
