@@ -301,10 +301,12 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
 #pragma unroll
   for (int q = 0; q < G::NBLK; ++q) block_mask |= s_wmask[q];
   block_mask = __builtin_amdgcn_readfirstlane(block_mask);
-  // the DMA instructions of this wave cover tile rows [32*wave, 32*wave + 32): OR of their masks (skip empty instructions)
+  // the DMA instructions of this wave cover tile rows [DMA_ROWS * wave, DMA_ROWS * (wave + 1)): OR of their blocks' masks (skip empty instructions)
   uint32_t dma_mask = 0u;
 #pragma unroll
-  for (int q = 0; q < (G::DMA_ROWS + 31) / 32; ++q) dma_mask |= s_wmask[(wave * G::DMA_ROWS) / 32 + q];
+  for (int q = 0; q <= (G::DMA_ROWS + 30) / 32; ++q)  // (rows that do not start on a block boundary reach one block further)
+    if ((wave * G::DMA_ROWS) / 32 + q < G::NBLK && (wave * G::DMA_ROWS) / 32 + q <= (wave * G::DMA_ROWS + G::DMA_ROWS - 1) / 32)
+      dma_mask |= s_wmask[(wave * G::DMA_ROWS) / 32 + q];
   dma_mask = __builtin_amdgcn_readfirstlane(dma_mask);
   // mask of the row this lane holds in the B fragment of row block rb
   uint32_t mrow[RBW];
@@ -649,11 +651,18 @@ static int dispatch_cs(const void* in, const void* wp, void* out, const int32_t*
     case 96: return launch_cs<T, 96, 3, 1, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
     case 128: return launch_cs<T, 128, 4, 1, 2>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
 #else
+    // (CO = 64, round 6 again: 4 waves x 64 rows `<64, 1, 2>` 251.8 us, 2 waves x 96 rows `<64, 3, 1>` 255.8 us, against 221.8)
     case 64: return launch_cs<T, 64, 2, 1, 4>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
     case 96: return launch_cs<T, 96, 3, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);  // 3 waves x 96 rows
-    // (round 6, with the 27 VGPRs the single B-fragment set freed: 160-row tiles `<T, 128, 5, 1, 3>` - weight fragments per row
-    // -20 %, 166 VGPRs, 54.2 KB of LDS - run 244.6 vs 204.7 us: the third workgroup of a CU no longer fits)
+    // CO = 128, round 6: 96-row tiles, FOUR workgroups a CU (122 VGPRs with the single B-fragment set, 32.6 KB) instead of 128-row
+    // tiles and three (141 VGPRs, 42.3 KB): 197.3 vs 200.3 us in the trace, 0.207 vs 0.212 ms in the step, surface scene 728.6 vs
+    // 730.1 M voxels/s (same box; `-DWCN_CS_RBW4` builds the old shape).  160-row tiles `<T, 128, 5, 1, 3>` - weight fragments per
+    // row -20 %, 166 VGPRs, 54.2 KB - run 244.6 us: the third workgroup of a CU no longer fits.
+#ifdef WCN_CS_RBW4
     case 128: return launch_cs<T, 128, 4, 1, 3>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+#else
+    case 128: return launch_cs<T, 128, 3, 1, 4>(in, wp, out, nbr, mask, perm, epi, n_out, cin, cout, K, out32, s);
+#endif
 #endif
     default: return WCN_ERROR_UNSUPPORTED_CONFIG;
   }
