@@ -274,16 +274,19 @@ __device__ unsigned long long g_bprof[4096 * 12];
 #define BSTAMP(i)
 #endif
 
-// One wave per block.  LDS: the halo gather list (shared by the workgroup), then per wave grid[g.cells] row ids
-// (-1 = empty) and own[512] u16 grid indices of the block's occupied cells.
+// One wave per block.  LDS: the halo gather list (shared by the workgroup; not for COMPACT with up to 8 rounds), then per wave
+// grid[g.cells] row ids (-1 = empty), own[512] u16 grid indices of the block's occupied cells and (COMPACT) the 64 rows being
+// assembled.
 // FAST: every byte offset into nbr / mask fits 31 bits and every row index 24 bits (n < 2^24, n * kp * 4 < 2^31): the
-// addresses of the probe loop are one full-rate 24-bit multiply-add instead of two quarter-rate 64-bit ones.
-// COMPACT (LPR == 32, one mask word): the voxel's row is 16 ints - its mask, then the neighbour rows of its SET offsets in
+// addresses of the stores are one full-rate 24-bit multiply-add instead of two quarter-rate 64-bit ones.
+// Dense rows (COMPACT = false): LPR lanes per voxel, one lane per (voxel, offset), masks by ballot, every lane stores its answer.
+// COMPACT (one mask word, 17 <= K <= 31): the voxel's row is 16 ints - its mask, then the neighbour rows of its SET offsets in
 // ascending k (kmap_cells.h: kCompactPitch) - instead of 32 columns of which 4 - 9 hold a neighbour on the scenes of the bench:
-// half the bytes for this kernel's stores and for every later reader of the table (pair scatter, both gather GEMMs).  Every
-// lane that found a neighbour stores it at its rank among the voxel's set offsets (ballot + popcount); words behind the last
-// neighbour stay unwritten.  A voxel with more than kCompactIds neighbours raises WCN_FLAG_ROW_OVERFLOW: the host rebuilds
-// with dense rows.
+// half the bytes for every later reader of the table (pair scatter, both gather GEMMs).  One lane per VOXEL probes the K offsets
+// and appends to its row in LDS; 64 rows leave as 16-B pieces, 4 lanes a row (see the probe section).  A voxel with more than
+// kCompactIds neighbours raises WCN_FLAG_ROW_OVERFLOW: the host rebuilds with dense rows.
+// Register budget: amdgpu_waves_per_eu(3) = 168 VGPRs (the compact path uses ~150); the host sizes the compact grid to exactly
+// the resident workgroups (3 waves a SIMD measured best: 58.3 us against 61.8 at 4 and 62.4 at 2).
 template <int LPR, bool FAST, bool COMPACT>
 __global__ __launch_bounds__(kNbThreads) __attribute__((amdgpu_waves_per_eu(kNbWavesPerSimd))) void cell_neighbors_kernel(CellTable t, const uint32_t* __restrict__ halo,
                                                                     CellGeom g, int K, int kp, int mw,
