@@ -30,7 +30,6 @@
 // MaskGemm_forward_64x64x32_1s_flat.h:287-296.
 #include <cstdlib>
 
-#include <atomic>
 #include "wcn_common.h"
 
 namespace wcn {
@@ -60,8 +59,6 @@ constexpr int kCsCIC = 64;         // input channels per step (one 128-B row pie
 // Workgroup shape: WC = CO / 32 channel slices x WR row groups waves; a wave holds RBW 32-row blocks of its 32 channels.
 //   CO = 128: RBW 4, WR 1 -> 4 waves, 128-row tile (RBW 2: 64-row tile, half the LDS, twice the weight traffic per row)
 //   CO =  64: RBW 2, WR 2 -> 4 waves, 128-row tile;  RBW 2, WR 1 -> 2 waves, 64-row tile (same weight traffic per row)
-constexpr int kCsTicketGroups = 32, kCsTicketStride = 32, kCsTicketSets = 256;
-
 template <int CO, int RBW_, int WR_>
 struct CsCfg {
 #ifdef WCN_CS_PAIR  // ablation build (round 6): two (offset, chunk) steps per barrier, four ring stages - profiles/r06_gemm_limits.md
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
                                                                 const uint32_t* __restrict__ mask,
                                                                 const int32_t* __restrict__ perm, const ConvEpilogue epi,
                                                                 int64_t n_out, int cin, int K, int kp,
-                                                                float* __restrict__ out32, int ldc, int32_t* __restrict__ tickets, int groups) {
+                                                                float* __restrict__ out32, int ldc) {
   // ldc: channels of an output (and residual) row; blockIdx.y: the CO-wide column block of it this workgroup produces
   typedef CsCfg<CO, RBW_, WR_> G;
   typedef typename CFrag<T>::type frag_t;
@@ -182,38 +179,22 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
   char* s_zero = smem + G::OFF_ZERO - shift;                                       // 128 B of zeros
   float* s_epi = reinterpret_cast<float*>(smem + G::OFF_EPI - shift);             // [3][CO]: bias, scale, shift
 
-  const int nchunk = (cin + kCsCIC - 1) / kCsCIC;
-  const int last_pieces = (cin - (nchunk - 1) * kCsCIC) / 8;  // 16-B pieces of the last chunk that exist (8, or 4 when cin % 64 == 32)
-  const int col0 = blockIdx.y * CO;  // first output channel of this column block
-  wp += (size_t)blockIdx.y * ((size_t)K * nchunk * kCsCIC * CO);
-  // tickets != null (launch_cs): the grid is one workgroup per resident slot and every workgroup walks tiles - no workgroup
-  // turnover between tiles (2.2 - 2.8 us of every 20 - 35 us slot life, profiles/r06_gemm_limits.md (d)).  The workgroups form
-  // `groups` groups (blockIdx % groups); group g owns the tiles j * groups + g, a workgroup's first j is its index in the group,
-  // every further j a ticket from the group's counter (its own 128-B line: one counter for all serialises at ~12 ns an atomic),
-  // drawn while the previous tile is computed.  The last workgroup to leave zeroes the counters for the next launch.
-  const int64_t ntiles = (n_out + TILE - 1) / TILE;
-  const int grp = tickets ? (int)(blockIdx.x % (unsigned)groups) : 0;
-  const int grp_wgs = tickets ? (int)(gridDim.x / (unsigned)groups) : 0;
-  __shared__ int s_next_j;
-#ifdef WCN_PROF
-  const bool cs_prof = threadIdx.x == 0 && (blockIdx.x & 3) == 0 && (blockIdx.x >> 2) < 2048;
-  unsigned long long pt0 = CS_CLK(), pt1 = 0, pt2 = 0, pa = 0, pw = 0, pi = 0, pc = 0, pn = 0;
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 16384) { g_cstime[blockIdx.x * 4] = wall_clock64(); g_cstime[blockIdx.x * 4 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804); }
-#endif
-  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  for (int64_t tile = tickets ? (int64_t)(blockIdx.x / (unsigned)groups) * groups + grp : (int64_t)blockIdx.x; tile < ntiles;) {
-  int drawn = 0;  // (thread 0) the ticket for the tile after this one, in flight under this tile's steps
-  if (tickets && threadIdx.x == 0)
-    drawn = __hip_atomic_fetch_add(tickets + grp * kCsTicketStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // (the thread's coordinates are re-derived per tile behind an opaque zero: hoisted out of the tile loop, the per-lane constants
-  // of the step loop stay live through prologue and epilogue and the kernel - at its register limit - spills 69 dwords a lane)
-  int opaque_zero;
-  asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
-  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)opaque_zero));
-  const int wave = wave_s, tid = wave * 64 + lane;  // (not from threadIdx.x: one VGPR less across the step loop)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, n = lane & 31;
   const int cs = wave % WC, rg = wave / WC;  // channel slice, row group
-  const int64_t row0 = tile * TILE;
+  const int nchunk = (cin + kCsCIC - 1) / kCsCIC;
+  const int last_pieces = (cin - (nchunk - 1) * kCsCIC) / 8;  // 16-B pieces of the last chunk that exist (8, or 4 when cin % 64 == 32)
+  const int64_t row0 = (int64_t)blockIdx.x * TILE;
+  const int col0 = blockIdx.y * CO;  // first output channel of this column block
+  wp += (size_t)blockIdx.y * ((size_t)K * nchunk * kCsCIC * CO);
+#ifdef WCN_PROF
+  const bool cs_prof = tid == 0 && (blockIdx.x & 3) == 0 && (blockIdx.x >> 2) < 2048;
+  unsigned long long pt0 = CS_CLK(), pt1 = 0, pt2 = 0, pa = 0, pw = 0, pi = 0, pc = 0, pn = 0;
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 16384) {
+    g_cstime[blockIdx.x * 4] = wall_clock64();
+    g_cstime[blockIdx.x * 4 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
+  }
+#endif
 
   // ---- output row ids (through the mask-sorted permutation), masks, index slab ----
   if (tid < TILE) {
@@ -222,18 +203,12 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     if (pr < n_out) r = perm ? perm[pr] : (int32_t)pr;
     s_rows[tid] = r;
   }
-<<<<<<< ours
   if (tid < 8) reinterpret_cast<int4*>(s_zero)[tid] = make_int4(0, 0, 0, 0);
   if (tid < 8) s_wmask[tid] = 0;
-=======
-  if (tid < 8) reinterpret_cast<int4*>(s_zero)[tid] = make_int4(opaque_zero, opaque_zero, opaque_zero, opaque_zero);
-  if (tid < 4) s_wmask[tid] = 0;  // (NBLK <= 4)
->>>>>>> theirs
   if (last_pieces < 8) {
     // cin % 64 == 32: the upper half of the last chunk is never requested; it meets zero weights in the packed image, so it
     // only has to be FINITE - clear the ring once (uninitialised LDS may hold NaN patterns)
-    for (int e = tid; e < (int)(G::OFF_NBR / 16); e += NT)
-      reinterpret_cast<int4*>(smem)[e] = make_int4(opaque_zero, opaque_zero, opaque_zero, opaque_zero);
+    for (int e = tid; e < (int)(G::OFF_NBR / 16); e += NT) reinterpret_cast<int4*>(smem)[e] = make_int4(0, 0, 0, 0);
   }
   // per-channel epilogue terms: requested first, used last (their latency is off the critical path)
   for (int c = tid; c < CO; c += NT) {
@@ -254,7 +229,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
 #pragma unroll
     for (int t = 0; t < kIterC; ++t) {
       const int e = tid + t * NT;
-      vv[t] = make_int4(opaque_zero, opaque_zero, opaque_zero, opaque_zero);  // (no row: mask 0)
+      vv[t] = make_int4(0, 0, 0, 0);  // (no row: mask 0)
       if (rr[t] >= 0) {  // read once: non-temporal
         typedef __attribute__((ext_vector_type(4))) int i32x4;
         const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(nbr + (int64_t)rr[t] * 16) + (e & 3));
@@ -342,7 +317,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
 #pragma unroll
   for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[rb][q] = (float)opaque_zero;
+    for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
 
   if (block_mask != 0u) {
     // per-lane constants (LDS addresses as plain 32-bit integers: no generic-pointer null checks in the loop)
@@ -540,7 +515,8 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
                                                         acc[rb][4 * v + 2] + bv.z, acc[rb][4 * v + 3] + bv.w);
       }
     }
-  } else {
+    return;
+  }
   __syncthreads();  // ring and index slab are dead: reuse them as the [TILE][OUT_PITCH] output stage
 #pragma unroll
   for (int rb = 0; rb < RBW; ++rb) {
@@ -569,7 +545,7 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
     constexpr int kLanesPerRow = kPieces <= 4 ? 4 : (kPieces <= 8 ? 8 : 16);  // lanes set aside per row (CO = 96: 12 of 16 work)
     constexpr int kRowsPerInstr = 64 / kLanesPerRow;
     constexpr int kStores = G::DMA_ROWS / kRowsPerInstr;  // every wave stores TILE / WAVES rows
-    constexpr int kBatch = kStores < 2 ? kStores : 2;     // rows in flight per lane (residual loads; 4 spill in the tile loop)
+    constexpr int kBatch = kStores < 4 ? kStores : 4;     // rows in flight per lane (residual loads)
     const int piece = lane % kLanesPerRow, rsub = lane / kLanesPerRow;
 #pragma unroll
     for (int j0 = 0; j0 < kStores; j0 += kBatch) {
@@ -607,40 +583,14 @@ __global__ __launch_bounds__(64 * (CO / 32) * WR_, MINW) void gather_gemm_cs_ker
       }
     }
   }
-  }  // (bf16 / fp16 output)
-  if (!tickets) break;
-  if (threadIdx.x == 0) s_next_j = grp_wgs + drawn;
-  __syncthreads();  // the ticket; and the output stage and the row ids are rewritten by the next tile
-  tile = (int64_t)s_next_j * groups + grp;
-  }
-  if (tickets && threadIdx.x == 0) {
-    int32_t* done = tickets + kCsTicketGroups * kCsTicketStride;
-    if (__hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-      for (int g = 0; g < groups; ++g) tickets[g * kCsTicketStride] = 0;  // every workgroup has drawn its last ticket
-      *done = 0;
-    }
-  }
 #ifdef WCN_PROF
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 16384) g_cstime[blockIdx.x * 4 + 1] = wall_clock64();
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 16384) g_cstime[blockIdx.x * 4 + 1] = wall_clock64();
   if (cs_prof) {
     unsigned long long* p = g_csprof + (size_t)(blockIdx.x >> 2) * 8;
     const unsigned long long pt3 = CS_CLK();
     p[0] += pt1 - pt0; p[1] += pt2 - pt1; p[2] += pt3 - pt2; p[3] += 1; p[4] += pn; p[5] += pw; p[6] += pi; p[7] += pc;
   }
 #endif
-}
-
-// Tile tickets of the resident-grid launches: kCsTicketSets sets (a launch takes the next one, so launches in flight on
-// different streams never share counters), each kCsTicketGroups counters + the exit counter, 128 B apart; all zero between launches.
-__device__ int32_t g_cs_tickets[kCsTicketSets * (kCsTicketGroups + 1) * kCsTicketStride];
-
-// WARPCONVNET_AMD_CS_PERSIST: 1 (default) = launches of more than two rounds of workgroups run as one resident round
-static int cs_persist() {
-  static const int v = [] {
-    const char* e = getenv("WARPCONVNET_AMD_CS_PERSIST");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
 }
 
 template <typename T, int CO, int RBW, int WR, int MINW>
@@ -655,40 +605,10 @@ static int launch_cs(const void* in, const void* wp, void* out, const int32_t* n
   });
   if (rc != WCN_SUCCESS) return rc;
   const int kp = wcn_kmap_row_pitch(K);
-  const bool compact = mask == nullptr && nbr != nullptr;
-  const size_t lds = compact ? G::LDS_BYTES_COMPACT : G::LDS_BYTES;  // (compact rows: a smaller slab)
-  const int64_t ntiles = ceil_div(n_out, G::TILE);
-  // resident workgroups of this instantiation (per LDS size), asked once per device
-  static int slots_cache[2][16];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  int& slots = slots_cache[compact ? 1 : 0][dev & 15];
-  if (slots == 0) {
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(gather_gemm_cs_kernel<T, CO, RBW, WR, MINW>),
-                                                     G::NT, lds) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
-      return WCN_ERROR_KERNEL_INITIALIZATION;
-    slots = per_cu * cus;
-  }
-  const int64_t col_blocks = cout / CO;
-  // resident grid + tile tickets: one column block, more than two rounds of workgroups
-  const bool persist = cs_persist() && col_blocks == 1 && ntiles > 2 * (int64_t)slots;
-  int64_t gx = ntiles;
-  int32_t* tickets = nullptr;
-  int groups = 1;
-  if (persist) {
-    groups = kCsTicketGroups;
-    while (slots % groups != 0) groups >>= 1;
-    gx = slots;
-    static std::atomic<unsigned> launch_seq{0};
-    int32_t* base = nullptr;
-    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_cs_tickets)) != hipSuccess) return WCN_ERROR_KERNEL_INITIALIZATION;
-    tickets = base + (size_t)(launch_seq.fetch_add(1) % kCsTicketSets) * (kCsTicketGroups + 1) * kCsTicketStride;
-  }
-  hipLaunchKernelGGL((gather_gemm_cs_kernel<T, CO, RBW, WR, MINW>), dim3((unsigned)gx, (unsigned)col_blocks),
+  const size_t lds = (mask == nullptr && nbr != nullptr) ? G::LDS_BYTES_COMPACT : G::LDS_BYTES;  // (compact rows: a smaller slab)
+  hipLaunchKernelGGL((gather_gemm_cs_kernel<T, CO, RBW, WR, MINW>), dim3((unsigned)ceil_div(n_out, G::TILE), (unsigned)(cout / CO)),
                      dim3(G::NT), lds, s, (const T*)in, (const T*)wp, (T*)out, nbr, mask, perm, epi, n_out, cin, K, kp,
-                     out32, cout, tickets, groups);
+                     out32, cout);
   return launch_status();
 }
 
